@@ -1,0 +1,281 @@
+#!/usr/bin/env python
+"""Benchmark of the GRU4Rec session-parallel training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one mini-batch of the reference's `train_function` (gru4rec.py:623) at BASELINE.json config #2:
+RSC15-shaped synthetic sessions (I = 37,483 items), layers=[100], batch=128, n_sample=2048, BPR-max,
+constrained embedding, Adagrad.  The timed region is K plan steps with the plan, weights and sample store
+already resident in HBM; it includes sample-store refills (as the reference's epoch timing does) and
+excludes plan building / upload.  metric = mini-batches/s exactly as gru4rec.py:661 prints it (steps / seconds);
+events/s is reported next to it.  For N > 1 (one process per GPU, launched by torch.distributed.run) sessions
+are sharded over ranks, dense GRU gradients are all-reduced by RCCL every step, value = sum over ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+A30_PUBLISHED_MBS = 1240.0   # BPR-max, layers=[100], batch 128, n_sample 2048 on an A30 (Theano)
+
+CONFIGS = {
+    # BASELINE.json configs[1]
+    'cfg2': dict(n_items=37483, layers=[100], batch_size=128, n_sample=2048, loss='bpr-max', final_act='elu-0.5',
+                 bpreg=1.0, learning_rate=0.1, momentum=0.0, sample_alpha=0.75, logq=0.0, dropout_p_embed=0.0,
+                 dropout_p_hidden=0.0, constrained_embedding=True),
+    # BASELINE.json configs[2] (Rees46 shape, HBM-bound gather)
+    'cfg3': dict(n_items=3000000, layers=[512], batch_size=240, n_sample=2048, loss='cross-entropy', final_act='softmax',
+                 bpreg=0.0, learning_rate=0.065, momentum=0.0, sample_alpha=0.5, logq=1.0, dropout_p_embed=0.45,
+                 dropout_p_hidden=0.0, constrained_embedding=True),
+    # BASELINE.json configs[4]
+    'cfg5': dict(n_items=37483, layers=[100, 100], batch_size=128, n_sample=2048, loss='top1-max', final_act='elu-0.5',
+                 bpreg=1.0, learning_rate=0.1, momentum=0.0, sample_alpha=0.75, logq=0.0, dropout_p_embed=0.2,
+                 dropout_p_hidden=0.0, constrained_embedding=True),
+}
+
+
+def algorithmic_cost(cfg):
+    """Per-launch algorithmic bytes / flops of the step kernels."""
+    B, ns, D = cfg['batch_size'], cfg['n_sample'], cfg['layers'][-1]
+    N, R = B + ns, 2 * B + ns
+    mom = 2 if cfg['momentum'] > 0 else 0
+    return {
+        # gradient row read + param r/w + accumulator r/w (+ velocity r/w) per occurrence, By path, index list
+        'k_sparse_update': dict(bound='hbm', bytes=(5 + mom) * R * D * 4 + 5 * N * 4 + R * 4),
+        # gathered Wy rows + h + score write ; 2*B*D*N flops
+        'k_score_fwd': dict(bound='mfma', flops=2.0 * B * D * N, bytes=N * D * 4 + B * D * 4 + B * N * 4),
+        # dSy = ds^T h and dh = ds Sy
+        'k_score_bwd': dict(bound='mfma', flops=4.0 * B * D * N, bytes=2 * B * N * 4 + 2 * N * D * 4 + B * D * 4),
+        'k_loss_rows': dict(bound='hbm', bytes=2 * B * N * 4),
+        'k_gru_fwd': dict(bound='mfma', flops=2.0 * B * 6 * D * D, bytes=B * D * 4 * 6 + 6 * D * D * 4),
+        'k_gru_bwd_rows': dict(bound='mfma', flops=2.0 * B * 4 * D * D, bytes=B * D * 4 * 8 + 4 * D * D * 4),
+        'k_dense_grad': dict(bound='mfma', flops=2.0 * B * 6 * D * D, bytes=B * D * 4 * 6 + 3 * 6 * D * D * 4),
+    }
+
+
+PEAK = {'hbm': (8000.0, 'GB/s'), 'mfma': (157.3, 'TFLOP/s')}   # MI355X_MICROARCH.md: HBM3E 8 TB/s, fp32 MFMA 157.3 TF
+
+
+def make_plan(cfg, n_steps, rank, nranks, seed=42):
+    """RSC15-shaped sessions -> (plan, number of sessions).  Enough sessions for n_steps full-batch steps."""
+    from gru4rec_amd import _native, synth
+    B = cfg['batch_size']
+    n_sessions = int(n_steps * B / 2.6) + 8 * B           # ~2.9 scoring events per session
+    n_items = min(cfg['n_items'], 200000)
+    data = synth.make_sessions(n_sessions * nranks, n_items=n_items, seed=seed)
+    sizes = data.groupby('SessionId').size().values
+    offs = np.zeros(len(sizes) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(sizes)
+    ids, inv = np.unique(data.ItemId.values, return_inverse=True)
+    items_all = inv.astype(np.int32)
+    if cfg['n_items'] > n_items:
+        # spread the item ids over the full catalogue (large-table configs): a fixed random injection
+        rng = np.random.RandomState(seed + 1)
+        spread = np.sort(rng.choice(cfg['n_items'], size=len(ids), replace=False)).astype(np.int32)
+        items_all = spread[items_all]
+    mine = np.arange(rank, len(sizes), nranks)
+    lens = sizes[mine]
+    sub_off = np.zeros(len(mine) + 1, dtype=np.int32)
+    sub_off[1:] = np.cumsum(lens)
+    idx = np.concatenate([np.arange(offs[s], offs[s + 1]) for s in mine])
+    items = items_all[idx]
+    support = np.bincount(items_all, minlength=cfg['n_items']).astype(np.float64) + 1.0
+    plan = _native.build_plan(sub_off, np.arange(len(mine)), items, B, cfg['n_sample'])
+    return plan, support
+
+
+def create_model(cfg, support, rank, nranks, device, unique_id, use_graph=True, seed=12345):
+    from gru4rec_amd import _native
+    from gru4rec_amd.gru4rec import _parse_act
+    fa = _parse_act(cfg['final_act'], True)
+    m = _native.Model(
+        n_items=cfg['n_items'], layers=cfg['layers'], batch_size=cfg['batch_size'], n_sample=cfg['n_sample'],
+        loss=_native.LOSS_IDS[cfg['loss']], final_act=fa[0], final_act_p0=fa[1], final_act_p1=fa[2],
+        hidden_act=_native.ACT_IDS['tanh'], embed_mode=_native.EMBED_CONSTRAINED, embedding=0,
+        learning_rate=cfg['learning_rate'], momentum=cfg['momentum'], lmbd=0.0, bpreg=cfg['bpreg'], logq=cfg['logq'],
+        sample_alpha=cfg['sample_alpha'], dropout_p_hidden=cfg['dropout_p_hidden'],
+        dropout_p_embed=cfg['dropout_p_embed'], sample_store=10000000, seed=seed + 7919 * rank, device=device,
+        rank=rank, nranks=nranks, use_graph=1 if use_graph else 0)
+    if nranks > 1:
+        m.comm_init(unique_id, nranks, rank)
+    # reference initialisation (gru4rec.py:252-294): uniform(-s, s), s = sqrt(6 / (fan_in + fan_out)) per block
+    rng = np.random.RandomState(42)
+
+    def init(shape):
+        s = np.sqrt(6.0 / (shape[0] + shape[1]))
+        return (rng.rand(*shape) * 2 * s - s).astype(np.float32)
+    L = cfg['layers']
+    for i, D in enumerate(L):
+        n_in = L[i - 1] if i > 0 else L[-1]
+        m.set_param('Wx', np.hstack([init((n_in, D)) for _ in range(3)]), i)
+        m.set_param('Wh', init((D, D)), i)
+        m.set_param('Wrz', np.hstack([init((D, D)) for _ in range(2)]), i)
+    m.set_param('Wy', init((cfg['n_items'], L[-1])))
+    pop = support ** cfg['sample_alpha']
+    pop = pop.cumsum() / pop.sum()
+    pop[-1] = 1
+    lq_t = lq_s = None
+    if cfg['logq']:
+        p0 = support.astype(np.float32)
+        lq_t, lq_s = np.log(p0), np.log(p0 ** np.float32(cfg['sample_alpha']))
+    m.set_popularity(pop.astype(np.float32), lq_t, lq_s)
+    return m
+
+
+def cpu_baseline(cfg, plan, support, budget_s=15.0):
+    """The NumPy oracle (CPU restatement of the reference step; Theano itself is not installable) timed on
+    this box's host cores over the first steps of the same plan."""
+    from oracle.model import OracleGRU4Rec
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count()
+    o = OracleGRU4Rec(n_items=cfg['n_items'], layers=tuple(cfg['layers']), batch_size=cfg['batch_size'],
+                      loss=cfg['loss'], final_act=cfg['final_act'], n_sample=cfg['n_sample'],
+                      sample_alpha=cfg['sample_alpha'], learning_rate=cfg['learning_rate'], momentum=cfg['momentum'],
+                      bpreg=cfg['bpreg'], logq=cfg['logq'], dropout_p_hidden=cfg['dropout_p_hidden'],
+                      dropout_p_embed=cfg['dropout_p_embed'], constrained_embedding=True)
+    o.set_popularity(support)
+    o.make_sample_store(cfg['n_sample'] * 64)       # a short store: the refill cost is not what is being timed
+    for t in range(3):
+        o.train_step(plan['in_idx'][t], plan['out_idx'][t], int(plan['M'][t]), plan['reset'][t])
+    t0 = time.time()
+    n = ev = 0
+    t = 3
+    while time.time() - t0 < budget_s and t < plan['T']:
+        M = int(plan['M'][t])
+        o.train_step(plan['in_idx'][t], plan['out_idx'][t], M, plan['reset'][t])
+        n += 1
+        ev += M
+        t += 1
+    dt = time.time() - t0
+    return dict(value=n / dt, unit='mini-batches/s', cores=int(threads), kind='port',
+                sample='%d steps (%d events) of the same plan, NumPy/BLAS fp32 oracle, %.1f s' % (n, ev, dt),
+                events_per_s=ev / dt, host_cpus=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=6000)
+    ap.add_argument('--warmup', type=int, default=600)
+    ap.add_argument('--config', default='cfg2', choices=sorted(CONFIGS))
+    ap.add_argument('--profile-steps', type=int, default=300)
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('WORLD_SIZE (%d) != --gpus (%d)' % (world, args.gpus))
+    from gru4rec_amd import _native
+    if _native.device_count() <= 0:
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    dist = None
+    unique_id = None
+    if world > 1:
+        # torch.distributed is control plane only (rendezvous, barrier, max-reduce); the data path is RCCL inside the library
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+        obj = [_native.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(obj, src=0)
+        unique_id = obj[0]
+    n_profile = args.profile_steps if (rank == 0 and world == 1) else 0
+    total_steps = args.warmup + args.steps + n_profile + 8
+    plan, support = make_plan(cfg, total_steps, rank, world)
+    assert plan['T'] >= total_steps, 'synthetic plan too short: %d < %d' % (plan['T'], total_steps)
+    assert (plan['M'][:total_steps] == cfg['batch_size']).all()
+    m = create_model(cfg, support, rank, world, local_rank if world > 1 else 0, unique_id, use_graph=not args.no_graph)
+    for k in ('in_idx', 'out_idx', 'reset', 'M'):
+        plan[k] = plan[k][:total_steps]
+    plan['T'] = total_steps
+    plan['n_compact'] = 0
+    m.set_plan(plan)
+    m.reset_hidden()
+    m.train_steps(0, args.warmup)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+    barrier()
+    t0 = time.perf_counter()
+    m.train_steps(args.warmup, args.steps)        # synchronous at return (hipStreamSynchronize inside)
+    dt = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    losses = m.get_losses(args.warmup, args.steps)
+    events = int(plan['M'][args.warmup:args.warmup + args.steps].sum()) * world
+    out = {
+        'metric': 'mini-batches/sec (gru4rec.py:661), RSC15-shaped batch=128 n_sample=2048 BPR-max',
+        'value': args.steps * world / dt, 'unit': 'mini-batches/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': (args.steps * world / dt) / A30_PUBLISHED_MBS if args.config == 'cfg2' else None,
+        'baseline_note': 'BASELINE.md: ~1240 mb/s, Theano on an NVIDIA A30 (closest published point; no MI355X number exists)',
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE.json configs[1]: RSC15-shaped synthetic sessions (%d items), layers=%s, batch=%d, '
+                               'n_sample=%d, %s, constrained_embedding, Adagrad' % (
+                                   cfg['n_items'], cfg['layers'], cfg['batch_size'], cfg['n_sample'], cfg['loss'])
+                   if args.config == 'cfg2' else args.config,
+                   'global_batch': cfg['batch_size'] * world, 'parallelism': 'session-sharded dp%d' % world,
+                   'hip_graph': not args.no_graph},
+        'events_per_s': events / dt, 'loss_first': float(losses[0]), 'loss_last': float(losses[-1]),
+        'loss_finite': bool(np.isfinite(losses).all()),
+    }
+    if rank == 0 and world == 1:
+        # per-kernel durations: HIP events on the library's own stream, eager launches over the next plan steps
+        m.profile(True)
+        m.train_steps(args.warmup + args.steps, n_profile)
+        m.profile(False)
+        kt = m.kernel_times()
+        alg = algorithmic_cost(cfg)
+        kern = {}
+        for name, (ms, n) in kt.items():
+            us = 1000.0 * ms / n
+            e = {'avg_us': us, 'launches_per_step': n / n_profile}
+            a = alg.get(name)
+            if a:
+                per = n / n_profile
+                if a['bound'] == 'hbm':
+                    e.update(bound='hbm', achieved=a['bytes'] / per / (us * 1e-6) / 1e9, unit='GB/s')
+                else:
+                    e.update(bound='mfma', achieved=a['flops'] / per / (us * 1e-6) / 1e12, unit='TFLOP/s',
+                             bytes_GBps=a['bytes'] / per / (us * 1e-6) / 1e9)
+                e['frac'] = e['achieved'] / PEAK[e['bound']][0]
+            kern[name] = e
+        out['kernels'] = kern
+        out['kernel_time_sum_us_per_step'] = sum(1000.0 * ms / n_profile for ms, n in kt.values())
+        # the roofline entry: the embedding gather/scatter kernel north_star names (HBM-bound)
+        k = kern.get('k_sparse_update')
+        if k:
+            out['roofline'] = {'kernel': 'k_sparse_update', 'bound': 'hbm', 'achieved': k['achieved'], 'peak': 8000.0,
+                               'unit': 'GB/s', 'frac': k['achieved'] / 8000.0, 'traffic': None,
+                               'note': 'algorithmic bytes per launch = %d (gradient rows + param/accumulator r/w per occurrence); '
+                                       'the 15 MB table is Infinity-Cache resident at this config' % alg['k_sparse_update']['bytes']}
+        dom = max(kern.items(), key=lambda kv: kv[1]['avg_us'] * kv[1]['launches_per_step'])
+        out['dominant_kernel'] = dom[0]
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg, plan, support)
+    if rank == 0:
+        print(json.dumps(out))
+    m.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,28 @@
+"""Builds gru4rec_amd/libgru4rec_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, 'csrc', 'g4r_api.hip')
+OUT = os.path.join(HERE, 'libgru4rec_hip.so')
+DEPS = [os.path.join(HERE, 'csrc', f) for f in ('g4r_api.hip', 'g4r_device.cuh', 'g4r_train_kernels.cuh',
+                                                 'g4r_eval_kernels.cuh')] + \
+       [os.path.join(os.path.dirname(HERE), 'include', 'gru4rec_hip.h')]
+
+
+def build(force=False, verbose=False):
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+        return OUT
+    rocm = os.environ.get('ROCM_PATH', '/opt/rocm')
+    cmd = [os.path.join(rocm, 'bin', 'hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+           '-I' + os.path.join(rocm, 'include'), '-o', OUT, SRC, '-L' + os.path.join(rocm, 'lib'), '-lrccl',
+           '-Wl,-rpath,' + os.path.join(rocm, 'lib')]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,841 @@
+// libgru4rec_hip.so -- host side of the C ABI declared in include/gru4rec_hip.h.
+// Owns device memory, the HIP stream, the captured step graph and the (optional) RCCL communicator.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "g4r_eval_kernels.cuh"
+
+static thread_local std::string g_err;
+static int fail(const std::string& s) { g_err = s; return -1; }
+#define HIPCHK(x)                                                                                        \
+    do {                                                                                                 \
+        hipError_t e_ = (x);                                                                             \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(std::string(#x) + ": " + hipGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
+    } while (0)
+#define NCCLCHK(x)                                                                                         \
+    do {                                                                                                   \
+        ncclResult_t e_ = (x);                                                                             \
+        if (e_ != ncclSuccess)                                                                             \
+            return fail(std::string(#x) + ": " + ncclGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
+    } while (0)
+
+enum { KN_GRU_FWD = 0, KN_SCORE_FWD, KN_LOSS, KN_SCORE_BWD, KN_GRU_BWD, KN_DENSE, KN_ALLREDUCE, KN_DENSE_APPLY,
+       KN_SPARSE, KN_COUNT };
+static const char* KN_NAMES[KN_COUNT] = {"k_gru_fwd", "k_score_fwd", "k_loss_rows", "k_score_bwd", "k_gru_bwd_rows",
+                                         "k_dense_grad", "rccl_allreduce", "k_dense_apply", "k_sparse_update"};
+
+struct g4r_model {
+    g4r_config cfg;
+    DevModel dm;
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;
+    // plan
+    int *d_in = nullptr, *d_out = nullptr, *d_M = nullptr, *d_cmaps = nullptr;
+    unsigned char* d_reset = nullptr;
+    float* d_loss = nullptr;
+    int64_t T = 0, loss_cap = 0;
+    std::vector<int64_t> compact_steps;
+    // samples
+    int* d_ST = nullptr;
+    float *d_P = nullptr, *d_lqt = nullptr, *d_lqs = nullptr;
+    int64_t gl = 0;
+    bool store_frozen = false, have_pop = false;
+    unsigned refills = 0;
+    int64_t gstep = 0;
+    // launch geometry
+    DenseTile* d_tiles = nullptr;
+    int ntiles = 0, tn = 32, nwavesA = 0, nblkA = 0, nblkB = 0, nblk_occ = 0;
+    size_t smem_gru_fwd[G4R_MAX_LAYERS], smem_gru_bwd[G4R_MAX_LAYERS], smem_score = 0, smem_loss = 0;
+    float* d_tmpH = nullptr;
+    // graph
+    hipGraphExec_t gexec = nullptr;
+    int graph_steps = 0;
+    // profiling
+    bool profiling = false;
+    double kn_ms[KN_COUNT] = {0};
+    int64_t kn_n[KN_COUNT] = {0};
+    std::vector<hipEvent_t> evs;
+    // prediction
+    int pbatch = 0, ppar = 0;
+    float* pH[G4R_MAX_LAYERS][2] = {{nullptr}};
+    float* phout[G4R_MAX_LAYERS] = {nullptr};
+    int *p_in = nullptr, *p_items = nullptr, *p_tgt = nullptr, *p_keep = nullptr;
+    unsigned char* p_zero = nullptr;
+    float *p_scores = nullptr, *p_ranks = nullptr;
+    int64_t p_scores_cap = 0, p_items_cap = 0, p_nsel = 0, p_ldo = 0;
+    // rccl
+    ncclComm_t comm = nullptr;
+    bool comm_ready = false;
+};
+
+template <class T>
+static int dalloc(g4r_model* m, T** p, size_t n, bool zero = true) {
+    void* q = nullptr;
+    if (n == 0) n = 1;
+    HIPCHK(hipMalloc(&q, n * sizeof(T)));
+    if (zero) HIPCHK(hipMemsetAsync(q, 0, n * sizeof(T), m->stream));
+    m->allocs.push_back(q);
+    *p = (T*)q;
+    return 0;
+}
+static void dfree(g4r_model* m, void* p) {
+    if (!p) return;
+    auto it = std::find(m->allocs.begin(), m->allocs.end(), p);
+    if (it != m->allocs.end()) m->allocs.erase(it);
+    (void)hipFree(p);
+}
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+extern "C" {
+
+int g4r_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+const char* g4r_last_error(void) { return g_err.c_str(); }
+const char* g4r_version(void) { return "gru4rec_hip 0.1 (gfx950)"; }
+int g4r_sizeof_config(void) { return (int)sizeof(g4r_config); }
+
+int g4r_create(const g4r_config* cfg, g4r_model** out) {
+    if (!cfg || !out) return fail("null argument");
+    if (cfg->n_layers < 1 || cfg->n_layers > G4R_MAX_LAYERS) return fail("n_layers out of range");
+    if (cfg->batch_size < 1 || cfg->n_items < 1) return fail("batch_size / n_items must be positive");
+    for (int l = 0; l < cfg->n_layers; ++l)
+        if (cfg->layers[l] % 4 != 0 || cfg->layers[l] < 4 || cfg->layers[l] > 512)
+            return fail("layer sizes must be multiples of 4 in [4, 512]");
+    if (cfg->embed_mode == G4R_EMBED_SEPARATE && (cfg->embedding % 4 != 0 || cfg->embedding < 4 || cfg->embedding > 512))
+        return fail("embedding must be a multiple of 4 in [4, 512]");
+    if (cfg->embed_mode != G4R_EMBED_CONSTRAINED && cfg->embed_mode != G4R_EMBED_SEPARATE)
+        return fail("unsupported embedding mode");
+    if (cfg->loss < 0 || cfg->loss > G4R_LOSS_TOP1_MAX) return fail("unsupported loss");
+    if (cfg->hidden_act == G4R_ACT_SOFTMAX) return fail("softmax is not a hidden activation");
+    int ndev = g4r_device_count();
+    if (ndev <= 0) return fail("no HIP device visible: the gfx950 path has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail("device ordinal out of range");
+    HIPCHK(hipSetDevice(cfg->device));
+    g4r_model* m = new g4r_model();
+    m->cfg = *cfg;
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return fail("stream create"); }
+    DevModel& d = m->dm;
+    memset(&d, 0, sizeof(d));
+    const int L = cfg->n_layers, B = cfg->batch_size;
+    d.n_items = cfg->n_items; d.n_layers = L; d.B = B;
+    // negatives: generate_length = sample_store // n_sample ; a store of <= 1 rows means "no store" (gru4rec.py:546-550)
+    int ns = cfg->n_sample;
+    int64_t gl = (ns > 0 && cfg->sample_store > 0) ? cfg->sample_store / ns : 0;
+    if (gl <= 1) { ns = 0; gl = 0; }
+    m->gl = gl;
+    d.ns = ns; d.N = B + ns; d.R = 2 * B + ns; d.ldSc = (d.N + 15) & ~15;
+    d.gl = (int)std::max<int64_t>(gl, 1);
+    d.loss = cfg->loss; d.final_act = cfg->final_act; d.hidden_act = cfg->hidden_act; d.embed_mode = cfg->embed_mode;
+    d.fa_p0 = cfg->final_act_p0; d.fa_p1 = cfg->final_act_p1; d.ha_p0 = cfg->hidden_act_p0; d.ha_p1 = cfg->hidden_act_p1;
+    d.lr = cfg->learning_rate; d.mom = cfg->momentum; d.lmbd = cfg->lmbd; d.bpreg = cfg->bpreg; d.logq = cfg->logq;
+    d.inv_B = 1.0f / (float)B;
+    d.drop_h = cfg->dropout_p_hidden; d.drop_e = cfg->dropout_p_embed;
+    d.seed = cfg->seed;
+    d.Dtop = cfg->layers[L - 1];
+    d.Ein = (cfg->embed_mode == G4R_EMBED_CONSTRAINED) ? d.Dtop : cfg->embedding;
+    int off = 0;
+    for (int l = 0; l < L; ++l) {
+        d.D[l] = cfg->layers[l];
+        d.IN[l] = (l == 0) ? d.Ein : cfg->layers[l - 1];
+        d.offWx[l] = off; off += d.IN[l] * 3 * d.D[l];
+        d.offWh[l] = off; off += d.D[l] * d.D[l];
+        d.offWrz[l] = off; off += d.D[l] * 2 * d.D[l];
+        d.offBh[l] = off; off += 3 * d.D[l];
+    }
+    d.dense_count = off;
+    d.apply_dense_inplace = (cfg->nranks <= 1) ? 1 : 0;
+    d.grad_scale = 1.0f / (float)std::max(cfg->nranks, 1);
+    const size_t I = cfg->n_items;
+#define DA(p, n) if (dalloc(m, &(p), (n))) { g4r_destroy(m); return -1; }
+    DA(d.dense_p, off); DA(d.dense_acc, off); DA(d.dense_vel, off); DA(d.dense_g, off);
+    DA(d.Wy, I * d.Dtop); DA(d.accWy, I * d.Dtop); DA(d.By, I); DA(d.accBy, I);
+    if (cfg->momentum > 0.f) { DA(d.velWy, I * d.Dtop); DA(d.velBy, I); }
+    if (cfg->embed_mode == G4R_EMBED_SEPARATE) {
+        DA(d.E, I * d.Ein); DA(d.accE, I * d.Ein);
+        if (cfg->momentum > 0.f) DA(d.velE, I * d.Ein);
+    }
+    int maxD = 0;
+    for (int l = 0; l < L; ++l) {
+        const size_t bd = (size_t)B * d.D[l];
+        maxD = std::max(maxD, d.D[l]);
+        DA(d.H[l][0], bd); DA(d.H[l][1], bd);
+        DA(d.r[l], bd); DA(d.z[l], bd); DA(d.c[l], bd); DA(d.hd[l], bd); DA(d.Hr[l], bd);
+        DA(d.dV[l], bd * 3); DA(d.dyl[l], bd);
+    }
+    DA(m->d_tmpH, (size_t)B * maxD);
+    DA(d.yin0, (size_t)B * d.Ein);
+    DA(d.Sc, (size_t)B * d.ldSc);
+    DA(d.dSx, (size_t)B * d.Ein); DA(d.dSy, (size_t)d.ldSc * d.Dtop); DA(d.dSBy, d.ldSc);
+    DA(d.lossrow, B);
+    DA(d.occ_idx, d.R + 64); DA(d.col_item, d.ldSc);
+    DA(d.st, 1);
+    // split-K of dh = ds * Sy: enough (row-tile x d-group x k-chunk) waves to fill the chip
+    {
+        const int ndt = cdiv(d.Dtop, 16), ndg = cdiv(ndt, SB_DG), nrt = cdiv(B, 16);
+        int ks = std::max(1, std::min(cdiv(2048, nrt * ndg), cdiv(d.ldSc, 64)));
+        d.kch = ((cdiv(d.ldSc, ks) + 15) / 16) * 16;
+        d.ksplit = cdiv(d.ldSc, d.kch);
+        DA(d.dhpart, (size_t)d.ksplit * B * d.Dtop);
+        m->nwavesA = cdiv(d.N, 16) * ndg;
+        m->nblkA = cdiv(m->nwavesA, 4);
+        m->nblkB = cdiv((long long)d.ksplit * nrt * ndg, 4);
+        m->nblk_occ = cdiv(d.R, 4);
+    }
+    if (ns > 0) DA(m->d_ST, (size_t)gl * ns);
+    d.ST = m->d_ST;
+    // dense-gradient tile table
+    {
+        std::vector<DenseTile> tiles;
+        for (int l = 0; l < L; ++l) {
+            const int D = d.D[l], IN = d.IN[l];
+            for (int r = 0; r < IN; r += 16) for (int c = 0; c < 3 * D; c += 16) tiles.push_back({l, 0, r, c});
+            for (int r = 0; r < D; r += 16) for (int c = 0; c < D; c += 16) tiles.push_back({l, 1, r, c});
+            for (int r = 0; r < D; r += 16) for (int c = 0; c < 2 * D; c += 16) tiles.push_back({l, 2, r, c});
+            for (int c = 0; c < 3 * D; c += 16) tiles.push_back({l, 3, 0, c});
+        }
+        m->ntiles = (int)tiles.size();
+        DA(m->d_tiles, tiles.size());
+        if (hipMemcpyAsync(m->d_tiles, tiles.data(), tiles.size() * sizeof(DenseTile), hipMemcpyHostToDevice, m->stream) != hipSuccess) {
+            g4r_destroy(m); return fail("tile upload");
+        }
+        if (hipStreamSynchronize(m->stream) != hipSuccess) { g4r_destroy(m); return fail("sync"); }
+    }
+#undef DA
+    // launch geometry + LDS opt-in
+    for (int l = 0; l < L; ++l) {
+        const int D = d.D[l], IN = d.IN[l];
+        m->smem_gru_fwd[l] = (size_t)GRU_ROWS * ((D + 2) + std::max(IN + 2, 3 * D + 2)) * sizeof(float);
+        m->smem_gru_bwd[l] = (size_t)GRU_ROWS * (3 * D + 2) * sizeof(float);
+    }
+    m->tn = (cdiv(d.N, 32) * cdiv(B, SC_BM) >= 128) ? 32 : 16;
+    m->smem_score = ((size_t)(SC_BM + 32) * (SC_KC + 2) + 32) * sizeof(float);
+    m->smem_loss = (size_t)(d.ldSc + 8) * sizeof(float);
+    const int big = 160 * 1024;
+    (void)hipFuncSetAttribute((const void*)k_gru_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)k_gru_bwd_rows, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)k_score_fwd<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)k_score_fwd<16>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)k_score_all<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)k_loss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel"); }
+    if (hipStreamSynchronize(m->stream) != hipSuccess) { g4r_destroy(m); return fail("sync"); }
+    *out = m;
+    return 0;
+}
+
+void g4r_destroy(g4r_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->cfg.device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
+    if (m->comm_ready) (void)ncclCommDestroy(m->comm);
+    for (auto e : m->evs) (void)hipEventDestroy(e);
+    for (void* p : m->allocs) (void)hipFree(p);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+// ------------------------------------------------------------------------------------------------ parameters
+static int locate(g4r_model* m, const char* name, int layer, float** p, int64_t* n) {
+    DevModel& d = m->dm;
+    std::string s(name);
+    float *base_p = d.dense_p;
+    bool want_acc = false, want_vel = false;
+    if (s.rfind("acc_", 0) == 0) { want_acc = true; s = s.substr(4); }
+    else if (s.rfind("vel_", 0) == 0) { want_vel = true; s = s.substr(4); }
+    if (want_vel && m->cfg.momentum <= 0.f && (s == "Wy" || s == "By" || s == "E")) return fail("no velocity state without momentum");
+    const int64_t I = d.n_items;
+    if (s == "Wy") { *p = want_acc ? d.accWy : (want_vel ? d.velWy : d.Wy); *n = I * d.Dtop; return 0; }
+    if (s == "By") { *p = want_acc ? d.accBy : (want_vel ? d.velBy : d.By); *n = I; return 0; }
+    if (s == "E") {
+        if (!d.E) return fail("model has no separate embedding");
+        *p = want_acc ? d.accE : (want_vel ? d.velE : d.E); *n = I * d.Ein; return 0;
+    }
+    if (layer < 0 || layer >= d.n_layers) return fail("layer out of range");
+    if (want_acc) base_p = d.dense_acc; else if (want_vel) base_p = d.dense_vel;
+    const int D = d.D[layer], IN = d.IN[layer];
+    if (s == "Wx") { *p = base_p + d.offWx[layer]; *n = (int64_t)IN * 3 * D; return 0; }
+    if (s == "Wh") { *p = base_p + d.offWh[layer]; *n = (int64_t)D * D; return 0; }
+    if (s == "Wrz") { *p = base_p + d.offWrz[layer]; *n = (int64_t)D * 2 * D; return 0; }
+    if (s == "Bh") { *p = base_p + d.offBh[layer]; *n = 3 * D; return 0; }
+    if (s == "H" && !want_acc && !want_vel) { *p = d.H[layer][m->gstep & 1]; *n = (int64_t)d.B * D; return 0; }
+    return fail(std::string("unknown parameter ") + name);
+}
+
+int g4r_set_param(g4r_model* m, const char* name, int32_t layer, const float* host, int64_t count) {
+    if (!m || !name || !host) return fail("null argument");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    float* p; int64_t n;
+    if (locate(m, name, layer, &p, &n)) return -1;
+    if (n != count) return fail(std::string("size mismatch for ") + name);
+    HIPCHK(hipMemcpyAsync(p, host, n * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+int g4r_get_param(g4r_model* m, const char* name, int32_t layer, float* host, int64_t count) {
+    if (!m || !name || !host) return fail("null argument");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    float* p; int64_t n;
+    if (locate(m, name, layer, &p, &n)) return -1;
+    if (n != count) return fail(std::string("size mismatch for ") + name);
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipMemcpy(host, p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ sampling
+static int refill_store(g4r_model* m) {
+    const long long n = (long long)m->gl * m->dm.ns;
+    const int blocks = cdiv(cdiv(n, 4), 256);
+    hipLaunchKernelGGL(k_sample_refill, dim3(blocks), dim3(256), 0, m->stream, m->d_ST, n, m->d_P, m->dm.n_items,
+                       m->dm.seed, m->refills);
+    m->refills++;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int g4r_set_popularity(g4r_model* m, const float* cum_p, const float* lq_tgt, const float* lq_smp, int64_t n) {
+    if (!m || !cum_p) return fail("null argument");
+    if (n != m->dm.n_items) return fail("popularity table size != n_items");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    if (!m->d_P) { if (dalloc(m, &m->d_P, n)) return -1; }
+    HIPCHK(hipMemcpyAsync(m->d_P, cum_p, n * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    if (m->dm.logq != 0.f) {
+        if (!lq_tgt || !lq_smp) return fail("logq > 0 needs the logQ tables");
+        if (!m->d_lqt) { if (dalloc(m, &m->d_lqt, n)) return -1; if (dalloc(m, &m->d_lqs, n)) return -1; }
+        HIPCHK(hipMemcpyAsync(m->d_lqt, lq_tgt, n * sizeof(float), hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(m->d_lqs, lq_smp, n * sizeof(float), hipMemcpyHostToDevice, m->stream));
+        m->dm.lq_tgt = m->d_lqt; m->dm.lq_smp = m->d_lqs;
+    }
+    m->have_pop = true;
+    if (m->dm.ns > 0 && !m->store_frozen) {
+        m->refills = 0;
+        if (refill_store(m)) return -1;     // gru4rec.py:564 generate_samples()
+    }
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+int64_t g4r_sample_store_rows(g4r_model* m) { return m ? m->gl : -1; }
+int g4r_set_sample_store(g4r_model* m, const int32_t* store, int64_t rows) {
+    if (!m || !store) return fail("null argument");
+    if (rows != m->gl || m->dm.ns == 0) return fail("sample store shape mismatch");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    HIPCHK(hipMemcpyAsync(m->d_ST, store, (size_t)rows * m->dm.ns * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->store_frozen = true;
+    return 0;
+}
+int g4r_get_sample_store(g4r_model* m, int32_t* store, int64_t rows) {
+    if (!m || !store) return fail("null argument");
+    if (rows != m->gl || m->dm.ns == 0) return fail("sample store shape mismatch");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipMemcpy(store, m->d_ST, (size_t)rows * m->dm.ns * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ plan
+int64_t g4r_build_plan(const int32_t* off, int64_t n_sessions, const int64_t* order, const int32_t* items,
+                       int32_t B, int32_t n_sample, int32_t* in_idx, int32_t* out_idx, uint8_t* reset, int32_t* M,
+                       int64_t* compact_steps, int32_t* compact_maps, int64_t max_steps, int64_t max_compact,
+                       int64_t* n_compact) {
+    if (!off || !order || !items || B < 1) { fail("null argument"); return -1; }
+    if (n_sessions < B) { fail("fewer sessions than batch_size (the reference raises IndexError here, gru4rec.py:596)"); return -1; }
+    const bool write = in_idx && out_idx && reset && M;
+    std::vector<int64_t> slot(B), first(B), last(B);
+    for (int j = 0; j < B; ++j) { slot[j] = j; first[j] = off[order[j]]; last[j] = off[order[j] + 1]; }
+    int64_t next_free = B - 1, T = 0, nc = 0;
+    int cur = B;
+    std::vector<char> done(B), valid(B);
+    for (;;) {
+        int64_t run = last[0] - first[0];
+        for (int j = 1; j < cur; ++j) run = std::min(run, last[j] - first[j]);
+        for (int64_t i = 0; i + 1 < run; ++i) {
+            if (write) {
+                if (T >= max_steps) { fail("plan buffer too small"); return -1; }
+                int32_t* pi = in_idx + T * B; int32_t* po = out_idx + T * B; uint8_t* pr = reset + T * B;
+                for (int j = 0; j < cur; ++j) {
+                    const int64_t e = first[j] + i;
+                    pi[j] = items[e]; po[j] = items[e + 1]; pr[j] = (e + 1 == last[j] - 1) ? 1 : 0;
+                }
+                for (int j = cur; j < B; ++j) { pi[j] = 0; po[j] = 0; pr[j] = 0; }
+                M[T] = cur;
+            }
+            ++T;
+        }
+        int n_done = 0, n_valid = 0;
+        for (int j = 0; j < cur; ++j) { first[j] += run - 1; done[j] = (last[j] - first[j] <= 1); }
+        for (int j = 0; j < cur; ++j) if (done[j]) { slot[j] = next_free + 1 + n_done; ++n_done; }
+        next_free += n_done;
+        for (int j = 0; j < cur; ++j) { valid[j] = slot[j] < n_sessions; n_valid += valid[j]; }
+        if (n_valid == 0 || (n_valid < 2 && n_sample == 0)) break;
+        for (int j = 0; j < cur; ++j)
+            if (done[j] && valid[j]) { const int64_t s = order[slot[j]]; first[j] = off[s]; last[j] = off[s + 1]; }
+        if (n_valid < cur) {
+            if (compact_steps && compact_maps) {
+                if (nc >= max_compact) { fail("compaction buffer too small"); return -1; }
+                compact_steps[nc] = T;
+                int32_t* mp = compact_maps + nc * B;
+                int q = 0;
+                for (int j = 0; j < cur; ++j) if (valid[j]) mp[q++] = j;
+                for (; q < B; ++q) mp[q] = -1;
+            }
+            ++nc;
+            int q = 0;
+            for (int j = 0; j < cur; ++j)
+                if (valid[j]) { slot[q] = slot[j]; first[q] = first[j]; last[q] = last[j]; ++q; }
+            cur = n_valid;
+        }
+    }
+    if (n_compact) *n_compact = nc;
+    return T;
+}
+
+int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, const uint8_t* reset, const int32_t* M,
+                 int64_t T, const int64_t* compact_steps, const int32_t* compact_maps, int64_t n_compact) {
+    if (!m || !in_idx || !out_idx || !reset || !M || T < 1) return fail("null / empty plan");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    const int B = m->dm.B;
+    dfree(m, m->d_in); dfree(m, m->d_out); dfree(m, m->d_reset); dfree(m, m->d_M); dfree(m, m->d_cmaps);
+    m->d_in = m->d_out = m->d_M = m->d_cmaps = nullptr; m->d_reset = nullptr;
+    if (dalloc(m, &m->d_in, (size_t)T * B, false) || dalloc(m, &m->d_out, (size_t)T * B, false) ||
+        dalloc(m, &m->d_reset, (size_t)T * B, false) || dalloc(m, &m->d_M, (size_t)T, false))
+        return -1;
+    HIPCHK(hipMemcpyAsync(m->d_in, in_idx, (size_t)T * B * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_out, out_idx, (size_t)T * B * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_reset, reset, (size_t)T * B, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_M, M, (size_t)T * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    m->compact_steps.clear();
+    if (n_compact > 0) {
+        if (!compact_steps || !compact_maps) return fail("compaction arrays missing");
+        if (dalloc(m, &m->d_cmaps, (size_t)n_compact * B, false)) return -1;
+        HIPCHK(hipMemcpyAsync(m->d_cmaps, compact_maps, (size_t)n_compact * B * sizeof(int), hipMemcpyHostToDevice, m->stream));
+        m->compact_steps.assign(compact_steps, compact_steps + n_compact);
+    }
+    if (T > m->loss_cap) {
+        dfree(m, m->d_loss);
+        if (dalloc(m, &m->d_loss, (size_t)T)) return -1;
+        m->loss_cap = T;
+    }
+    for (int64_t t = 0; t < T; ++t)
+        if (M[t] < 1 || M[t] > B) return fail("plan M out of range");
+    m->T = T;
+    m->dm.in_idx = m->d_in; m->dm.out_idx = m->d_out; m->dm.reset = m->d_reset; m->dm.Mplan = m->d_M;
+    m->dm.loss_steps = m->d_loss;
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->gexec) { (void)hipGraphExecDestroy(m->gexec); m->gexec = nullptr; }   // kernel args embed plan pointers
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ the step
+struct EvRec { int kn; hipEvent_t a, b; };
+
+static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
+    DevModel& d = m->dm;
+    const int L = d.n_layers, B = d.B;
+    hipStream_t s = m->stream;
+    GruFwdPredict nopa = {};
+    size_t evi = 0;
+    auto begin = [&](int kn) {
+        if (!recs) return;
+        while (m->evs.size() < evi + 2) { hipEvent_t e; (void)hipEventCreate(&e); m->evs.push_back(e); }
+        EvRec r = {kn, m->evs[evi], m->evs[evi + 1]};
+        evi += 2;
+        (void)hipEventRecord(r.a, s);
+        recs->push_back(r);
+    };
+    auto end = [&]() { if (recs) (void)hipEventRecord(recs->back().b, s); };
+    for (int l = 0; l < L; ++l) {
+        begin(KN_GRU_FWD);
+        hipLaunchKernelGGL(k_gru_fwd, dim3(cdiv(B, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_fwd[l], s, d, l, 1, l == 0 ? 1 : 0, nopa);
+        end();
+    }
+    begin(KN_SCORE_FWD);
+    {
+        const size_t sm = ((size_t)(SC_BM + m->tn) * (SC_KC + 2) + m->tn) * sizeof(float);
+        if (m->tn == 32) hipLaunchKernelGGL(k_score_fwd<32>, dim3(cdiv(d.N, 32), cdiv(B, SC_BM)), dim3(256), sm, s, d);
+        else hipLaunchKernelGGL(k_score_fwd<16>, dim3(cdiv(d.N, 16), cdiv(B, SC_BM)), dim3(256), sm, s, d);
+    }
+    end();
+    begin(KN_LOSS);
+    hipLaunchKernelGGL(k_loss_rows, dim3(B), dim3(256), m->smem_loss, s, d);
+    end();
+    begin(KN_SCORE_BWD);
+    hipLaunchKernelGGL(k_score_bwd, dim3(m->nblkA + m->nblkB), dim3(256), 0, s, d, m->nwavesA, m->nblkA);
+    end();
+    for (int l = L - 1; l >= 0; --l) {
+        begin(KN_GRU_BWD);
+        hipLaunchKernelGGL(k_gru_bwd_rows, dim3(cdiv(B, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_bwd[l], s, d, l);
+        end();
+    }
+    begin(KN_DENSE);
+    hipLaunchKernelGGL(k_dense_grad, dim3(cdiv(m->ntiles, 4)), dim3(256), 0, s, d, (const DenseTile*)m->d_tiles, m->ntiles);
+    end();
+    if (!d.apply_dense_inplace) {
+        if (!m->comm_ready) return fail("nranks > 1 but g4r_comm_init was not called");
+        begin(KN_ALLREDUCE);
+        NCCLCHK(ncclAllReduce(d.dense_g, d.dense_g, d.dense_count, ncclFloat, ncclSum, m->comm, s));
+        end();
+        begin(KN_DENSE_APPLY);
+        hipLaunchKernelGGL(k_dense_apply, dim3(cdiv(d.dense_count, 256)), dim3(256), 0, s, d);
+        end();
+    }
+    begin(KN_SPARSE);
+    hipLaunchKernelGGL(k_sparse_update, dim3(m->nblk_occ + 1), dim3(256), 0, s, d, m->nblk_occ);
+    end();
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int apply_compaction(g4r_model* m, int64_t ci) {
+    // gru4rec.py:647-651: H[i] <- H[i][valid_mask]; the current hidden state lives in H[l][gstep & 1]
+    DevModel& d = m->dm;
+    const int B = d.B;
+    for (int l = 0; l < d.n_layers; ++l) {
+        float* Hc = d.H[l][m->gstep & 1];
+        const int W = d.D[l];
+        hipLaunchKernelGGL(k_gather_rows, dim3(cdiv((long long)B * W, 256)), dim3(256), 0, m->stream, m->d_tmpH, (const float*)Hc,
+                           (const int*)(m->d_cmaps + ci * B), B, W);
+        HIPCHK(hipMemcpyAsync(Hc, m->d_tmpH, (size_t)B * W * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
+    }
+    return 0;
+}
+
+#define G4R_GRAPH_STEPS 16
+static int ensure_graph(g4r_model* m) {
+    if (m->gexec) return 0;
+    hipGraph_t graph;
+    HIPCHK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < G4R_GRAPH_STEPS; ++i)
+        if (launch_step(m, nullptr)) { hipGraph_t g2; (void)hipStreamEndCapture(m->stream, &g2); return -1; }
+    HIPCHK(hipStreamEndCapture(m->stream, &graph));
+    HIPCHK(hipGraphInstantiate(&m->gexec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    m->graph_steps = G4R_GRAPH_STEPS;
+    return 0;
+}
+
+int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
+    if (!m) return fail("null model");
+    if (!m->d_in) return fail("no plan uploaded");
+    if (t0 < 0 || n_steps < 0 || t0 + n_steps > m->T) return fail("step range outside the plan");
+    if (m->dm.ns > 0 && !m->have_pop && !m->store_frozen) return fail("negative sampling needs g4r_set_popularity first");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(1), 0, m->stream, m->dm.st, (long long)t0, (long long)m->gstep);
+    const bool use_graph = m->cfg.use_graph && !m->profiling && m->dm.apply_dense_inplace;
+    size_t ci = std::lower_bound(m->compact_steps.begin(), m->compact_steps.end(), t0) - m->compact_steps.begin();
+    int64_t t = t0;
+    const int64_t tend = t0 + n_steps;
+    std::vector<EvRec> recs;
+    while (t < tend) {
+        // host-scheduled events that sit between steps: batch compaction, sample-store refill
+        while (ci < m->compact_steps.size() && m->compact_steps[ci] == t) { if (apply_compaction(m, (int64_t)ci)) return -1; ++ci; }
+        if (m->dm.ns > 0 && !m->store_frozen && m->gstep > 0 && m->gstep % m->gl == 0)
+            if (refill_store(m)) return -1;      // gru4rec.py:618-620
+        // steps until the next event
+        int64_t run = tend - t;
+        if (ci < m->compact_steps.size()) run = std::min(run, m->compact_steps[ci] - t);
+        if (m->dm.ns > 0 && !m->store_frozen) run = std::min<int64_t>(run, m->gl - (m->gstep % m->gl));
+        if (run <= 0) return fail("internal: empty run");
+        int64_t done = 0;
+        if (use_graph && run >= G4R_GRAPH_STEPS) {
+            if (ensure_graph(m)) return -1;
+            for (; done + m->graph_steps <= run; done += m->graph_steps) HIPCHK(hipGraphLaunch(m->gexec, m->stream));
+        }
+        for (; done < run; ++done) {
+            if (m->profiling) {
+                recs.clear();
+                if (launch_step(m, &recs)) return -1;
+                HIPCHK(hipStreamSynchronize(m->stream));
+                for (auto& r : recs) {
+                    float ms = 0.f;
+                    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { m->kn_ms[r.kn] += ms; m->kn_n[r.kn]++; }
+                }
+            } else if (launch_step(m, nullptr)) return -1;
+        }
+        t += run;
+        m->gstep += run;
+    }
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int g4r_get_losses(g4r_model* m, int64_t t0, int64_t n, float* out) {
+    if (!m || !out) return fail("null argument");
+    if (t0 < 0 || n < 0 || t0 + n > m->T) return fail("range outside the plan");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipMemcpy(out, m->d_loss + t0, n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+int g4r_synchronize(g4r_model* m) {
+    if (!m) return fail("null model");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+int64_t g4r_global_step(g4r_model* m) { return m ? m->gstep : -1; }
+int g4r_profile(g4r_model* m, int32_t enable) {
+    if (!m) return fail("null model");
+    m->profiling = enable != 0;
+    if (enable) for (int i = 0; i < KN_COUNT; ++i) { m->kn_ms[i] = 0; m->kn_n[i] = 0; }
+    return 0;
+}
+int g4r_kernel_time(g4r_model* m, int32_t which, const char** name, double* total_ms, int64_t* launches) {
+    if (!m || which < 0 || which >= KN_COUNT) return fail("bad kernel index");
+    if (name) *name = KN_NAMES[which];
+    if (total_ms) *total_ms = m->kn_ms[which];
+    if (launches) *launches = m->kn_n[which];
+    return 0;
+}
+
+int g4r_reset_hidden(g4r_model* m) {
+    if (!m) return fail("null model");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    for (int l = 0; l < m->dm.n_layers; ++l)
+        for (int q = 0; q < 2; ++q)
+            HIPCHK(hipMemsetAsync(m->dm.H[l][q], 0, (size_t)m->dm.B * m->dm.D[l] * sizeof(float), m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ prediction
+int g4r_predict_begin(g4r_model* m, int32_t batch) {
+    if (!m || batch < 1) return fail("bad batch");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    DevModel& d = m->dm;
+    if (batch != m->pbatch) {
+        for (int l = 0; l < d.n_layers; ++l) {
+            dfree(m, m->pH[l][0]); dfree(m, m->pH[l][1]); dfree(m, m->phout[l]);
+            if (dalloc(m, &m->pH[l][0], (size_t)batch * d.D[l]) || dalloc(m, &m->pH[l][1], (size_t)batch * d.D[l]) ||
+                dalloc(m, &m->phout[l], (size_t)batch * d.D[l]))
+                return -1;
+        }
+        dfree(m, m->p_in); dfree(m, m->p_tgt); dfree(m, m->p_keep); dfree(m, m->p_zero); dfree(m, m->p_ranks);
+        if (dalloc(m, &m->p_in, batch) || dalloc(m, &m->p_tgt, batch) || dalloc(m, &m->p_keep, batch) ||
+            dalloc(m, &m->p_zero, batch) || dalloc(m, &m->p_ranks, batch))
+            return -1;
+        m->pbatch = batch;
+    } else {
+        for (int l = 0; l < d.n_layers; ++l)
+            for (int q = 0; q < 2; ++q) HIPCHK(hipMemsetAsync(m->pH[l][q], 0, (size_t)batch * d.D[l] * sizeof(float), m->stream));
+    }
+    m->ppar = 0;
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int g4r_predict_hidden(g4r_model* m, const uint8_t* zero_mask, const int32_t* keep_rows, int32_t n_keep) {
+    if (!m || !m->pbatch) return fail("g4r_predict_begin first");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    DevModel& d = m->dm;
+    const int PB = m->pbatch;
+    if (zero_mask) {
+        HIPCHK(hipMemcpyAsync(m->p_zero, zero_mask, PB, hipMemcpyHostToDevice, m->stream));
+        for (int l = 0; l < d.n_layers; ++l)
+            hipLaunchKernelGGL(k_zero_rows, dim3(cdiv((long long)PB * d.D[l], 256)), dim3(256), 0, m->stream, m->pH[l][m->ppar],
+                               (const unsigned char*)m->p_zero, PB, d.D[l]);
+    }
+    if (keep_rows) {
+        if (n_keep < 0 || n_keep > PB) return fail("n_keep out of range");
+        std::vector<int> mp(PB, -1);
+        for (int j = 0; j < n_keep; ++j) mp[j] = keep_rows[j];
+        HIPCHK(hipMemcpyAsync(m->p_keep, mp.data(), PB * sizeof(int), hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        for (int l = 0; l < d.n_layers; ++l)
+            hipLaunchKernelGGL(k_gather_rows, dim3(cdiv((long long)PB * d.D[l], 256)), dim3(256), 0, m->stream, m->pH[l][m->ppar ^ 1],
+                               (const float*)m->pH[l][m->ppar], (const int*)m->p_keep, PB, d.D[l]);
+        m->ppar ^= 1;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int g4r_predict_step(g4r_model* m, const int32_t* in_idx, int32_t mrows, const int32_t* item_idx, int64_t n_sel,
+                     float* out_scores) {
+    if (!m || !in_idx) return fail("null argument");
+    if (!m->pbatch) return fail("g4r_predict_begin first");
+    if (mrows < 1 || mrows > m->pbatch) return fail("mrows out of range");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    DevModel& d = m->dm;
+    if (!item_idx) n_sel = d.n_items;
+    if (n_sel < 1) return fail("n_sel must be positive");
+    for (int i = 0; i < mrows; ++i)
+        if (in_idx[i] < 0 || in_idx[i] >= d.n_items) return fail("input item index out of range");
+    HIPCHK(hipMemcpyAsync(m->p_in, in_idx, mrows * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    if (item_idx) {
+        if (n_sel > m->p_items_cap) {
+            dfree(m, m->p_items);
+            if (dalloc(m, &m->p_items, (size_t)n_sel, false)) return -1;
+            m->p_items_cap = n_sel;
+        }
+        for (int64_t i = 0; i < n_sel; ++i)
+            if (item_idx[i] < 0 || item_idx[i] >= d.n_items) return fail("item index out of range");
+        HIPCHK(hipMemcpyAsync(m->p_items, item_idx, n_sel * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    }
+    const int64_t ldo = (n_sel + 3) & ~3LL;
+    if ((int64_t)m->pbatch * ldo > m->p_scores_cap) {
+        HIPCHK(hipStreamSynchronize(m->stream));
+        dfree(m, m->p_scores);
+        if (dalloc(m, &m->p_scores, (size_t)m->pbatch * ldo, false)) return -1;
+        m->p_scores_cap = (int64_t)m->pbatch * ldo;
+    }
+    for (int l = 0; l < d.n_layers; ++l) {
+        GruFwdPredict pa;
+        pa.in_idx = m->p_in;
+        pa.ysrc = l > 0 ? m->phout[l - 1] : nullptr;
+        pa.Hcur = m->pH[l][m->ppar];
+        pa.Hnext = m->pH[l][m->ppar ^ 1];
+        pa.hout = m->phout[l];
+        pa.M = mrows;
+        hipLaunchKernelGGL(k_gru_fwd, dim3(cdiv(mrows, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_fwd[l], m->stream, d, l, 0, 0, pa);
+    }
+    m->ppar ^= 1;
+    const bool sm = (d.final_act == G4R_ACT_SOFTMAX);
+    hipLaunchKernelGGL(k_score_all<32>, dim3(cdiv(n_sel, 32), cdiv(mrows, SC_BM)), dim3(256), m->smem_score, m->stream, d,
+                       (const float*)m->phout[d.n_layers - 1], (int)mrows, item_idx ? (const int*)m->p_items : (const int*)nullptr,
+                       (long long)n_sel, m->p_scores, (long long)ldo, sm ? 0 : 1);
+    if (sm) hipLaunchKernelGGL(k_softmax_rows, dim3(mrows), dim3(256), 0, m->stream, m->p_scores, (long long)n_sel, (long long)ldo);
+    HIPCHK(hipGetLastError());
+    m->p_nsel = n_sel; m->p_ldo = ldo;
+    if (out_scores) {
+        HIPCHK(hipMemcpy2DAsync(out_scores, n_sel * sizeof(float), m->p_scores, ldo * sizeof(float), n_sel * sizeof(float), mrows,
+                                hipMemcpyDeviceToHost, m->stream));
+    }
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int g4r_rank_targets(g4r_model* m, const int32_t* target_col, int32_t mrows, int64_t col_begin, int32_t mode, float* ranks) {
+    if (!m || !target_col || !ranks) return fail("null argument");
+    if (!m->p_scores || mrows < 1 || mrows > m->pbatch) return fail("no scores / mrows out of range");
+    if (mode < 0 || mode > G4R_RANK_MEDIAN) return fail("unknown rank mode");
+    for (int i = 0; i < mrows; ++i)
+        if (target_col[i] < 0 || target_col[i] >= m->p_nsel) return fail("target column out of range");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    HIPCHK(hipMemcpyAsync(m->p_tgt, target_col, mrows * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(k_rank_rows, dim3(mrows), dim3(256), 0, m->stream, (const float*)m->p_scores, (long long)m->p_nsel,
+                       (long long)m->p_ldo, (const int*)m->p_tgt, (long long)col_begin, (int)mode, m->p_ranks);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(ranks, m->p_ranks, mrows * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ RCCL
+__global__ void k_scale(float* p, long long n, float s) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] *= s;
+}
+
+int g4r_comm_unique_id(char* out128) {
+    if (!out128) return fail("null argument");
+    ncclUniqueId id;
+    NCCLCHK(ncclGetUniqueId(&id));
+    static_assert(sizeof(ncclUniqueId) <= 128, "unique id size");
+    memset(out128, 0, 128);
+    memcpy(out128, &id, sizeof(id));
+    return 0;
+}
+int g4r_comm_init(g4r_model* m, const char* id128, int32_t nranks, int32_t rank) {
+    if (!m || !id128) return fail("null argument");
+    if (nranks != m->cfg.nranks || rank != m->cfg.rank) return fail("rank layout differs from g4r_config");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    NCCLCHK(ncclCommInitRank(&m->comm, nranks, id, rank));
+    m->comm_ready = true;
+    return 0;
+}
+static int allreduce_avg(g4r_model* m, float* p, long long n) {
+    NCCLCHK(ncclAllReduce(p, p, n, ncclFloat, ncclSum, m->comm, m->stream));
+    hipLaunchKernelGGL(k_scale, dim3(cdiv(n, 256)), dim3(256), 0, m->stream, p, n, 1.0f / (float)m->cfg.nranks);
+    return 0;
+}
+int g4r_comm_sync_sparse(g4r_model* m) {
+    if (!m) return fail("null model");
+    if (m->cfg.nranks <= 1) return 0;
+    if (!m->comm_ready) return fail("g4r_comm_init first");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    DevModel& d = m->dm;
+    const long long I = d.n_items;
+    if (allreduce_avg(m, d.Wy, I * d.Dtop) || allreduce_avg(m, d.accWy, I * d.Dtop) || allreduce_avg(m, d.By, I) ||
+        allreduce_avg(m, d.accBy, I))
+        return -1;
+    if (d.E && (allreduce_avg(m, d.E, I * d.Ein) || allreduce_avg(m, d.accE, I * d.Ein))) return -1;
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ debug
+int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
+    if (!m || !name || !host) return fail("null argument");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    DevModel& d = m->dm;
+    std::string s(name);
+    const float* p = nullptr; int64_t n = 0;
+    int l = 0;
+    if (!s.empty() && isdigit((unsigned char)s.back())) { l = s.back() - '0'; s.pop_back(); }
+    if (l >= d.n_layers) return fail("layer out of range");
+    const int64_t bd = (int64_t)d.B * d.D[l];
+    if (s == "scores") { p = d.Sc; n = (int64_t)d.B * d.ldSc; }
+    else if (s == "dSx") { p = d.dSx; n = (int64_t)d.B * d.Ein; }
+    else if (s == "dSy") { p = d.dSy; n = (int64_t)d.ldSc * d.Dtop; }
+    else if (s == "dSBy") { p = d.dSBy; n = d.ldSc; }
+    else if (s == "dhpart") { p = d.dhpart; n = (int64_t)d.ksplit * d.B * d.Dtop; }
+    else if (s == "lossrow") { p = d.lossrow; n = d.B; }
+    else if (s == "yin") { p = d.yin0; n = (int64_t)d.B * d.Ein; }
+    else if (s == "hd") { p = d.hd[l]; n = bd; }
+    else if (s == "r") { p = d.r[l]; n = bd; }
+    else if (s == "z") { p = d.z[l]; n = bd; }
+    else if (s == "c") { p = d.c[l]; n = bd; }
+    else if (s == "Hr") { p = d.Hr[l]; n = bd; }
+    else if (s == "dV") { p = d.dV[l]; n = bd * 3; }
+    else if (s == "dyl") { p = d.dyl[l]; n = bd; }
+    else if (s == "Hprev") { p = d.H[l][(m->gstep + 1) & 1]; n = bd; }
+    else if (s == "occ_idx") { p = (const float*)d.occ_idx; n = d.R; }
+    else if (s == "ldSc") { if (count < 1) return fail("count"); host[0] = (float)d.ldSc; return 0; }
+    else if (s == "ksplit") { if (count < 1) return fail("count"); host[0] = (float)d.ksplit; return 0; }
+    else return fail(std::string("unknown debug buffer ") + name);
+    if (count != n) return fail(std::string("size mismatch for debug buffer ") + name + " expected " + std::to_string(n));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipMemcpy(host, p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int g4r_selftest_mfma(float* max_abs_err) {
+    if (g4r_device_count() <= 0) return fail("no HIP device");
+    const int K = 20;
+    std::vector<float> A(16 * K), Bm(K * 16), C(256), R(256, 0.f);
+    for (int i = 0; i < 16; ++i) for (int k = 0; k < K; ++k) A[i * K + k] = 0.25f * (float)((i * 7 + k * 3) % 11) - 1.0f;
+    for (int k = 0; k < K; ++k) for (int j = 0; j < 16; ++j) Bm[k * 16 + j] = 0.5f * (float)((k * 5 + j * 13) % 9) - 2.0f + 0.01f * j;
+    for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { float s = 0.f; for (int k = 0; k < K; ++k) s = fmaf(A[i * K + k], Bm[k * 16 + j], s); R[i * 16 + j] = s; }
+    float *dA, *dB, *dC;
+    HIPCHK(hipMalloc(&dA, A.size() * 4)); HIPCHK(hipMalloc(&dB, Bm.size() * 4)); HIPCHK(hipMalloc(&dC, 256 * 4));
+    HIPCHK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dB, Bm.data(), Bm.size() * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_selftest_mfma, dim3(1), dim3(64), 0, 0, (const float*)dA, (const float*)dB, dC, K);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(C.data(), dC, 256 * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+    float e = 0.f;
+    for (int i = 0; i < 256; ++i) e = std::max(e, std::fabs(C[i] - R[i]));
+    if (max_abs_err) *max_abs_err = e;
+    return 0;
+}
+
+}  // extern "C"

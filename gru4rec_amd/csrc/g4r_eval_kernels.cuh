@@ -1,0 +1,133 @@
+// Prediction / evaluation kernels (gfx950): replaces the compiled `self.predict` of
+// gru4rec.py:691-711 and the evaluate function of evaluation.py:54-76.
+//   k_gru_fwd (train = 0)   forward GRU step without dropout / reset        (g4r_train_kernels.cuh)
+//   k_score_all             scores[m, n_sel] = h Wy[items]^T + By[items]     gru4rec.py:499-505
+//   k_softmax_rows          final_act == softmax over the selected items     gru4rec.py:193-195
+//   k_rank_rows             rank of the target among the other scores        evaluation.py:56-65
+#pragma once
+#include "g4r_train_kernels.cuh"
+
+template <int TN>
+__global__ __launch_bounds__(256) void k_score_all(DevModel m, const float* h, int mrows, const int* item_idx,
+                                                   long long n_sel, float* out, long long ldo, int apply_act) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int D = m.Dtop;
+    const int ldk = SC_KC + 2;
+    float* sA = smem;
+    float* sB = sA + SC_BM * ldk;
+    int* sItem = reinterpret_cast<int*>(sB + TN * ldk);
+    const long long n0 = (long long)blockIdx.x * TN;
+    const int rbase = blockIdx.y * SC_BM;
+    if (tid < TN) {
+        const long long n = n0 + tid;
+        int item = -1;
+        if (n < n_sel) item = item_idx ? item_idx[n] : (int)n;
+        sItem[tid] = item;
+    }
+    __syncthreads();
+    constexpr int CT = TN / 16;
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < CT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kc0 = 0; kc0 < D; kc0 += SC_KC) {
+        const int kc = min(SC_KC, D - kc0), kc4 = kc >> 2;
+        for (int e = tid; e < SC_BM * kc4; e += 256) {
+            const int i = e / kc4, c4 = e - i * kc4, row = rbase + i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < mrows) v = *reinterpret_cast<const float4*>(h + (size_t)row * D + kc0 + 4 * c4);
+            float2* d = reinterpret_cast<float2*>(sA + i * ldk + 4 * c4);
+            d[0] = make_float2(v.x, v.y);
+            d[1] = make_float2(v.z, v.w);
+        }
+        for (int e = tid; e < TN * kc4; e += 256) {
+            const int j = e / kc4, c4 = e - j * kc4, item = sItem[j];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (item >= 0) v = *reinterpret_cast<const float4*>(m.Wy + (size_t)item * D + kc0 + 4 * c4);
+            float2* d = reinterpret_cast<float2*>(sB + j * ldk + 4 * c4);
+            d[0] = make_float2(v.x, v.y);
+            d[1] = make_float2(v.z, v.w);
+        }
+        __syncthreads();
+        for (int k = 0; k < kc; k += 4) {
+            const float a0 = sA[(32 * wid + li) * ldk + k + lg];
+            const float a1 = sA[(32 * wid + 16 + li) * ldk + k + lg];
+#pragma unroll
+            for (int cj = 0; cj < CT; ++cj) {
+                const float b = sB[(16 * cj + li) * ldk + k + lg];
+                acc[0][cj] = mfma16(a0, b, acc[0][cj]);
+                acc[1][cj] = mfma16(a1, b, acc[1][cj]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int cj = 0; cj < CT; ++cj) {
+        const long long n = n0 + 16 * cj + li;
+        const int item = sItem[16 * cj + li];
+        const float add = item >= 0 ? m.By[item] : 0.f;
+#pragma unroll
+        for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int row = rbase + 32 * wid + 16 * ri + 4 * lg + rg;
+                if (row < mrows && n < n_sel) {
+                    float v = acc[ri][cj][rg] + add;
+                    if (apply_act) v = act_fwd(m.final_act, m.fa_p0, m.fa_p1, v);
+                    out[(size_t)row * ldo + n] = v;
+                }
+            }
+    }
+}
+
+// in-place softmax over n_sel columns of each row (one 256-thread workgroup per row)
+__global__ __launch_bounds__(256) void k_softmax_rows(float* sc, long long n_sel, long long ldo) {
+    __shared__ float red[8];
+    float* row = sc + (size_t)blockIdx.x * ldo;
+    float mx = -INFINITY;
+    for (long long j = threadIdx.x; j < n_sel; j += 256) mx = fmaxf(mx, row[j]);
+    mx = block_max_256(mx, red);
+    float sm = 0.f;
+    for (long long j = threadIdx.x; j < n_sel; j += 256) sm += expf(row[j] - mx);
+    sm = block_sum_256(sm, red);
+    for (long long j = threadIdx.x; j < n_sel; j += 256) row[j] = expf(row[j] - mx) / sm;
+}
+
+// ranks (evaluation.py:62-65): others = columns [col_begin, n_sel); target = column target_col[row]
+__global__ __launch_bounds__(256) void k_rank_rows(const float* sc, long long n_sel, long long ldo, const int* target_col,
+                                                   long long col_begin, int mode, float* ranks) {
+    __shared__ float red[8];
+    const float* row = sc + (size_t)blockIdx.x * ldo;
+    const float t = row[target_col[blockIdx.x]];
+    float gt = 0.f, eq = 0.f;
+    for (long long j = col_begin + threadIdx.x; j < n_sel; j += 256) {
+        const float v = row[j];
+        gt += (v > t) ? 1.f : 0.f;
+        eq += (v == t) ? 1.f : 0.f;
+    }
+    gt = block_sum_256(gt, red);
+    eq = block_sum_256(eq, red);
+    if (threadIdx.x == 0) {
+        float r;
+        if (mode == G4R_RANK_CONSERVATIVE) r = gt + eq;
+        else if (mode == G4R_RANK_MEDIAN) r = gt + 0.5f * (eq - 1.f) + 1.f;
+        else r = gt + 1.f;
+        ranks[blockIdx.x] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_zero_rows(float* H, const unsigned char* zero_mask, int nrows, int W) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nrows * W) return;
+    if (zero_mask[e / W]) H[e] = 0.f;
+}
+
+// 16x16x4 fp32 MFMA operand/accumulator layout self-test: C = A(16xK) * B(Kx16), asymmetric inputs
+__global__ void k_selftest_mfma(const float* A, const float* Bm, float* C, int K) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; k += 4) acc = mfma16(A[li * K + k + lg], Bm[(k + lg) * 16 + li], acc);
+    for (int rg = 0; rg < 4; ++rg) C[(4 * lg + rg) * 16 + li] = acc[rg];
+}

@@ -1,0 +1,82 @@
+"""Recall@N / MRR@N on the device: same signature and results as the reference's
+`evaluation.evaluate_gpu` (evaluation.py:15-147), without the Theano graph.
+
+The session-parallel test loop (evaluation.py:90-139) runs on the host; every step is one
+`g4r_predict_step` (GRU forward + scores against all / the given items, final activation applied in
+fp32 as the reference does) followed by `g4r_rank_targets` (the > / >= / == counts of :62-65).
+"""
+import numpy as np
+import pandas as pd
+
+
+def evaluate_gpu(gru, test_data, items=None, session_key='SessionId', item_key='ItemId', time_key='Time',
+                 cut_off=[20], batch_size=100, mode='standard'):
+    """Returns (recall list, mrr list) -- one entry per cut-off, like the reference."""
+    if gru.error_during_train:
+        raise Exception
+    if mode not in ('standard', 'conservative', 'median', 'tiebreaking'):
+        raise NotImplementedError
+    multi = isinstance(cut_off, (list, tuple))
+    cuts = list(cut_off) if multi else [cut_off]
+    print('Measuring Recall@{} and MRR@{}'.format(','.join(str(c) for c in cuts), ','.join(str(c) for c in cuts)))
+    if mode == 'tiebreaking':
+        # the reference adds uniform*1e-10 to the scores (evaluation.py:55) and then ranks as 'standard'; the
+        # perturbation is below fp32 resolution for scores of ordinary magnitude, so ranks equal 'standard'
+        mode = 'standard'
+    model = gru._ensure_model()
+    lookup = pd.DataFrame({'ItemIdx': gru.itemidmap.values, item_key: gru.itemidmap.index})
+    test_data = pd.merge(test_data, lookup, on=item_key, how='inner')
+    test_data.sort_values([session_key, time_key, item_key], inplace=True)
+    titems = test_data.ItemIdx.values.astype(np.int32)
+    item_idxs = None if items is None else gru.itemidmap[items].values.astype(np.int32)
+    sizes = test_data.groupby(session_key).size().values
+    n_sessions = len(sizes)
+    offs = np.zeros(n_sessions + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(sizes)
+    if n_sessions < batch_size:
+        raise IndexError('fewer test sessions ({}) than batch_size ({})'.format(n_sessions, batch_size))
+    rec = np.zeros(len(cuts))
+    mrr = np.zeros(len(cuts))
+    n = 0
+    model.predict_begin(batch_size)
+    slot = np.arange(batch_size)
+    next_free = batch_size - 1
+    first = offs[slot].copy()
+    last = offs[slot + 1].copy()
+    while True:
+        run = int((last - first).min())
+        for i in range(run - 1):
+            cur_in = titems[first + i]
+            cur_out = titems[first + i + 1]
+            m = len(slot)
+            if item_idxs is None:
+                model.predict_step(cur_in, None, want_scores=False)
+                ranks = model.rank_targets(cur_out, 0, mode)
+            else:
+                model.predict_step(cur_in, np.concatenate([cur_out, item_idxs]), want_scores=False)
+                ranks = model.rank_targets(np.arange(m, dtype=np.int32), m, mode)
+            for j, c in enumerate(cuts):
+                hit = ranks <= c
+                rec[j] += hit.sum()
+                mrr[j] += (hit / ranks).sum()
+            n += m
+        first = first + run - 1
+        done = (last - first) <= 1
+        n_done = int(done.sum())
+        slot[done] = next_free + 1 + np.arange(n_done)
+        next_free += n_done
+        valid = slot < n_sessions
+        if not valid.any():
+            break
+        refill = done & valid
+        first[refill] = offs[slot[refill]]
+        last[refill] = offs[slot[refill] + 1]
+        # hidden rows of restarted slots are zeroed, rows of exhausted slots dropped (evaluation.py:134-139)
+        keep = np.nonzero(valid)[0].astype(np.int32)
+        model.predict_hidden(zero_mask=refill.astype(np.uint8) if len(refill) == batch_size else
+                             np.pad(refill.astype(np.uint8), (0, batch_size - len(refill))),
+                             keep_rows=keep if len(keep) < len(valid) else None)
+        slot, first, last = slot[valid], first[valid], last[valid]
+    rec = (rec / n).tolist()
+    mrr = (mrr / n).tolist()
+    return rec, mrr

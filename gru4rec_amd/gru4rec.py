@@ -1,0 +1,416 @@
+"""GRU4Rec on MI355X: the reference's `GRU4Rec` class surface over hand-written gfx950 kernels.
+
+Mirrors hidasib/GRU4Rec `gru4rec.py` (class GRU4Rec :27; __init__ :97-135; set_params :162-187;
+fit :515-664; predict_next_batch :665-728; savemodel/loadmodel :742-781) so that `run.py -g
+gru4rec_amd.gru4rec` / `evaluation.evaluate_gpu` keep working, but nothing here builds a Theano graph:
+`fit` turns the session-parallel loop into an epoch plan (host scheduler, C++), uploads it once and
+lets the device run whole epochs without a host round trip (libgru4rec_hip.so through ctypes).
+
+There is deliberately no CPU fallback.
+"""
+import pickle
+import time
+from collections import OrderedDict  # noqa: F401  (kept: parameter files use it)
+
+import numpy as np
+import pandas as pd
+
+from . import _native, datatools
+
+_PLAIN_ACTS = ('linear', 'relu', 'tanh', 'softmax')
+
+
+def _parse_act(name, allow_softmax):
+    """'elu-0.5' -> (act id, p0, p1); unknown names raise NotImplementedError (gru4rec.py:144-161)."""
+    if name in _PLAIN_ACTS:
+        if name == 'softmax' and not allow_softmax:
+            raise NotImplementedError
+        return _native.ACT_IDS[name], 0.0, 0.0
+    if name == 'softmax_logit' and allow_softmax:
+        raise NotImplementedError('final_act=softmax_logit (xe_logit loss) is not available in the MI355X path yet')
+    for prefix, npar in (('leaky-', 1), ('elu-', 1), ('selu-', 2)):
+        if name.startswith(prefix):
+            p = [float(x) for x in name.split('-')[1:]]
+            if len(p) < npar:
+                raise NotImplementedError
+            return _native.ACT_IDS[prefix[:-1]], p[0], (p[1] if npar == 2 else 0.0)
+    raise NotImplementedError
+
+
+class GRU4Rec:
+    """Same constructor arguments and defaults as the reference (gru4rec.py:97-101)."""
+
+    def __init__(self, loss='bpr-max', final_act='linear', hidden_act='tanh', layers=[100],
+                 n_epochs=10, batch_size=32, dropout_p_hidden=0.0, dropout_p_embed=0.0, learning_rate=0.1,
+                 momentum=0.0, lmbd=0.0, embedding=0, n_sample=2048, sample_alpha=0.75, smoothing=0.0,
+                 constrained_embedding=False, adapt='adagrad', adapt_params=[], grad_cap=0.0, bpreg=1.0, logq=0.0,
+                 sigma=0.0, init_as_normal=False, train_random_order=False, time_sort=True,
+                 session_key='SessionId', item_key='ItemId', time_key='Time'):
+        self.layers = layers
+        self.n_epochs = n_epochs
+        self.batch_size = batch_size
+        self.dropout_p_hidden = dropout_p_hidden
+        self.dropout_p_embed = dropout_p_embed
+        self.learning_rate = learning_rate
+        self.adapt_params = adapt_params
+        self.momentum = momentum
+        self.sigma = sigma
+        self.init_as_normal = init_as_normal
+        self.session_key = session_key
+        self.item_key = item_key
+        self.time_key = time_key
+        self.grad_cap = grad_cap
+        self.bpreg = bpreg
+        self.logq = logq
+        self.train_random_order = train_random_order
+        self.lmbd = lmbd
+        self.embedding = self.layers[0] if embedding == 'layersize' else embedding
+        self.constrained_embedding = constrained_embedding
+        self.time_sort = time_sort
+        self.adapt = adapt
+        self.loss = loss
+        self.set_loss_function(self.loss)
+        self.final_act = final_act
+        self.set_final_activation(self.final_act)
+        self.hidden_act = hidden_act
+        self.set_hidden_activation(self.hidden_act)
+        self.n_sample = n_sample
+        self.sample_alpha = sample_alpha
+        self.smoothing = smoothing
+        # ---- MI355X-path extras (not in the reference)
+        self.seed = 12345            # Philox key (the reference's MRG default seed is 12345 as well)
+        self.device = 0
+        self.use_graph = True
+        self.steps_per_call = 16384  # plan steps per C-ABI call (NaN check granularity)
+        self._model = None
+        self._dist = None
+        self.loss_history = []
+
+    # ------------------------------------------------------------------ validation of names
+    def set_loss_function(self, loss):
+        if loss in ('cross-entropy', 'bpr-max', 'top1-max'):
+            self._loss_id = _native.LOSS_IDS[loss]
+        elif loss in ('bpr', 'top1', 'xe_logit'):
+            # valid reference names (gru4rec.py:136-143) outside this hot path; rejected when fit() starts
+            self._loss_id = None
+        else:
+            raise NotImplementedError
+
+    def set_final_activation(self, final_act):
+        if final_act == 'softmax_logit':
+            self._final = None
+            return
+        self._final = _parse_act(final_act, True)
+
+    def set_hidden_activation(self, hidden_act):
+        self._hidden = _parse_act(hidden_act, False)
+
+    def set_params(self, **kvargs):
+        """String -> typed coercion against the current attribute type, as gru4rec.py:162-187."""
+        kw = max(len(str(k)) for k in kvargs.keys())
+        vw = max(len(str(v)) for v in kvargs.values())
+
+        def show(k):
+            val = getattr(self, k)
+            print('SET   {}{}TO   {}{}(type: {})'.format(k, ' ' * (kw - len(k) + 3), val,
+                                                          ' ' * (vw - len(str(val)) + 3), type(val)))
+        for k, v in kvargs.items():
+            if not hasattr(self, k) or k.startswith('_'):
+                print('Unkown attribute: {}'.format(k))
+                raise NotImplementedError
+            cur = getattr(self, k)
+            if isinstance(v, str):
+                if k == 'adapt_params':
+                    v = [float(x) for x in v.split('/')]
+                elif isinstance(cur, list):
+                    v = [int(x) for x in v.split('/')]
+                elif isinstance(cur, bool):
+                    if v in ('True', '1'):
+                        v = True
+                    elif v in ('False', '0'):
+                        v = False
+                    else:
+                        print('Invalid value for boolean parameter: {}'.format(v))
+                        raise NotImplementedError
+            if k == 'embedding' and v == 'layersize':
+                self.embedding = 'layersize'
+            setattr(self, k, type(getattr(self, k))(v))
+            if k == 'loss':
+                self.set_loss_function(self.loss)
+            if k == 'final_act':
+                self.set_final_activation(self.final_act)
+            if k == 'hidden_act':
+                self.set_hidden_activation(self.hidden_act)
+            show(k)
+        if self.embedding == 'layersize':
+            self.embedding = self.layers[0]
+            show('embedding')
+
+    # ------------------------------------------------------------------ weights (gru4rec.py:252-294)
+    def _init_matrix(self, shape):
+        sigma = self.sigma if self.sigma != 0 else np.sqrt(6.0 / (shape[0] + shape[1]))
+        if self.init_as_normal:
+            return np.asarray(np.random.randn(*shape) * sigma, dtype=np.float32)
+        return np.asarray(np.random.rand(*shape) * sigma * 2 - sigma, dtype=np.float32)
+
+    def _init_host_weights(self):
+        """Same RNG draw order as the reference after np.random.seed(42): [E], per layer 3 Wx blocks, Wh,
+        2 Wrz blocks, finally Wy -- so both implementations start from identical weights."""
+        np.random.seed(42)
+        L = self.layers
+        if self.constrained_embedding:
+            n_features = L[-1]
+        elif self.embedding:
+            self.E = self._init_matrix((self.n_items, self.embedding))
+            n_features = self.embedding
+        else:
+            n_features = self.n_items
+        self.Wx, self.Wh, self.Wrz, self.Bh, self.H = [], [], [], [], []
+        for i, D in enumerate(L):
+            n_in = L[i - 1] if i > 0 else n_features
+            self.Wx.append(np.hstack([self._init_matrix((n_in, D)) for _ in range(3)]))
+            self.Wh.append(self._init_matrix((D, D)))
+            self.Wrz.append(np.hstack([self._init_matrix((D, D)) for _ in range(2)]))
+            self.Bh.append(np.zeros(3 * D, dtype=np.float32))
+            self.H.append(np.zeros((self.batch_size, D), dtype=np.float32))
+        self.Wy = self._init_matrix((self.n_items, L[-1]))
+        self.By = np.zeros((self.n_items, 1), dtype=np.float32)
+
+    # ------------------------------------------------------------------ native model management
+    def _check_supported(self):
+        if self._loss_id is None:
+            raise NotImplementedError('loss {} is outside the MI355X hot path (cross-entropy, bpr-max, top1-max)'.format(self.loss))
+        if self._final is None:
+            raise NotImplementedError('final_act softmax_logit is outside the MI355X hot path')
+        if self.adapt != 'adagrad':
+            raise NotImplementedError('adapt={} is outside the MI355X hot path (adagrad only)'.format(self.adapt))
+        if self.smoothing or self.grad_cap:
+            raise NotImplementedError('smoothing / grad_cap are outside the MI355X hot path')
+        if not self.constrained_embedding and not self.embedding:
+            raise NotImplementedError('one-hot input (embedding=0, constrained_embedding=False) is not in the MI355X path yet; '
+                                      'use constrained_embedding=True or embedding=<size>')
+
+    def _create_model(self, sample_store, batch_size=None):
+        self._check_supported()
+        nranks = self._dist['nranks'] if self._dist else 1
+        rank = self._dist['rank'] if self._dist else 0
+        m = _native.Model(
+            n_items=int(self.n_items), layers=self.layers, batch_size=int(batch_size or self.batch_size),
+            n_sample=int(self.n_sample), loss=self._loss_id,
+            final_act=self._final[0], final_act_p0=self._final[1], final_act_p1=self._final[2],
+            hidden_act=self._hidden[0], hidden_act_p0=self._hidden[1], hidden_act_p1=self._hidden[2],
+            embed_mode=_native.EMBED_CONSTRAINED if self.constrained_embedding else _native.EMBED_SEPARATE,
+            embedding=int(self.embedding or 0), learning_rate=self.learning_rate, momentum=self.momentum,
+            lmbd=self.lmbd, bpreg=self.bpreg, logq=self.logq, sample_alpha=self.sample_alpha,
+            dropout_p_hidden=self.dropout_p_hidden, dropout_p_embed=self.dropout_p_embed,
+            sample_store=int(sample_store), seed=int(self.seed) + 7919 * rank, device=int(self.device),
+            rank=rank, nranks=nranks, use_graph=1 if self.use_graph else 0)
+        if self._dist:
+            m.comm_init(self._dist['unique_id'], nranks, rank)
+        return m
+
+    def _upload_weights(self, m):
+        for i in range(len(self.layers)):
+            m.set_param('Wx', self.Wx[i], i)
+            m.set_param('Wh', self.Wh[i], i)
+            m.set_param('Wrz', self.Wrz[i], i)
+            m.set_param('Bh', self.Bh[i], i)
+        m.set_param('Wy', self.Wy)
+        m.set_param('By', self.By.reshape(-1))
+        if not self.constrained_embedding and self.embedding:
+            m.set_param('E', self.E)
+
+    def _download_weights(self):
+        m = self._model
+        L = self.layers
+        for i, D in enumerate(L):
+            n_in = self.Wx[i].shape[0]
+            self.Wx[i] = m.get_param('Wx', (n_in, 3 * D), i)
+            self.Wh[i] = m.get_param('Wh', (D, D), i)
+            self.Wrz[i] = m.get_param('Wrz', (D, 2 * D), i)
+            self.Bh[i] = m.get_param('Bh', (3 * D,), i)
+            self.H[i] = m.get_param('H', (m.cfg.batch_size, D), i)
+        self.Wy = m.get_param('Wy', (self.n_items, L[-1]))
+        self.By = m.get_param('By', (self.n_items,)).reshape(-1, 1)
+        if not self.constrained_embedding and self.embedding:
+            self.E = m.get_param('E', (self.n_items, self.embedding))
+
+    def set_distributed(self, rank, nranks, unique_id):
+        """One process per GPU: sessions are sharded round-robin over ranks, dense GRU gradients are
+        all-reduced with RCCL every step, embedding rows stay GPU-local."""
+        self._dist = dict(rank=int(rank), nranks=int(nranks), unique_id=unique_id) if nranks > 1 else None
+
+    # ------------------------------------------------------------------ training (gru4rec.py:515-664)
+    def prepare(self, data, sample_store=10000000, store_type='gpu'):
+        """Everything fit() does before its epoch loop: item map, sort, offsets, weights, popularity tables,
+        device model.  Split out so that benchmarks can time the epoch loop alone (the reference's own
+        mb/s excludes these as well)."""
+        if store_type not in ('gpu', 'cpu'):
+            print('Invalid store type {}'.format(store_type))
+            raise NotImplementedError
+        self.predict = None
+        self.error_during_train = False
+        itemids = data[self.item_key].unique()
+        self.n_items = len(itemids)
+        self.itemidmap = pd.Series(data=np.arange(self.n_items), index=itemids, name='ItemIdx')
+        data['ItemIdx'] = self.itemidmap[data[self.item_key].values].values
+        datatools.sort_if_needed(data, [self.session_key, self.time_key])
+        self._offsets = datatools.compute_offset(data, self.session_key)
+        self._init_host_weights()
+        support = data.groupby(self.item_key).size()
+        support = support[self.itemidmap.index.values].values
+        if self._model is not None:
+            self._model.close()
+        self._model = self._create_model(sample_store)
+        m = self._model
+        self._upload_weights(m)
+        if self.n_sample and m.sample_store_rows() == 0:
+            print('No example store was used')
+        lq_t = lq_s = None
+        if self.logq:
+            p0 = support.astype(np.float32)
+            lq_t = np.log(p0)
+            lq_s = np.log(p0 ** np.float32(self.sample_alpha))
+        pop = support.astype(np.float64) ** self.sample_alpha
+        pop = pop.cumsum() / pop.sum()
+        pop[-1] = 1
+        m.set_popularity(pop.astype(np.float32), lq_t, lq_s)
+        if self.n_sample and m.sample_store_rows() > 0:
+            print('Created sample store with {} batches of samples (type=GPU)'.format(m.sample_store_rows()))
+        if self.time_sort:
+            self._base_order = np.argsort(data.groupby(self.session_key)[self.time_key].min().values)
+        else:
+            self._base_order = np.arange(len(self._offsets) - 1)
+        self._data_items = data.ItemIdx.values.astype(np.int32)
+        self._plan_key = None
+        self.loss_history = []
+
+    def _epoch_plan(self):
+        n_sessions = len(self._offsets) - 1
+        order = np.random.permutation(n_sessions) if self.train_random_order else self._base_order
+        if self._dist:
+            order = order[self._dist['rank']::self._dist['nranks']]
+        key = None if self.train_random_order else 'static'
+        if key is not None and self._plan_key == key:
+            return self._plan
+        offs = self._offsets
+        if self._dist:
+            # a rank sees only its own sessions: remap them to a dense 0..n-1 range for the scheduler
+            lens = (offs[1:] - offs[:-1])[order]
+            sub_off = np.zeros(len(order) + 1, dtype=np.int32)
+            sub_off[1:] = np.cumsum(lens)
+            idx = np.concatenate([np.arange(offs[s], offs[s + 1]) for s in order]) if len(order) else np.zeros(0, dtype=np.int64)
+            items = self._data_items[idx]
+            plan = _native.build_plan(sub_off, np.arange(len(order)), items, self.batch_size, self.n_sample)
+        else:
+            plan = _native.build_plan(offs, order, self._data_items, self.batch_size, self.n_sample)
+        self._model.set_plan(plan)
+        self._plan = plan
+        self._plan_key = key
+        return plan
+
+    def run_epoch(self, epoch, max_steps=None):
+        """One pass of the reference's epoch body (gru4rec.py:587-661).  Returns (costs, M per step) or None on NaN."""
+        m = self._model
+        t0 = time.time()
+        plan = self._epoch_plan()
+        m.reset_hidden()
+        T = plan['T'] if max_steps is None else min(plan['T'], max_steps)
+        costs = np.empty(T, dtype=np.float32)
+        done = 0
+        while done < T:
+            n = min(self.steps_per_call, T - done)
+            m.train_steps(done, n)
+            c = m.get_losses(done, n)
+            costs[done:done + n] = c
+            bad = np.isnan(c)
+            if bad.any():
+                print(str(epoch) + ': NaN error!')
+                self.error_during_train = True
+                return None
+            done += n
+        cc = plan['M'][:T]
+        avgc = np.sum(costs * cc) / np.sum(cc)
+        if np.isnan(avgc):
+            print('Epoch {}: NaN error!'.format(str(epoch)))
+            self.error_during_train = True
+            return None
+        dt = time.time() - t0
+        print('Epoch{} --> loss: {:.6f} \t({:.2f}s) \t[{:.2f} mb/s | {:.0f} e/s]'.format(epoch + 1, avgc, dt, T / dt, np.sum(cc) / dt))
+        self.loss_history.append(float(avgc))
+        self.last_epoch_stats = dict(steps=int(T), events=int(np.sum(cc)), seconds=dt, loss=float(avgc))
+        return costs, cc
+
+    def fit(self, data, sample_store=10000000, store_type='gpu'):
+        """Trains the network; same contract as the reference's fit (gru4rec.py:515-664): mutates `data`
+        (adds ItemIdx, may sort in place), sets n_items / itemidmap / error_during_train."""
+        self.prepare(data, sample_store=sample_store, store_type=store_type)
+        for epoch in range(self.n_epochs):
+            if self.run_epoch(epoch) is None:
+                return
+            if self._dist:
+                self._model.comm_sync_sparse()
+        self._download_weights()
+
+    # ------------------------------------------------------------------ prediction (gru4rec.py:665-728)
+    def _ensure_model(self):
+        if self._model is None:
+            self._model = self._create_model(0)
+            self._upload_weights(self._model)
+        return self._model
+
+    def predict_next_batch(self, session_ids, input_item_ids, predict_for_item_ids=None, batch=100):
+        """Scores for the next item of every session in the batch.  Rows: items, columns: batch events."""
+        if self.error_during_train:
+            raise Exception
+        m = self._ensure_model()
+        if self.predict is None or self.predict_batch != batch:
+            self.predict_batch = batch
+            m.predict_begin(batch)
+            self.current_session = np.ones(batch) * -1
+            self.predict = True
+        session_ids = np.asarray(session_ids)
+        changed = session_ids != self.current_session
+        if changed.any():
+            m.predict_hidden(zero_mask=changed.astype(np.uint8))
+            self.current_session = session_ids.copy()
+        in_idxs = self.itemidmap[input_item_ids].values
+        if predict_for_item_ids is not None:
+            iidx = self.itemidmap[predict_for_item_ids].values
+            preds = m.predict_step(in_idxs, iidx).T
+            return pd.DataFrame(data=preds, index=predict_for_item_ids)
+        preds = m.predict_step(in_idxs).T
+        return pd.DataFrame(data=preds, index=self.itemidmap.index)
+
+    def symbolic_predict(self, X, Y, M, items, batch_size):
+        raise NotImplementedError('symbolic_predict builds a Theano graph (gru4rec.py:729-741); the MI355X path '
+                                  'exposes the same computation through gru4rec_amd.evaluation.evaluate_gpu')
+
+    # ------------------------------------------------------------------ (de)serialisation (gru4rec.py:742-781)
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        for k in ('_model', '_plan', '_plan_key', '_data_items', '_offsets', '_base_order', '_dist'):
+            st.pop(k, None)
+        st['predict'] = None
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self._model = None
+        self._dist = None
+        self.predict = None
+
+    def savemodel(self, fname):
+        """Pickle with the reference's attribute names / array layouts (Wx[i] (in,3D)=[cand|r|z], Wrz[i] (D,2D)=[r|z],
+        Wh[i], Bh[i], H[i], Wy (n_items,D), By (n_items,1), E, itemidmap)."""
+        if self._model is not None and not self.error_during_train:
+            self._download_weights()
+        with open(fname, 'wb') as f:
+            pickle.dump(self, f)
+
+    @classmethod
+    def loadmodel(cls, fname):
+        gru = pd.read_pickle(fname)
+        gru._model = None
+        gru.predict = None
+        return gru

@@ -1,0 +1,144 @@
+/*
+ * gru4rec_hip.h -- C ABI of libgru4rec_hip.so: the MI355X (gfx950) implementation of GRU4Rec's
+ * session-parallel mini-batch training / prediction hot path.
+ *
+ * This is the drop-in boundary.  The reference (hidasib/GRU4Rec) has no FFI of its own: its
+ * device code is reached through compiled Theano functions.  Each entry point below replaces one
+ * such Theano-function boundary (cited per function as reference file:line).  The Python host
+ * (`gru4rec_amd/gru4rec.py`, mirroring the reference's `GRU4Rec` class) binds these with ctypes;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every call returns 0 on success, <0 on error; g4r_last_error() returns the message
+ *   - plain pointers + sizes only; the caller owns every host buffer, the library owns device memory
+ *   - a model handle is not thread-safe; one HIP stream per handle; calls are synchronous at return
+ *     unless stated otherwise
+ *   - all matrices are row-major fp32; layer sizes / embedding size must be multiples of 4
+ */
+#ifndef GRU4REC_HIP_H
+#define GRU4REC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define G4R_MAX_LAYERS 8
+
+/* gru4rec.py:136-143 (set_loss_function) */
+enum { G4R_LOSS_XE = 0, G4R_LOSS_BPR_MAX = 1, G4R_LOSS_TOP1_MAX = 2 };
+/* gru4rec.py:144-161 (set_final_activation / set_hidden_activation) */
+enum { G4R_ACT_LINEAR = 0, G4R_ACT_RELU = 1, G4R_ACT_TANH = 2, G4R_ACT_LEAKY = 3, G4R_ACT_ELU = 4,
+       G4R_ACT_SELU = 5, G4R_ACT_SOFTMAX = 6 };
+/* gru4rec.py:438-470: where the GRU input comes from */
+enum { G4R_EMBED_CONSTRAINED = 0 /* Wy shared, :438-448 */, G4R_EMBED_SEPARATE = 1 /* E, :449-456 */ };
+/* evaluation.py:62-65 */
+enum { G4R_RANK_STANDARD = 0, G4R_RANK_CONSERVATIVE = 1, G4R_RANK_MEDIAN = 2 };
+
+/* Constructor arguments of the reference's GRU4Rec (gru4rec.py:97-135) that the hot path needs. */
+typedef struct g4r_config {
+    int32_t n_items;
+    int32_t n_layers;
+    int32_t layers[G4R_MAX_LAYERS];
+    int32_t batch_size;
+    int32_t n_sample;            /* additional negatives per step (0 = in-batch only) */
+    int32_t loss;                /* G4R_LOSS_* */
+    int32_t final_act;           /* G4R_ACT_* */
+    float   final_act_p0, final_act_p1;
+    int32_t hidden_act;          /* G4R_ACT_* (not softmax) */
+    float   hidden_act_p0, hidden_act_p1;
+    int32_t embed_mode;          /* G4R_EMBED_* */
+    int32_t embedding;           /* width of E when embed_mode == SEPARATE */
+    float   learning_rate, momentum, lmbd, bpreg, logq, sample_alpha;
+    float   dropout_p_hidden, dropout_p_embed;
+    int64_t sample_store;        /* ints in the negative-sample store (gru4rec.py:515,547) */
+    uint64_t seed;               /* Philox key for sampler + dropout */
+    int32_t device;              /* HIP device ordinal */
+    int32_t rank, nranks;        /* data-parallel rank layout (1 process per GPU) */
+    int32_t use_graph;           /* capture steady-state steps into a hipGraph */
+    int32_t reserved[7];
+} g4r_config;
+
+typedef struct g4r_model g4r_model;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+int  g4r_device_count(void);
+const char* g4r_last_error(void);
+const char* g4r_version(void);
+int  g4r_sizeof_config(void);   /* sizeof(g4r_config), for binding self-checks */
+/* replaces GRU4Rec.init()'s theano.shared allocations, gru4rec.py:267-294 */
+int  g4r_create(const g4r_config* cfg, g4r_model** out);
+void g4r_destroy(g4r_model* m);
+
+/* ---- parameters (gru4rec.py:742-781 savemodel/loadmodel get_value/set_value) ------------------ */
+/* name: "Wy" [I,D], "By" [I], "E" [I,emb], "Wx" [in,3D], "Wh" [D,D], "Wrz" [D,2D], "Bh" [3D], "H" [B,D];
+ * optimizer state with prefix "acc_" / "vel_" (gru4rec.py:331,401,425).  `layer` ignored for Wy/By/E. */
+int g4r_set_param(g4r_model* m, const char* name, int32_t layer, const float* host, int64_t count);
+int g4r_get_param(g4r_model* m, const char* name, int32_t layer, float* host, int64_t count);
+
+/* ---- negative sampling (gru4rec.py:539-571; kernel semantics custom_theano_ops.py:318-349) ---- */
+/* cum_p: float32 cumulative supp**alpha (P, :543-545,556); lq_tgt/lq_smp: logQ tables (:495), may be NULL */
+int g4r_set_popularity(g4r_model* m, const float* cum_p, const float* lq_tgt, const float* lq_smp, int64_t n);
+/* test hook: overwrite the device sample store (rows x n_sample) and freeze refills */
+int g4r_set_sample_store(g4r_model* m, const int32_t* store, int64_t rows);
+int g4r_get_sample_store(g4r_model* m, int32_t* store, int64_t rows);
+int64_t g4r_sample_store_rows(g4r_model* m);
+
+/* ---- epoch plan: the (X, Y, M, R) argument stream of train_function, gru4rec.py:599-651 ------- */
+/* Host-side scheduler (no GPU needed): restates the while/for loop of fit() for a whole epoch.
+ * Pass NULL outputs to only count.  Returns the number of steps T (or <0); *n_compact receives the
+ * number of batch-shrink events (gru4rec.py:647-651).  compact_maps is [n_compact][batch_size]:
+ * new row j takes old row map[j] (-1 = none). */
+int64_t g4r_build_plan(const int32_t* offset_sessions, int64_t n_sessions, const int64_t* session_order,
+                       const int32_t* data_items, int32_t batch_size, int32_t n_sample,
+                       int32_t* in_idx, int32_t* out_idx, uint8_t* reset, int32_t* M,
+                       int64_t* compact_steps, int32_t* compact_maps, int64_t max_steps, int64_t max_compact,
+                       int64_t* n_compact);
+/* upload a plan: in_idx/out_idx [T,B] int32, reset [T,B] uint8, M [T] */
+int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, const uint8_t* reset,
+                 const int32_t* M, int64_t T, const int64_t* compact_steps, const int32_t* compact_maps,
+                 int64_t n_compact);
+
+/* ---- the hot path: replaces `train_function(in_idx, y, len(iters), reset)`, gru4rec.py:584,623 - */
+/* runs plan steps [t0, t0+n): gather -> GRU -> sampled scoring -> loss -> backward -> Adagrad, with no
+ * host round trip in between; per-step costs stay on the device until g4r_get_losses. */
+int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps);
+int g4r_get_losses(g4r_model* m, int64_t t0, int64_t n, float* out);     /* cost of :623 per step */
+int g4r_synchronize(g4r_model* m);
+int64_t g4r_global_step(g4r_model* m);
+/* average HIP-event time (ms) per launch of each step kernel since the last reset; names via index */
+int g4r_kernel_time(g4r_model* m, int32_t which, const char** name, double* total_ms, int64_t* launches);
+int g4r_profile(g4r_model* m, int32_t enable);
+
+/* hidden state (gru4rec.py:589-590 zeroing, :647-651 compaction; evaluation.py:134-139) */
+int g4r_reset_hidden(g4r_model* m);
+
+/* ---- prediction: replaces the compiled `self.predict` / evaluate functions --------------------- */
+/* gru4rec.py:691-711 (+ symbolic_predict :729-741): allocate prediction state for `batch` rows */
+int g4r_predict_begin(g4r_model* m, int32_t batch);
+/* zero rows where zero_mask != 0, then keep rows in `keep_rows` order (NULL = identity), evaluation.py:134-139,
+ * gru4rec.py:712-717 */
+int g4r_predict_hidden(g4r_model* m, const uint8_t* zero_mask, const int32_t* keep_rows, int32_t n_keep);
+/* forward only; scores[m, n_sel] = final_act(h Wy[item_idx]^T + By) (all items if item_idx NULL); out may be NULL */
+int g4r_predict_step(g4r_model* m, const int32_t* in_idx, int32_t mrows, const int32_t* item_idx, int64_t n_sel,
+                     float* out_scores);
+/* rank of column target_col[i] of row i among columns [col_begin, n_sel) of the last g4r_predict_step's
+ * scores (evaluation.py:56-65; col_begin = 0 for the all-items case, = M when `items` were given) */
+int g4r_rank_targets(g4r_model* m, const int32_t* target_col, int32_t mrows, int64_t col_begin, int32_t mode,
+                     float* ranks);
+
+/* ---- multi-GPU (new: the reference is single-GPU).  RCCL all-reduce of dense GRU gradients ---- */
+int g4r_comm_unique_id(char* out128);                         /* rank 0: ncclGetUniqueId */
+int g4r_comm_init(g4r_model* m, const char* id128, int32_t nranks, int32_t rank);
+int g4r_comm_sync_sparse(g4r_model* m);                        /* average GPU-local embedding replicas */
+
+/* ---- debugging / tests ---------------------------------------------------------------------- */
+/* copy a named intermediate of the most recent step (e.g. "scores", "dS", "dV0", "hd0") */
+int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count);
+int g4r_selftest_mfma(float* max_abs_err);                    /* 16x16x4 f32 MFMA layout check */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

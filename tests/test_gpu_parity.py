@@ -1,0 +1,334 @@
+"""Parity of the HIP hot path against the CPU oracle, through the C ABI (ctypes).  Needs an MI355X.
+
+Floating point tolerance (fp32 path vs fp32 oracle; both accumulate in fp32 but in different orders):
+  per-step cost            rtol 2e-4 (+ atol 2e-6)
+  intermediates / params   atol 3e-5 + rtol 3e-4 unless stated
+Integer work (sample store, plan, occurrence lists) is bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from gru4rec_amd import _native
+from oracle.model import OracleGRU4Rec, parse_act
+from oracle.scheduler import fit_schedule
+
+pytestmark = pytest.mark.gpu
+
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'parity_report.txt')
+
+
+def report(line):
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        with open(REPORT, 'a') as f:
+            f.write(line + '\n')
+    except OSError:
+        pass
+
+
+def close(name, got, want, atol=3e-5, rtol=3e-4, errs=None):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    err = np.abs(got - want)
+    tol = atol + rtol * np.abs(want)
+    worst = float((err / tol).max()) if err.size else 0.0
+    bad = not np.isfinite(got).all() or worst > 1.0
+    report('%-28s max_abs_err %.3e  max|want| %.3e  worst/tol %.3f %s' % (
+        name, float(err.max()) if err.size else 0.0, float(np.abs(want).max()) if want.size else 0.0, worst,
+        'FAIL' if bad else 'ok'))
+    if bad and errs is not None:
+        errs.append(name)
+    return not bad
+
+
+def make_pair(I, B, ns, store_rows, seed=3, **kw):
+    """An oracle and a device model with identical weights / popularity / sample store."""
+    use_graph = kw.pop('use_graph', 0)
+    o = OracleGRU4Rec(n_items=I, batch_size=B, n_sample=ns, dtype=np.float32, seed=seed, **kw)
+    rng = np.random.RandomState(seed)
+    support = rng.randint(1, 40, size=I)
+    o.set_popularity(support)
+    o.make_sample_store(store_rows * ns if ns else 0)
+    fa = parse_act(kw.get('final_act', 'linear'))
+    ha = parse_act(kw.get('hidden_act', 'tanh'))
+    m = _native.Model(
+        n_items=I, layers=list(o.layers), batch_size=B, n_sample=ns, loss=_native.LOSS_IDS[o.loss],
+        final_act=_native.ACT_IDS[fa[0]], final_act_p0=fa[1], final_act_p1=fa[2],
+        hidden_act=_native.ACT_IDS[ha[0]], hidden_act_p0=ha[1], hidden_act_p1=ha[2],
+        embed_mode=0 if o.constrained_embedding else 1, embedding=int(o.embedding or 0),
+        learning_rate=o.learning_rate, momentum=o.momentum, lmbd=o.lmbd, bpreg=o.bpreg, logq=o.logq,
+        sample_alpha=o.sample_alpha, dropout_p_hidden=o.dropout_p_hidden, dropout_p_embed=o.dropout_p_embed,
+        sample_store=store_rows * ns if ns else 0, seed=seed, device=0, rank=0, nranks=1,
+        use_graph=use_graph)
+    # non-trivial biases / hidden state so that every term is exercised
+    for i, D in enumerate(o.layers):
+        o.Bh[i] = (rng.randn(3 * D) * 0.1).astype(np.float32)
+        o.H[i] = (rng.randn(B, D) * 0.3).astype(np.float32)
+        m.set_param('Wx', o.Wx[i], i)
+        m.set_param('Wh', o.Wh[i], i)
+        m.set_param('Wrz', o.Wrz[i], i)
+        m.set_param('Bh', o.Bh[i], i)
+        m.set_param('H', o.H[i], i)
+    o.By = (rng.randn(I) * 0.1).astype(np.float32)
+    m.set_param('Wy', o.Wy)
+    m.set_param('By', o.By)
+    if o.E is not None:
+        m.set_param('E', o.E)
+    m.set_popularity(o.P, o.lq_tgt if o.logq else None, o.lq_smp if o.logq else None)
+    return o, m
+
+
+def random_plan(I, B, T, seed, tail=False):
+    rng = np.random.RandomState(seed)
+    M = np.full(T, B, dtype=np.int32)
+    if tail:
+        M[T // 2:] = max(1, B - 3)
+        M[-1] = max(1, B // 2)
+    return dict(in_idx=rng.randint(0, I, size=(T, B)).astype(np.int32),
+                out_idx=rng.randint(0, I, size=(T, B)).astype(np.int32),
+                reset=(rng.rand(T, B) < 0.25).astype(np.uint8), M=M, T=T, n_compact=0,
+                compact_steps=np.zeros(0, dtype=np.int64), compact_maps=np.zeros((0, B), dtype=np.int32))
+
+
+def compare_params(o, m, errs, tag, atol=3e-5, rtol=3e-4, Mrows=None):
+    I = o.n_items
+    Mrows = o.batch_size if Mrows is None else Mrows
+    for i, D in enumerate(o.layers):
+        n_in = o.Wx[i].shape[0]
+        close('%s Wx%d' % (tag, i), m.get_param('Wx', (n_in, 3 * D), i), o.Wx[i], atol, rtol, errs)
+        close('%s Wh%d' % (tag, i), m.get_param('Wh', (D, D), i), o.Wh[i], atol, rtol, errs)
+        close('%s Wrz%d' % (tag, i), m.get_param('Wrz', (D, 2 * D), i), o.Wrz[i], atol, rtol, errs)
+        close('%s Bh%d' % (tag, i), m.get_param('Bh', (3 * D,), i), o.Bh[i], atol, rtol, errs)
+        close('%s H%d' % (tag, i), m.get_param('H', (o.batch_size, D), i)[:Mrows], o.H[i][:Mrows], atol, rtol, errs)
+        close('%s acc_Wx%d' % (tag, i), m.get_param('acc_Wx', (n_in, 3 * D), i), o.acc['Wx'][i], atol, rtol * 3, errs)
+    close('%s Wy' % tag, m.get_param('Wy', (I, o.layers[-1])), o.Wy, atol, rtol, errs)
+    close('%s By' % tag, m.get_param('By', (I,)), o.By, atol, rtol, errs)
+    close('%s acc_Wy' % tag, m.get_param('acc_Wy', (I, o.layers[-1])), o.acc['Wy'], atol, rtol * 3, errs)
+    close('%s acc_By' % tag, m.get_param('acc_By', (I,)), o.acc['By'], atol, rtol * 3, errs)
+    if o.E is not None:
+        close('%s E' % tag, m.get_param('E', (I, o.embedding)), o.E, atol, rtol, errs)
+    if o.momentum > 0:
+        close('%s vel_Wy' % tag, m.get_param('vel_Wy', (I, o.layers[-1])), o.vel['Wy'], atol, rtol, errs)
+
+
+def test_mfma_layout_selftest():
+    assert _native.selftest_mfma() < 1e-5
+
+
+def test_sample_store_bit_exact():
+    o, m = make_pair(I=997, B=8, ns=64, store_rows=50, loss='bpr-max', constrained_embedding=True, layers=(12,))
+    st = m.get_sample_store(64)
+    np.testing.assert_array_equal(st, o.ST)
+
+
+CASES = {
+    'bprmax_elu': dict(loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(12,), bpreg=0.7),
+    'bprmax_mom_drop': dict(loss='bpr-max', final_act='linear', constrained_embedding=True, layers=(16,), momentum=0.3,
+                            dropout_p_hidden=0.3, dropout_p_embed=0.2),
+    'top1max_2layer': dict(loss='top1-max', final_act='tanh', constrained_embedding=True, layers=(8, 12),
+                           dropout_p_hidden=0.2),
+    'xe_softmax_logq': dict(loss='cross-entropy', final_act='softmax', constrained_embedding=True, layers=(12,),
+                            logq=1.0, sample_alpha=0.5, momentum=0.2),
+    'xe_sep_embed': dict(loss='cross-entropy', final_act='softmax', constrained_embedding=False, embedding=20,
+                         layers=(12,)),
+    'bprmax_relu_sep2': dict(loss='bpr-max', final_act='relu', hidden_act='relu', constrained_embedding=False,
+                             embedding=8, layers=(8, 8), lmbd=0.01),
+    'bprmax_softmax': dict(loss='bpr-max', final_act='softmax', constrained_embedding=True, layers=(12,)),
+}
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_first_step_intermediates(name):
+    """One step: every intermediate the kernels expose against the oracle's debug dump."""
+    kw = CASES[name]
+    I, B, ns = 60, 20, 40
+    o, m = make_pair(I, B, ns, store_rows=7, **kw)
+    plan = random_plan(I, B, 1, seed=5)
+    plan['M'][:] = B - 3          # exercise the inactive in-batch rows/columns as well
+    m.set_plan(plan)
+    M = int(plan['M'][0])
+    cost, dbg = o.train_step(plan['in_idx'][0], plan['out_idx'][0], M, plan['reset'][0], return_debug=True)
+    m.train_steps(0, 1)
+    errs = []
+    report('--- first step %s' % name)
+    N = B + ns
+    ld = int(m.get_debug('ldSc', (1,))[0])
+    cols = np.r_[0:M, B:N]
+    L = len(o.layers)
+    for i, D in enumerate(o.layers):
+        cch = dbg['caches'][i]
+        close('hd%d' % i, m.get_debug('hd%d' % i, (B, D))[:M], cch['hd'], errs=errs)
+        close('r%d' % i, m.get_debug('r%d' % i, (B, D))[:M], cch['r'], errs=errs)
+        close('z%d' % i, m.get_debug('z%d' % i, (B, D))[:M], cch['z'], errs=errs)
+        close('c%d' % i, m.get_debug('c%d' % i, (B, D))[:M], cch['c'], errs=errs)
+    ds = m.get_debug('scores', (B, ld))
+    close('ds', ds[:M][:, cols], dbg['ds'], atol=1e-6, rtol=1e-3, errs=errs)
+    assert not ds[:M][:, M:B].any(), 'inactive in-batch columns must carry zero gradient'
+    close('dSy', m.get_debug('dSy', (ld, o.layers[-1]))[cols], dbg['dSy'], atol=1e-6, rtol=1e-3, errs=errs)
+    close('dSBy', m.get_debug('dSBy', (ld,))[cols], dbg['dSBy'], atol=1e-6, rtol=1e-3, errs=errs)
+    ks = int(m.get_debug('ksplit', (1,))[0])
+    dhp = m.get_debug('dhpart', (ks, B, o.layers[-1])).sum(axis=0)
+    close('dh_top', dhp[:M], dbg['dtop'], atol=1e-6, rtol=1e-3, errs=errs)
+    n_in = o.layers[-1] if o.constrained_embedding else o.embedding
+    close('dSx', m.get_debug('dSx', (B, n_in))[:M], dbg['dSx'], atol=1e-6, rtol=1e-3, errs=errs)
+    close('cost', m.get_losses(0, 1), [cost], atol=2e-6, rtol=2e-4, errs=errs)
+    compare_params(o, m, errs, 'p1', Mrows=M)
+    assert not errs, errs
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_loss_curve_and_weights_after_many_steps(name):
+    """60 steps with a shrinking batch at the end and several sample-store wrap-arounds (refill path)."""
+    kw = CASES[name]
+    I, B, ns, T = 80, 12, 24, 60
+    o, m = make_pair(I, B, ns, store_rows=9, **kw)
+    plan = random_plan(I, B, T, seed=11, tail=True)
+    m.set_plan(plan)
+    want = []
+    for t in range(T):
+        M = int(plan['M'][t])
+        want.append(o.train_step(plan['in_idx'][t], plan['out_idx'][t], M, plan['reset'][t]))
+    m.train_steps(0, 25)
+    m.train_steps(25, T - 25)
+    got = m.get_losses(0, T)
+    errs = []
+    report('--- curve %s' % name)
+    close('loss curve', got, np.array(want), atol=5e-6, rtol=5e-4, errs=errs)
+    np.testing.assert_array_equal(m.get_sample_store(ns), o.ST)
+    compare_params(o, m, errs, 'p60', atol=1e-4, rtol=2e-3, Mrows=int(plan['M'][-1]))
+    assert not errs, errs
+
+
+def test_graph_replay_is_bit_identical_to_eager():
+    kw = CASES['bprmax_mom_drop']
+    I, B, ns, T = 80, 12, 24, 80
+    plan = random_plan(I, B, T, seed=13)
+    outs = []
+    for g in (0, 1):
+        _, m = make_pair(I, B, ns, store_rows=200, use_graph=g, **dict(kw))
+        m.set_plan(plan)
+        m.train_steps(0, T)
+        outs.append((m.get_losses(0, T), m.get_param('Wy', (I, 16)), m.get_param('Wx', (16, 48), 0)))
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_epoch_with_real_schedule_and_compaction():
+    """Sessions -> C++ plan -> device epoch (with H compaction at the tail) vs the oracle driven by the
+    literal restatement of the reference loop."""
+    rng = np.random.RandomState(7)
+    n_sess, I, B, ns = 90, 70, 16, 24
+    lens = rng.randint(1, 8, size=n_sess)
+    off = np.zeros(n_sess + 1, dtype=np.int32)
+    off[1:] = np.cumsum(lens)
+    items = rng.randint(0, I, size=off[-1]).astype(np.int32)
+    order = rng.permutation(n_sess)
+    o, m = make_pair(I, B, ns, store_rows=5, loss='bpr-max', final_act='elu-1', constrained_embedding=True,
+                     layers=(12,), momentum=0.1)
+    for i in range(len(o.layers)):
+        o.H[i][:] = 0
+    m.reset_hidden()
+    plan = _native.build_plan(off, order, items, B, ns)
+    m.set_plan(plan)
+    want = []
+    for ev in fit_schedule(off, order, items, B, ns):
+        if ev[0] == 'step':
+            want.append(o.train_step(ev[1], ev[2], ev[3], ev[4]))
+        else:
+            valid = ev[1]
+            for i in range(len(o.layers)):
+                H = np.zeros_like(o.H[i])
+                keep = o.H[i][:len(valid)][valid]
+                H[:len(keep)] = keep
+                o.H[i] = H
+    assert plan['T'] == len(want) and plan['n_compact'] > 0
+    m.train_steps(0, plan['T'])
+    errs = []
+    report('--- epoch with compaction')
+    close('loss curve', m.get_losses(0, plan['T']), np.array(want), atol=5e-6, rtol=5e-4, errs=errs)
+    Mlast = int(plan['M'][-1])
+    close('H tail', m.get_param('H', (B, 12), 0)[:Mlast], o.H[0][:Mlast], errs=errs)
+    close('Wy', m.get_param('Wy', (I, 12)), o.Wy, 1e-4, 2e-3, errs=errs)
+    assert not errs, errs
+
+
+def test_baseline_config2_shape_few_steps():
+    """BASELINE config #2 shape: I = 37,483, B = 128, layers = [100], n_sample = 2048, BPR-max, constrained."""
+    I, B, ns, T = 37483, 128, 2048, 6
+    o, m = make_pair(I, B, ns, store_rows=16, loss='bpr-max', final_act='elu-0.5', constrained_embedding=True,
+                     layers=(100,), learning_rate=0.1, bpreg=1.0)
+    plan = random_plan(I, B, T, seed=17)
+    # make duplicates certain: popular items repeated inside the batch and against the samples
+    plan['in_idx'][:, :8] = o.ST[0][:8]
+    plan['out_idx'][:, 8:16] = plan['in_idx'][:, :8]
+    m.set_plan(plan)
+    want = [o.train_step(plan['in_idx'][t], plan['out_idx'][t], B, plan['reset'][t]) for t in range(T)]
+    m.train_steps(0, T)
+    errs = []
+    report('--- config #2 shape')
+    close('loss curve', m.get_losses(0, T), np.array(want), atol=5e-6, rtol=5e-4, errs=errs)
+    compare_params(o, m, errs, 'cfg2', atol=1e-4, rtol=2e-3)
+    assert not errs, errs
+
+
+def test_wide_layer_and_big_batch():
+    """D = 320 with B = 160 (two 128-row blocks, K-chunked scoring) and a 2-chunk sparse row."""
+    I, B, ns, T = 3000, 160, 512, 3
+    o, m = make_pair(I, B, ns, store_rows=8, loss='cross-entropy', final_act='softmax', constrained_embedding=True,
+                     layers=(320,), learning_rate=0.05, logq=1.0, dropout_p_embed=0.3)
+    plan = random_plan(I, B, T, seed=19)
+    m.set_plan(plan)
+    want = [o.train_step(plan['in_idx'][t], plan['out_idx'][t], B, plan['reset'][t]) for t in range(T)]
+    m.train_steps(0, T)
+    errs = []
+    report('--- wide layer')
+    close('loss curve', m.get_losses(0, T), np.array(want), atol=5e-6, rtol=5e-4, errs=errs)
+    compare_params(o, m, errs, 'wide', atol=1e-4, rtol=2e-3)
+    assert not errs, errs
+
+
+@pytest.mark.parametrize('name', ['bprmax_elu', 'xe_softmax_logq', 'top1max_2layer', 'xe_sep_embed'])
+def test_predict_and_ranks(name):
+    kw = CASES[name]
+    I, B = 300, 24
+    o, m = make_pair(I, B, 0, store_rows=0, **kw)
+    rng = np.random.RandomState(23)
+    pb = 40
+    m.predict_begin(pb)
+    H = [np.zeros((pb, D), dtype=np.float32) for D in o.layers]
+    errs = []
+    report('--- predict %s' % name)
+    for step in range(3):
+        in_idx = rng.randint(0, I, size=pb)
+        tgt = rng.randint(0, I, size=pb)
+        want, H = o.predict_step(H, in_idx)
+        got = m.predict_step(in_idx)
+        close('scores step %d' % step, got, want, atol=2e-6, rtol=3e-4, errs=errs)
+        for mode in ('standard', 'conservative', 'median'):
+            r = m.rank_targets(tgt, 0, mode)
+            t = got[np.arange(pb), tgt][:, None]
+            gt = (got > t).sum(axis=1)
+            eq = (got == t).sum(axis=1)
+            ref = {'standard': gt + 1, 'conservative': gt + eq, 'median': gt + 0.5 * (eq - 1) + 1}[mode]
+            np.testing.assert_array_equal(r, ref.astype(np.float32))
+    # subset of items + hidden-state maintenance
+    sel = rng.permutation(I)[:77]
+    in_idx = rng.randint(0, I, size=pb)
+    zero = (rng.rand(pb) < 0.3)
+    for i in range(len(H)):
+        H[i] = H[i].copy()
+        H[i][zero] = 0
+    m.predict_hidden(zero_mask=zero.astype(np.uint8))
+    want, H = o.predict_step(H, in_idx, sel)
+    got = m.predict_step(in_idx, sel)
+    close('scores subset', got, want, atol=2e-6, rtol=3e-4, errs=errs)
+    keep = np.sort(rng.permutation(pb)[:31]).astype(np.int32)
+    m.predict_hidden(keep_rows=keep)
+    H = [h[keep] for h in H]
+    in_idx = rng.randint(0, I, size=len(keep))
+    want, H = o.predict_step(H, in_idx)
+    got = m.predict_step(in_idx)
+    close('scores after compaction', got, want, atol=2e-6, rtol=3e-4, errs=errs)
+    assert not errs, errs
