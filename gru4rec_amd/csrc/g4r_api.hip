@@ -34,7 +34,8 @@ static const char* KN_NAMES[KN_COUNT] = {"k_gru_fwd", "k_score_fwd", "k_loss_row
 
 struct g4r_model {
     g4r_config cfg;
-    DevModel dm;
+    DevModel dm;                 // host master copy of the device-resident model descriptor
+    DevModel* d_dm = nullptr;    // what the kernels read (passed by pointer: 8-byte kernarg)
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;
     // plan
@@ -93,6 +94,12 @@ static void dfree(g4r_model* m, void* p) {
     (void)hipFree(p);
 }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+// publish the host descriptor to the device copy (stream-ordered; pageable source is staged before return)
+static int sync_dm(g4r_model* m) {
+    HIPCHK(hipMemcpyAsync(m->d_dm, &m->dm, sizeof(DevModel), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
 
 extern "C" {
 
@@ -199,10 +206,20 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         std::vector<DenseTile> tiles;
         for (int l = 0; l < L; ++l) {
             const int D = d.D[l], IN = d.IN[l];
-            for (int r = 0; r < IN; r += 16) for (int c = 0; c < 3 * D; c += 16) tiles.push_back({l, 0, r, c});
-            for (int r = 0; r < D; r += 16) for (int c = 0; c < D; c += 16) tiles.push_back({l, 1, r, c});
-            for (int r = 0; r < D; r += 16) for (int c = 0; c < 2 * D; c += 16) tiles.push_back({l, 2, r, c});
-            for (int c = 0; c < 3 * D; c += 16) tiles.push_back({l, 3, 0, c});
+            auto add = [&](const float* x0, const float* x1, int ldx, int nrows, int ncols, int coff, int ldo, long long base) {
+                for (int r = 0; r < nrows; r += 16)
+                    for (int c = 0; c < ncols; c += 16) {
+                        DenseTile t;
+                        t.X0 = x0; t.X1 = x1; t.dV = d.dV[l]; t.base = base; t.ldx = ldx; t.ldv = 3 * D; t.nrows = nrows;
+                        t.ncols = ncols; t.coff = coff; t.ldo = ldo; t.r0 = r; t.c0 = c;
+                        tiles.push_back(t);
+                    }
+            };
+            const float* yin = (l == 0) ? d.yin0 : d.hd[l - 1];
+            add(yin, yin, IN, IN, 3 * D, 0, 3 * D, d.offWx[l]);                   // dWx  = yin^T dV
+            add(d.Hr[l], d.Hr[l], D, D, D, 0, D, d.offWh[l]);                     // dWh  = (H r)^T dV[:, :D]
+            add(d.H[l][0], d.H[l][1], D, D, 2 * D, D, 2 * D, d.offWrz[l]);        // dWrz = H^T dV[:, D:]
+            add(nullptr, nullptr, 0, 1, 3 * D, 0, 3 * D, d.offBh[l]);             // dBh  = colsum(dV)
         }
         m->ntiles = (int)tiles.size();
         DA(m->d_tiles, tiles.size());
@@ -229,7 +246,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     (void)hipFuncSetAttribute((const void*)k_score_all<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void*)k_loss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel"); }
-    if (hipStreamSynchronize(m->stream) != hipSuccess) { g4r_destroy(m); return fail("sync"); }
+    if (dalloc(m, &m->d_dm, 1) || sync_dm(m)) { g4r_destroy(m); return -1; }
     *out = m;
     return 0;
 }
@@ -319,6 +336,7 @@ int g4r_set_popularity(g4r_model* m, const float* cum_p, const float* lq_tgt, co
         m->dm.lq_tgt = m->d_lqt; m->dm.lq_smp = m->d_lqs;
     }
     m->have_pop = true;
+    if (sync_dm(m)) return -1;
     if (m->dm.ns > 0 && !m->store_frozen) {
         m->refills = 0;
         if (refill_store(m)) return -1;     // gru4rec.py:564 generate_samples()
@@ -434,9 +452,8 @@ int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
     m->T = T;
     m->dm.in_idx = m->d_in; m->dm.out_idx = m->d_out; m->dm.reset = m->d_reset; m->dm.Mplan = m->d_M;
     m->dm.loss_steps = m->d_loss;
-    HIPCHK(hipStreamSynchronize(m->stream));
-    if (m->gexec) { (void)hipGraphExecDestroy(m->gexec); m->gexec = nullptr; }   // kernel args embed plan pointers
-    return 0;
+    // the captured graph stays valid: kernels read the plan pointers from the device descriptor
+    return sync_dm(m);
 }
 
 // ------------------------------------------------------------------------------------------------ the step
@@ -456,32 +473,48 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
         (void)hipEventRecord(r.a, s);
         recs->push_back(r);
     };
-    auto end = [&]() { if (recs) (void)hipEventRecord(recs->back().b, s); };
+    static const bool trace = getenv("G4R_TRACE") != nullptr;
+    int trace_kn = -1;
+    auto begin0 = begin;
+    auto begin_t = [&](int kn) {
+        trace_kn = kn;
+        if (trace) { fprintf(stderr, "[g4r] launch %s\n", KN_NAMES[kn]); fflush(stderr); }
+        begin0(kn);
+    };
+    auto end = [&]() {
+        if (recs) (void)hipEventRecord(recs->back().b, s);
+        if (trace) {
+            hipError_t e = hipStreamSynchronize(s);
+            fprintf(stderr, "[g4r] done   %s: %s\n", KN_NAMES[trace_kn], hipGetErrorString(e));
+            fflush(stderr);
+        }
+    };
+#define begin begin_t
     for (int l = 0; l < L; ++l) {
         begin(KN_GRU_FWD);
-        hipLaunchKernelGGL(k_gru_fwd, dim3(cdiv(B, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_fwd[l], s, d, l, 1, l == 0 ? 1 : 0, nopa);
+        hipLaunchKernelGGL(k_gru_fwd, dim3(cdiv(B, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_fwd[l], s, (const DevModel*)m->d_dm, l, 1, l == 0 ? 1 : 0, nopa);
         end();
     }
     begin(KN_SCORE_FWD);
     {
         const size_t sm = ((size_t)(SC_BM + m->tn) * (SC_KC + 2) + m->tn) * sizeof(float);
-        if (m->tn == 32) hipLaunchKernelGGL(k_score_fwd<32>, dim3(cdiv(d.N, 32), cdiv(B, SC_BM)), dim3(256), sm, s, d);
-        else hipLaunchKernelGGL(k_score_fwd<16>, dim3(cdiv(d.N, 16), cdiv(B, SC_BM)), dim3(256), sm, s, d);
+        if (m->tn == 32) hipLaunchKernelGGL(k_score_fwd<32>, dim3(cdiv(d.N, 32), cdiv(B, SC_BM)), dim3(256), sm, s, (const DevModel*)m->d_dm);
+        else hipLaunchKernelGGL(k_score_fwd<16>, dim3(cdiv(d.N, 16), cdiv(B, SC_BM)), dim3(256), sm, s, (const DevModel*)m->d_dm);
     }
     end();
     begin(KN_LOSS);
-    hipLaunchKernelGGL(k_loss_rows, dim3(B), dim3(256), m->smem_loss, s, d);
+    hipLaunchKernelGGL(k_loss_rows, dim3(B), dim3(256), m->smem_loss, s, (const DevModel*)m->d_dm);
     end();
     begin(KN_SCORE_BWD);
-    hipLaunchKernelGGL(k_score_bwd, dim3(m->nblkA + m->nblkB), dim3(256), 0, s, d, m->nwavesA, m->nblkA);
+    hipLaunchKernelGGL(k_score_bwd, dim3(m->nblkA + m->nblkB), dim3(256), 0, s, (const DevModel*)m->d_dm, m->nwavesA, m->nblkA);
     end();
     for (int l = L - 1; l >= 0; --l) {
         begin(KN_GRU_BWD);
-        hipLaunchKernelGGL(k_gru_bwd_rows, dim3(cdiv(B, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_bwd[l], s, d, l);
+        hipLaunchKernelGGL(k_gru_bwd_rows, dim3(cdiv(B, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_bwd[l], s, (const DevModel*)m->d_dm, l);
         end();
     }
     begin(KN_DENSE);
-    hipLaunchKernelGGL(k_dense_grad, dim3(cdiv(m->ntiles, 4)), dim3(256), 0, s, d, (const DenseTile*)m->d_tiles, m->ntiles);
+    hipLaunchKernelGGL(k_dense_grad, dim3(cdiv(m->ntiles, 4)), dim3(256), 0, s, (const DevModel*)m->d_dm, (const DenseTile*)m->d_tiles, m->ntiles);
     end();
     if (!d.apply_dense_inplace) {
         if (!m->comm_ready) return fail("nranks > 1 but g4r_comm_init was not called");
@@ -489,12 +522,13 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
         NCCLCHK(ncclAllReduce(d.dense_g, d.dense_g, d.dense_count, ncclFloat, ncclSum, m->comm, s));
         end();
         begin(KN_DENSE_APPLY);
-        hipLaunchKernelGGL(k_dense_apply, dim3(cdiv(d.dense_count, 256)), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k_dense_apply, dim3(cdiv(d.dense_count, 256)), dim3(256), 0, s, (const DevModel*)m->d_dm);
         end();
     }
     begin(KN_SPARSE);
-    hipLaunchKernelGGL(k_sparse_update, dim3(m->nblk_occ + 1), dim3(256), 0, s, d, m->nblk_occ);
+    hipLaunchKernelGGL(k_sparse_update, dim3(m->nblk_occ + 1), dim3(256), 0, s, (const DevModel*)m->d_dm, m->nblk_occ);
     end();
+#undef begin
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -702,11 +736,11 @@ int g4r_predict_step(g4r_model* m, const int32_t* in_idx, int32_t mrows, const i
         pa.Hnext = m->pH[l][m->ppar ^ 1];
         pa.hout = m->phout[l];
         pa.M = mrows;
-        hipLaunchKernelGGL(k_gru_fwd, dim3(cdiv(mrows, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_fwd[l], m->stream, d, l, 0, 0, pa);
+        hipLaunchKernelGGL(k_gru_fwd, dim3(cdiv(mrows, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_fwd[l], m->stream, (const DevModel*)m->d_dm, l, 0, 0, pa);
     }
     m->ppar ^= 1;
     const bool sm = (d.final_act == G4R_ACT_SOFTMAX);
-    hipLaunchKernelGGL(k_score_all<32>, dim3(cdiv(n_sel, 32), cdiv(mrows, SC_BM)), dim3(256), m->smem_score, m->stream, d,
+    hipLaunchKernelGGL(k_score_all<32>, dim3(cdiv(n_sel, 32), cdiv(mrows, SC_BM)), dim3(256), m->smem_score, m->stream, (const DevModel*)m->d_dm,
                        (const float*)m->phout[d.n_layers - 1], (int)mrows, item_idx ? (const int*)m->p_items : (const int*)nullptr,
                        (long long)n_sel, m->p_scores, (long long)ldo, sm ? 0 : 1);
     if (sm) hipLaunchKernelGGL(k_softmax_rows, dim3(mrows), dim3(256), 0, m->stream, m->p_scores, (long long)n_sel, (long long)ldo);

@@ -8,9 +8,10 @@
 #include "g4r_train_kernels.cuh"
 
 template <int TN>
-__global__ __launch_bounds__(256) void k_score_all(DevModel m, const float* h, int mrows, const int* item_idx,
+__global__ __launch_bounds__(256) void k_score_all(const DevModel* __restrict__ mp, const float* h, int mrows, const int* item_idx,
                                                    long long n_sel, float* out, long long ldo, int apply_act) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevModel& m = *mp;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int D = m.Dtop;
     const int ldk = SC_KC + 2;

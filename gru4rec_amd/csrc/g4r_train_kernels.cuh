@@ -47,7 +47,8 @@ struct GruFwdPredict {
     int M;
 };
 
-__global__ __launch_bounds__(GRU_NW * 64) void k_gru_fwd(DevModel m, int l, int train, int first, GruFwdPredict pa) {
+__global__ __launch_bounds__(GRU_NW * 64) void k_gru_fwd(const DevModel* __restrict__ mp, int l, int train, int first, GruFwdPredict pa) {
+    const DevModel& m = *mp;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int D = m.D[l], IN = m.IN[l], D3 = 3 * D;
@@ -229,7 +230,8 @@ __global__ __launch_bounds__(GRU_NW * 64) void k_gru_fwd(DevModel m, int l, int 
 #define SC_BM 128
 #define SC_KC 128
 template <int TN>
-__global__ __launch_bounds__(256) void k_score_fwd(DevModel m) {
+__global__ __launch_bounds__(256) void k_score_fwd(const DevModel* __restrict__ mp) {
+    const DevModel& m = *mp;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lg = lane >> 4;
     const StepCtx c = load_ctx(m);
@@ -315,7 +317,8 @@ __global__ __launch_bounds__(256) void k_score_fwd(DevModel m) {
 // Column j is active iff j < M (in-batch targets) or j >= B (sampled negatives); row i's positive is
 // column i.  Losses: gru4rec.py:225-230 (cross_entropy), :239-241 (bpr_max), :245-248 (top1_max),
 // softmax_neg :199-203.  The gradient goes through the softmax weights, as T.grad does.
-__global__ __launch_bounds__(256) void k_loss_rows(DevModel m) {
+__global__ __launch_bounds__(256) void k_loss_rows(const DevModel* __restrict__ mp) {
+    const DevModel& m = *mp;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const StepCtx c = load_ctx(m);
@@ -437,7 +440,8 @@ __global__ __launch_bounds__(256) void k_loss_rows(DevModel m) {
 // (16 rows) x (<=4 tiles of d) x K-chunk, float4 reads of ds along n (K-permuted MFMA operands).
 // All operands come straight from L2 (the whole step working set is L2/MALL resident).
 #define SB_DG 4
-__global__ __launch_bounds__(256) void k_score_bwd(DevModel m, int nwavesA, int nblkA) {
+__global__ __launch_bounds__(256) void k_score_bwd(const DevModel* __restrict__ mp, int nwavesA, int nblkA) {
+    const DevModel& m = *mp;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lg = lane >> 4;
     const StepCtx c = load_ctx(m);
     const int M = c.M, B = m.B, D = m.Dtop, N = m.N, ld = m.ldSc;
@@ -539,7 +543,8 @@ __global__ __launch_bounds__(256) void k_score_bwd(DevModel m, int nwavesA, int 
 // GRU backward, row-local part (no BPTT: H is a constant input, gru4rec.py:460-463,576).
 //   dz = dh (c - H) ; dc = dh z ; da = dc act'(c) ; dr = (da Wh^T) H ; d(pre-sigmoid) ; dV = [da | drp | dzp]
 //   dy = dV Wx^T  -> embedding-row gradient dSx (layer 0) or the lower layer's dh.
-__global__ __launch_bounds__(GRU_NW * 64) void k_gru_bwd_rows(DevModel m, int l) {
+__global__ __launch_bounds__(GRU_NW * 64) void k_gru_bwd_rows(const DevModel* __restrict__ mp, int l) {
+    const DevModel& m = *mp;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lg = lane >> 4;
     const StepCtx c = load_ctx(m);
@@ -669,7 +674,14 @@ __global__ __launch_bounds__(GRU_NW * 64) void k_gru_bwd_rows(DevModel m, int l)
 //   dWx = yin^T dV ; dWh = (H r)^T dV[:, :D] ; dWrz = H^T dV[:, D:] ; dBh = colsum(dV)
 // with the dense Adagrad(+momentum) update (gru4rec.py:330-334,390-406) fused into the epilogue when
 // no all-reduce is needed (single GPU); otherwise the gradient goes to dense_g for RCCL.
-struct DenseTile { int layer, kind, r0, c0; };   // kind: 0 Wx, 1 Wh, 2 Wrz, 3 Bh
+// One 16x16 output tile of a dense GRU gradient, resolved on the host: out[r0.., c0..] (leading dim ldo, at
+// float offset `base` of the flat dense buffers) = X^T[., batch] * dV[batch, coff + .] ; X0/X1 = operand for
+// even/odd global step (the hidden state ping-pongs) ; X == nullptr selects the bias row (column sums of dV).
+struct DenseTile {
+    const float *X0, *X1, *dV;
+    long long base;
+    int ldx, ldv, nrows, ncols, coff, ldo, r0, c0;
+};
 
 __device__ __forceinline__ void dense_adagrad(const DevModel& m, size_t off, float g) {
     const float acc = m.dense_acc[off] + g * g;
@@ -685,36 +697,32 @@ __device__ __forceinline__ void dense_adagrad(const DevModel& m, size_t off, flo
     }
 }
 
-__global__ __launch_bounds__(256) void k_dense_grad(DevModel m, const DenseTile* tiles, int ntiles) {
+__global__ __launch_bounds__(256) void k_dense_grad(const DevModel* __restrict__ mp, const DenseTile* __restrict__ tiles, int ntiles) {
+    const DevModel& m = *mp;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int w = blockIdx.x * 4 + wid;
     if (w >= ntiles) return;
     const StepCtx c = load_ctx(m);
-    const DenseTile tl = tiles[w];
-    const int l = tl.layer, D = m.D[l], IN = m.IN[l], D3 = 3 * D, M = c.M;
-    const float* X; int ldx, nrows, ncols, coff, ldo; size_t base;
-    if (tl.kind == 0) { X = (l == 0) ? m.yin0 : m.hd[l - 1]; ldx = IN; nrows = IN; ncols = D3; coff = 0; ldo = D3; base = m.offWx[l]; }
-    else if (tl.kind == 1) { X = m.Hr[l]; ldx = D; nrows = D; ncols = D; coff = 0; ldo = D; base = m.offWh[l]; }
-    else if (tl.kind == 2) { X = m.H[l][c.g & 1]; ldx = D; nrows = D; ncols = 2 * D; coff = D; ldo = 2 * D; base = m.offWrz[l]; }
-    else { X = nullptr; ldx = 0; nrows = 1; ncols = D3; coff = 0; ldo = D3; base = m.offBh[l]; }
-    const float* dV = m.dV[l];
-    const int ra = tl.r0 + li, cb = tl.c0 + li;
+    const DenseTile tl = tiles[w];            // fully resolved on the host: no per-layer lookups here
+    const float* X = (c.g & 1) ? tl.X1 : tl.X0;
+    const float* dV = tl.dV;
+    const int M = c.M, ra = tl.r0 + li, cb = tl.c0 + li;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < M; k += 4) {
         const int b = k + lg;
         float a = 0.f, bv = 0.f;
         if (b < M) {
-            if (tl.kind == 3) a = (li == 0) ? 1.f : 0.f;
-            else if (ra < nrows) a = X[(size_t)b * ldx + ra];
-            if (cb < ncols) bv = dV[(size_t)b * D3 + coff + cb];
+            if (X == nullptr) a = (li == 0) ? 1.f : 0.f;      // bias row: column sums of dV
+            else if (ra < tl.nrows) a = X[(size_t)b * tl.ldx + ra];
+            if (cb < tl.ncols) bv = dV[(size_t)b * tl.ldv + tl.coff + cb];
         }
         acc = mfma16(a, bv, acc);
     }
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
         const int row = tl.r0 + 4 * lg + rg;
-        if (row < nrows && cb < ncols) {
-            const size_t off = base + (size_t)row * ldo + cb;
+        if (row < tl.nrows && cb < tl.ncols) {
+            const size_t off = (size_t)tl.base + (size_t)row * tl.ldo + cb;
             if (m.apply_dense_inplace) dense_adagrad(m, off, acc[rg]);
             else m.dense_g[off] = acc[rg];
         }
@@ -722,7 +730,8 @@ __global__ __launch_bounds__(256) void k_dense_grad(DevModel m, const DenseTile*
 }
 
 // after the RCCL all-reduce: element-wise dense Adagrad on the averaged gradient
-__global__ __launch_bounds__(256) void k_dense_apply(DevModel m) {
+__global__ __launch_bounds__(256) void k_dense_apply(const DevModel* __restrict__ mp) {
+    const DevModel& m = *mp;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < m.dense_count) dense_adagrad(m, (size_t)i, m.dense_g[i] * m.grad_scale);
 }
@@ -806,7 +815,8 @@ __device__ __forceinline__ void sparse_row_update(const DevModel& m, float* P, f
     }
 }
 
-__global__ __launch_bounds__(256) void k_sparse_update(DevModel m, int nblk_occ) {
+__global__ __launch_bounds__(256) void k_sparse_update(const DevModel* __restrict__ mp, int nblk_occ) {
+    const DevModel& m = *mp;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const StepCtx c = load_ctx(m);
     const int B = m.B, R = m.R;
