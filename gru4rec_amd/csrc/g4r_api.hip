@@ -12,6 +12,10 @@
 
 #include "g4r_eval_kernels.cuh"
 
+// Host code below is compiled in the host pass only: on the device pass the descriptor pointer fields are
+// address-space qualified (g4r_device.cuh) and the template kernels are instantiated explicitly.
+#if !defined(__HIP_DEVICE_COMPILE__)
+
 static thread_local std::string g_err;
 static int fail(const std::string& s) { g_err = s; return -1; }
 #define HIPCHK(x)                                                                                        \
@@ -54,7 +58,8 @@ struct g4r_model {
     // launch geometry
     DenseTile* d_tiles = nullptr;
     int ntiles = 0, tn = 32, nwavesA = 0, nblkA = 0, nblkB = 0, nblk_occ = 0;
-    size_t smem_gru_fwd[G4R_MAX_LAYERS], smem_gru_bwd[G4R_MAX_LAYERS], smem_score = 0, smem_loss = 0;
+    size_t smem_gru_fwd[G4R_MAX_LAYERS], smem_gru_bwd[G4R_MAX_LAYERS], smem_score = 0, smem_loss = 0, smem_sparse = 0;
+    int gru_cls[G4R_MAX_LAYERS];
     float* d_tmpH = nullptr;
     // graph
     hipGraphExec_t gexec = nullptr;
@@ -94,6 +99,21 @@ static void dfree(g4r_model* m, void* p) {
     (void)hipFree(p);
 }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// GRU row kernels are instantiated per width class (see g4r_train_kernels.cuh)
+typedef void (*gru_fwd_fn)(const DevModel*, int, int, int, GruFwdPredict);
+typedef void (*gru_bwd_fn)(const DevModel*, int);
+static inline int width_class(int w) { return w <= 128 ? 0 : (w <= 256 ? 1 : 2); }
+static gru_fwd_fn gru_fwd_kernel(int cls) {
+    if (cls == 0) return k_gru_fwd<3, 16, 1, 16>;
+    if (cls == 1) return k_gru_fwd<6, 8, 2, 16>;
+    return k_gru_fwd<12, 4, 4, 8>;
+}
+static gru_bwd_fn gru_bwd_kernel(int cls) {
+    if (cls == 0) return k_gru_bwd_rows<1, 16>;
+    if (cls == 1) return k_gru_bwd_rows<2, 16>;
+    return k_gru_bwd_rows<4, 8>;
+}
 // publish the host descriptor to the device copy (stream-ordered; pageable source is staged before return)
 static int sync_dm(g4r_model* m) {
     HIPCHK(hipMemcpyAsync(m->d_dm, &m->dm, sizeof(DevModel), hipMemcpyHostToDevice, m->stream));
@@ -197,7 +217,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         m->nwavesA = cdiv(d.N, 16) * ndg;
         m->nblkA = cdiv(m->nwavesA, 4);
         m->nblkB = cdiv((long long)d.ksplit * nrt * ndg, 4);
-        m->nblk_occ = cdiv(d.R, 4);
+        m->nblk_occ = cdiv(d.R, SP_WAVES);
+        m->smem_sparse = (size_t)(((d.R + 255) & ~255) + 256) * sizeof(int);
     }
     if (ns > 0) DA(m->d_ST, (size_t)gl * ns);
     d.ST = m->d_ST;
@@ -234,18 +255,24 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         const int D = d.D[l], IN = d.IN[l];
         m->smem_gru_fwd[l] = (size_t)GRU_ROWS * ((D + 2) + std::max(IN + 2, 3 * D + 2)) * sizeof(float);
         m->smem_gru_bwd[l] = (size_t)GRU_ROWS * (3 * D + 2) * sizeof(float);
+        m->gru_cls[l] = width_class(std::max(D, IN));
     }
     m->tn = (cdiv(d.N, 32) * cdiv(B, SC_BM) >= 128) ? 32 : 16;
     m->smem_score = ((size_t)(SC_BM + 32) * (SC_KC + 2) + 32) * sizeof(float);
     m->smem_loss = (size_t)(d.ldSc + 8) * sizeof(float);
     const int big = 160 * 1024;
-    (void)hipFuncSetAttribute((const void*)k_gru_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)k_gru_bwd_rows, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    for (int cls = 0; cls < 3; ++cls) {
+        (void)hipFuncSetAttribute((const void*)gru_fwd_kernel(cls), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)gru_bwd_kernel(cls), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    }
+    (void)hipFuncSetAttribute((const void*)k_sparse_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)k_sparse_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void*)k_score_fwd<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void*)k_score_fwd<16>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void*)k_score_all<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void*)k_loss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel"); }
+    if (getenv("G4R_CLK")) { if (dalloc(m, &d.dbgclk, 64 + 8 * (size_t)d.R)) { g4r_destroy(m); return -1; } }
     if (dalloc(m, &m->d_dm, 1) || sync_dm(m)) { g4r_destroy(m); return -1; }
     *out = m;
     return 0;
@@ -492,7 +519,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
 #define begin begin_t
     for (int l = 0; l < L; ++l) {
         begin(KN_GRU_FWD);
-        hipLaunchKernelGGL(k_gru_fwd, dim3(cdiv(B, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_fwd[l], s, (const DevModel*)m->d_dm, l, 1, l == 0 ? 1 : 0, nopa);
+        hipLaunchKernelGGL(gru_fwd_kernel(m->gru_cls[l]), dim3(cdiv(B, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_fwd[l], s, (const DevModel*)m->d_dm, l, 1, l == 0 ? 1 : 0, nopa);
         end();
     }
     begin(KN_SCORE_FWD);
@@ -510,7 +537,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
     end();
     for (int l = L - 1; l >= 0; --l) {
         begin(KN_GRU_BWD);
-        hipLaunchKernelGGL(k_gru_bwd_rows, dim3(cdiv(B, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_bwd[l], s, (const DevModel*)m->d_dm, l);
+        hipLaunchKernelGGL(gru_bwd_kernel(m->gru_cls[l]), dim3(cdiv(B, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_bwd[l], s, (const DevModel*)m->d_dm, l);
         end();
     }
     begin(KN_DENSE);
@@ -526,7 +553,8 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
         end();
     }
     begin(KN_SPARSE);
-    hipLaunchKernelGGL(k_sparse_update, dim3(m->nblk_occ + 1), dim3(256), 0, s, (const DevModel*)m->d_dm, m->nblk_occ);
+    if (std::max(d.Dtop, d.Ein) <= 256) hipLaunchKernelGGL(k_sparse_update<1>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, (const DevModel*)m->d_dm, m->nblk_occ);
+    else hipLaunchKernelGGL(k_sparse_update<2>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, (const DevModel*)m->d_dm, m->nblk_occ);
     end();
 #undef begin
     HIPCHK(hipGetLastError());
@@ -736,7 +764,7 @@ int g4r_predict_step(g4r_model* m, const int32_t* in_idx, int32_t mrows, const i
         pa.Hnext = m->pH[l][m->ppar ^ 1];
         pa.hout = m->phout[l];
         pa.M = mrows;
-        hipLaunchKernelGGL(k_gru_fwd, dim3(cdiv(mrows, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_fwd[l], m->stream, (const DevModel*)m->d_dm, l, 0, 0, pa);
+        hipLaunchKernelGGL(gru_fwd_kernel(m->gru_cls[l]), dim3(cdiv(mrows, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_fwd[l], m->stream, (const DevModel*)m->d_dm, l, 0, 0, pa);
     }
     m->ppar ^= 1;
     const bool sm = (d.final_act == G4R_ACT_SOFTMAX);
@@ -771,10 +799,6 @@ int g4r_rank_targets(g4r_model* m, const int32_t* target_col, int32_t mrows, int
 }
 
 // ------------------------------------------------------------------------------------------------ RCCL
-__global__ void k_scale(float* p, long long n, float s) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] *= s;
-}
 
 int g4r_comm_unique_id(char* out128) {
     if (!out128) return fail("null argument");
@@ -842,6 +866,7 @@ int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
     else if (s == "dyl") { p = d.dyl[l]; n = bd; }
     else if (s == "Hprev") { p = d.H[l][(m->gstep + 1) & 1]; n = bd; }
     else if (s == "occ_idx") { p = (const float*)d.occ_idx; n = d.R; }
+    else if (s == "dbgclk") { if (!d.dbgclk) return fail("G4R_CLK not set"); p = (const float*)d.dbgclk; n = 2 * (64 + 8 * (int64_t)d.R); }
     else if (s == "ldSc") { if (count < 1) return fail("count"); host[0] = (float)d.ldSc; return 0; }
     else if (s == "ksplit") { if (count < 1) return fail("count"); host[0] = (float)d.ksplit; return 0; }
     else return fail(std::string("unknown debug buffer ") + name);
@@ -873,3 +898,4 @@ int g4r_selftest_mfma(float* max_abs_err) {
 }
 
 }  // extern "C"
+#endif  // !__HIP_DEVICE_COMPILE__

@@ -17,6 +17,26 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define G4R_STREAM_DROP_HIDDEN 0x44484944u
 
 // ---------------------------------------------------------------------------------------------
+// Pointers that the kernels read out of device-resident descriptors (DevModel, DenseTile) would be generic
+// ("flat") to the compiler: flat_load/flat_store also count against lgkmcnt and therefore serialise with every
+// LDS access.  On the device pass the descriptor fields are typed as global-address-space pointers, so every
+// access through them is a global_load/global_store; the host pass sees plain pointers of identical layout.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GAS __attribute__((address_space(1)))
+#else
+#define GAS
+#endif
+#define GP(T) GAS T*
+
+__device__ __forceinline__ float4 ld4(const GAS float* p) { return *(const GAS float4*)p; }
+__device__ __forceinline__ void st4(GAS float* p, float4 v) { *(GAS float4*)p = v; }
+__device__ __forceinline__ int4 ldi4(const GAS int* p) { return *(const GAS int4*)p; }
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ void st4(float* p, float4 v) { *(float4*)p = v; }
+#endif
+
+// ---------------------------------------------------------------------------------------------
 // Device-resident step state.  The step index lives on the device so that a captured hipGraph of
 // step kernels is step-agnostic: the first kernel of a step reads *_a and republishes it as *_b,
 // the middle kernels read *_b, the last kernel writes *_a = *_b + 1.  No kernel both reads and
@@ -41,29 +61,39 @@ struct DevModel {
     // ---- dense GRU parameters: one flat buffer [Wx0|Wh0|Wrz0|Bh0|Wx1|...]
     int offWx[G4R_MAX_LAYERS], offWh[G4R_MAX_LAYERS], offWrz[G4R_MAX_LAYERS], offBh[G4R_MAX_LAYERS];
     int dense_count;
-    float *dense_p, *dense_acc, *dense_vel, *dense_g;
+    GP(float) dense_p; GP(float) dense_acc; GP(float) dense_vel; GP(float) dense_g;
     int apply_dense_inplace;   // 1: Adagrad fused into the gradient kernel (single GPU)
     float grad_scale;          // 1/nranks when gradients are all-reduced
     // ---- sparse tables (row-major, row = item)
-    float *Wy, *accWy, *velWy, *By, *accBy, *velBy, *E, *accE, *velE;
+    GP(float) Wy; GP(float) accWy; GP(float) velWy; GP(float) By; GP(float) accBy; GP(float) velBy;
+    GP(float) E; GP(float) accE; GP(float) velE;
     // ---- per-layer state and saved activations
-    float *H[G4R_MAX_LAYERS][2];
-    float *r[G4R_MAX_LAYERS], *z[G4R_MAX_LAYERS], *c[G4R_MAX_LAYERS], *hd[G4R_MAX_LAYERS], *Hr[G4R_MAX_LAYERS];
-    float *dV[G4R_MAX_LAYERS], *dyl[G4R_MAX_LAYERS];
-    float *yin0;
+    GP(float) H[G4R_MAX_LAYERS][2];
+    GP(float) r[G4R_MAX_LAYERS]; GP(float) z[G4R_MAX_LAYERS]; GP(float) c[G4R_MAX_LAYERS];
+    GP(float) hd[G4R_MAX_LAYERS]; GP(float) Hr[G4R_MAX_LAYERS];
+    GP(float) dV[G4R_MAX_LAYERS]; GP(float) dyl[G4R_MAX_LAYERS];
+    GP(float) yin0;
     // ---- scoring / loss
-    float *Sc, *dSx, *dSy, *dSBy, *dhpart, *lossrow, *loss_steps;
+    GP(float) Sc; GP(float) dSx; GP(float) dSy; GP(float) dSBy; GP(float) dhpart; GP(float) lossrow; GP(float) loss_steps;
     int ksplit, kch;
-    int *occ_idx;   // [R] item of each gathered-row occurrence (X | Y | samples), -1 = inactive
-    int *col_item;  // [ldSc] item of each score column, -1 = inactive
+    GP(int) occ_idx;   // [R] item of each gathered-row occurrence (X | Y | samples), -1 = inactive
+    GP(int) col_item;  // [ldSc] item of each score column, -1 = inactive
     // ---- plan + samples
-    const int *in_idx, *out_idx, *Mplan;
-    const unsigned char* reset;
-    const int* ST;
+    GP(const int) in_idx; GP(const int) out_idx; GP(const int) Mplan;
+    GP(const unsigned char) reset;
+    GP(const int) ST;
     int gl;
-    const float *lq_tgt, *lq_smp;
-    StepState* st;
+    GP(const float) lq_tgt; GP(const float) lq_smp;
+    GP(StepState) st;
+    GP(long long) dbgclk;   // optional [kernel][16] phase timestamps (100 MHz wall clock), block 0 only
 };
+
+// phase timestamp (debug): one lane of block 0 records the constant-rate wall clock
+#define G4R_TICK(m, kern, phase)                                                                     \
+    do {                                                                                             \
+        if ((m).dbgclk && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)                     \
+            (m).dbgclk[(kern) * 16 + (phase)] = wall_clock64();                                       \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
@@ -99,6 +129,35 @@ __device__ __forceinline__ float block_max_256(float v, float* red) {
 // lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; holds D[row = 4*(l>>4)+reg][col = l&15].
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// acc[ti] (16 rows x 16 cols each) += A(16 x K, LDS, row stride lda) * W(K x cols, global/L2).
+// The wave owns up to MAXT column tiles; boff[ti] is this lane's column offset into W (already multiplied
+// by the column stride; < 0 = column out of range) and tmask has bit ti set for tiles that take part.
+// W element (k, col) lives at W[k * sk + boff].  The K loop runs in batches of U k-steps whose operand
+// loads are all issued before the first MFMA of the batch: U*MAXT independent L2 loads in flight per
+// lane instead of one dependent load per MFMA (the step working set is L2 resident, latency is the bound).
+template <int MAXT, int U>
+__device__ __forceinline__ void tile_gemm_rows(f32x4 (&acc)[MAXT], unsigned tmask, const long long (&boff)[MAXT],
+                                               const float* sA, int lda, int K, const GAS float* __restrict__ W,
+                                               long long sk, int li, int lg) {
+    for (int k0 = 0; k0 < K; k0 += 4 * U) {
+        float a[U], b[U][MAXT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = k0 + 4 * u + lg;
+            const bool ok = (k0 + 4 * u) < K;
+            a[u] = ok ? sA[li * lda + kk] : 0.f;
+#pragma unroll
+            for (int ti = 0; ti < MAXT; ++ti)
+                b[u][ti] = (ok && ((tmask >> ti) & 1u) && boff[ti] >= 0) ? W[(long long)kk * sk + boff[ti]] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ti = 0; ti < MAXT; ++ti)
+                if ((tmask >> ti) & 1u) acc[ti] = mfma16(a[u], b[u][ti], acc[ti]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -140,16 +199,24 @@ __device__ __forceinline__ float4 drop_mult4(unsigned long long seed, unsigned g
 }
 
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Hardware transcendentals (v_exp_f32 / v_rcp_f32 / v_rsq_f32, ~1 ulp each): the element-wise chains of the
+// loss / GRU / Adagrad kernels run at one or two waves per SIMD, where the IEEE-exact expf / division / sqrtf
+// expansions (20-40 dependent instructions each) were the critical path.  Relative error <= ~1e-6, far inside
+// the parity tolerance (the fp32 summation-order differences against the oracle are of the same size).
+__device__ __forceinline__ float fexp(float x) { return __expf(x); }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return frcp(1.0f + fexp(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 1.0f - 2.0f * frcp(fexp(2.0f * x) + 1.0f); }
 
 // element-wise activations, gru4rec.py:189-223
 __device__ __forceinline__ float act_fwd(int kind, float p0, float p1, float x) {
     switch (kind) {
         case G4R_ACT_RELU: return fmaxf(x, 0.0f);
-        case G4R_ACT_TANH: return tanhf(x);
+        case G4R_ACT_TANH: return ftanh(x);
         case G4R_ACT_LEAKY: return x >= 0.0f ? x : p0 * x;
-        case G4R_ACT_ELU: return x >= 0.0f ? x : p0 * (expf(x) - 1.0f);
-        case G4R_ACT_SELU: return p0 * (x >= 0.0f ? x : p1 * (expf(x) - 1.0f));
+        case G4R_ACT_ELU: return x >= 0.0f ? x : p0 * (fexp(x) - 1.0f);
+        case G4R_ACT_SELU: return p0 * (x >= 0.0f ? x : p1 * (fexp(x) - 1.0f));
         default: return x;
     }
 }

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_score_all(const DevModel* __restrict__ 
         for (int e = tid; e < SC_BM * kc4; e += 256) {
             const int i = e / kc4, c4 = e - i * kc4, row = rbase + i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < mrows) v = *reinterpret_cast<const float4*>(h + (size_t)row * D + kc0 + 4 * c4);
+            if (row < mrows) v = ld4(h + (size_t)row * D + kc0 + 4 * c4);
             float2* d = reinterpret_cast<float2*>(sA + i * ldk + 4 * c4);
             d[0] = make_float2(v.x, v.y);
             d[1] = make_float2(v.z, v.w);
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_score_all(const DevModel* __restrict__ 
         for (int e = tid; e < TN * kc4; e += 256) {
             const int j = e / kc4, c4 = e - j * kc4, item = sItem[j];
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (item >= 0) v = *reinterpret_cast<const float4*>(m.Wy + (size_t)item * D + kc0 + 4 * c4);
+            if (item >= 0) v = ld4(m.Wy + (size_t)item * D + kc0 + 4 * c4);
             float2* d = reinterpret_cast<float2*>(sB + j * ldk + 4 * c4);
             d[0] = make_float2(v.x, v.y);
             d[1] = make_float2(v.z, v.w);
@@ -132,3 +132,21 @@ __global__ void k_selftest_mfma(const float* A, const float* Bm, float* C, int K
     for (int k = 0; k < K; k += 4) acc = mfma16(A[li * K + k + lg], Bm[(k + lg) * 16 + li], acc);
     for (int rg = 0; rg < 4; ++rg) C[(4 * lg + rg) * 16 + li] = acc[rg];
 }
+
+__global__ void k_scale(float* p, long long n, float s) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] *= s;
+}
+
+// explicit instantiations: the launching host code is not visible to the device pass
+template __global__ void k_gru_fwd<3, 16, 1, 16>(const DevModel*, int, int, int, GruFwdPredict);
+template __global__ void k_gru_fwd<6, 8, 2, 16>(const DevModel*, int, int, int, GruFwdPredict);
+template __global__ void k_gru_fwd<12, 4, 4, 8>(const DevModel*, int, int, int, GruFwdPredict);
+template __global__ void k_gru_bwd_rows<1, 16>(const DevModel*, int);
+template __global__ void k_gru_bwd_rows<2, 16>(const DevModel*, int);
+template __global__ void k_gru_bwd_rows<4, 8>(const DevModel*, int);
+template __global__ void k_sparse_update<1>(const DevModel*, int);
+template __global__ void k_sparse_update<2>(const DevModel*, int);
+template __global__ void k_score_fwd<32>(const DevModel*);
+template __global__ void k_score_fwd<16>(const DevModel*);
+template __global__ void k_score_all<32>(const DevModel*, const float*, int, const int*, long long, float*, long long, int);

@@ -13,8 +13,9 @@
 
 #define GRU_NW 8          // waves per workgroup in the GRU row kernels
 #define GRU_ROWS 16       // batch rows per workgroup (one MFMA tile high)
-#define GRU_MAXT 12       // max 16-col tiles per wave in phase 1  (=> 3*D <= 16*12*8)
-#define GRU_MAXT2 4       // max tiles per wave for D- or IN-wide outputs (=> D, IN <= 512)
+// The GRU row kernels are compiled for three width classes (max(D, IN) <= 128 / 256 / 512):
+//   T1 = 16-col tiles per wave over 3D columns, T2 = tiles per wave over D (or IN) columns,
+//   U1/U2 = k-steps whose operand loads are batched ahead of the MFMAs (see tile_gemm_rows).
 
 struct StepCtx { long long t, g; int M; };
 
@@ -39,14 +40,15 @@ __device__ __forceinline__ StepCtx load_ctx(const DevModel& m) {
 // (train = 1: step context from device state, dropout, reset switch, activations saved) and for
 // prediction (train = 0: explicit arguments, gru4rec.py:433 predict=True).
 struct GruFwdPredict {
-    const int* in_idx;   // device, layer 0 gather indices
-    const float* ysrc;   // layer > 0 input rows
-    const float* Hcur;
-    float* Hnext;
-    float* hout;         // [rows][D]
+    GP(const int) in_idx;   // device, layer 0 gather indices
+    GP(const float) ysrc;   // layer > 0 input rows
+    GP(const float) Hcur;
+    GP(float) Hnext;
+    GP(float) hout;         // [rows][D]
     int M;
 };
 
+template <int T1, int U1, int T2, int U2>
 __global__ __launch_bounds__(GRU_NW * 64) void k_gru_fwd(const DevModel* __restrict__ mp, int l, int train, int first, GruFwdPredict pa) {
     const DevModel& m = *mp;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -58,9 +60,9 @@ __global__ __launch_bounds__(GRU_NW * 64) void k_gru_fwd(const DevModel* __restr
     float* sV = sY;                                 // [16][ldv]  V(+G) (after phase 1; aliases sY)
     long long t = 0, g = 0;
     int M;
-    const float *Hcur, *ysrc = nullptr;
-    float* Hnext;
-    const int* gidx = nullptr;
+    const GAS float *Hcur, *ysrc = nullptr;
+    GAS float* Hnext;
+    const GAS int* gidx = nullptr;
     if (train) {
         StepCtx c = first ? load_ctx_first(m) : load_ctx(m);
         t = c.t; g = c.g; M = c.M;
@@ -68,29 +70,31 @@ __global__ __launch_bounds__(GRU_NW * 64) void k_gru_fwd(const DevModel* __restr
         Hnext = m.H[l][(g + 1) & 1];
         if (l == 0) gidx = m.in_idx + t * m.B; else ysrc = m.hd[l - 1];
     } else {
-        M = pa.M; Hcur = pa.Hcur; Hnext = pa.Hnext; gidx = pa.in_idx; ysrc = pa.ysrc;
+        M = pa.M; Hcur = pa.Hcur; Hnext = pa.Hnext; gidx = pa.in_idx; ysrc = pa.ysrc;   // kernel arguments: already global
     }
+    G4R_TICK(m, 0, 0);
+    if (m.dbgclk && train && first && blockIdx.x == 0 && threadIdx.x < 4) m.dbgclk[32 + threadIdx.x] = 0;   // per-step debug stats
     const int r0 = blockIdx.x * GRU_ROWS;
     if (train && l == 0 && tid < GRU_ROWS) {
         const int row = r0 + tid;
         if (row < m.B) m.occ_idx[row] = row < M ? gidx[row] : -1;
     }
     if (r0 >= M) return;
-    const float* table = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.Wy : m.E;
+    const GAS float* table = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.Wy : m.E;
     const float retain_e = 1.0f - m.drop_e, retain_h = 1.0f - m.drop_h;
     // ---- stage input rows (gather + embedding dropout) and hidden rows
     for (int e = tid; e < GRU_ROWS * (IN >> 2); e += GRU_NW * 64) {
         const int i = e / (IN >> 2), c4 = e - i * (IN >> 2), row = r0 + i;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < M) {
-            const float* src = (l == 0) ? table + (size_t)gidx[row] * IN : ysrc + (size_t)row * IN;
-            v = *reinterpret_cast<const float4*>(src + 4 * c4);
+            const GAS float* src = (l == 0) ? table + (size_t)gidx[row] * IN : ysrc + (size_t)row * IN;
+            v = ld4(src + 4 * c4);
             if (train && l == 0) {
                 if (m.drop_e > 0.f) {
                     const float4 mk = drop_mult4(m.seed, (unsigned)g, G4R_STREAM_DROP_EMBED, row, c4, retain_e);
                     v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
                 }
-                *reinterpret_cast<float4*>(m.yin0 + (size_t)row * IN + 4 * c4) = v;
+                st4(m.yin0 + (size_t)row * IN + 4 * c4, v);
             }
         }
         float2* d = reinterpret_cast<float2*>(sY + i * ldy + 4 * c4);
@@ -100,54 +104,37 @@ __global__ __launch_bounds__(GRU_NW * 64) void k_gru_fwd(const DevModel* __restr
     for (int e = tid; e < GRU_ROWS * (D >> 2); e += GRU_NW * 64) {
         const int i = e / (D >> 2), c4 = e - i * (D >> 2), row = r0 + i;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < M) v = *reinterpret_cast<const float4*>(Hcur + (size_t)row * D + 4 * c4);
+        if (row < M) v = ld4(Hcur + (size_t)row * D + 4 * c4);
         float2* d = reinterpret_cast<float2*>(sH + i * ldh + 4 * c4);
         d[0] = make_float2(v.x, v.y);
         d[1] = make_float2(v.z, v.w);
     }
     __syncthreads();
-    const float* Wx = m.dense_p + m.offWx[l];
-    const float* Wh = m.dense_p + m.offWh[l];
-    const float* Wrz = m.dense_p + m.offWrz[l];
-    const float* Bh = m.dense_p + m.offBh[l];
+    G4R_TICK(m, 0, 1);
+    const GAS float* Wx = m.dense_p + m.offWx[l];
+    const GAS float* Wh = m.dense_p + m.offWh[l];
+    const GAS float* Wrz = m.dense_p + m.offWrz[l];
+    const GAS float* Bh = m.dense_p + m.offBh[l];
     // ---- phase 1: V = y Wx (+ Bh) ; columns >= D additionally get H Wrz      (gru4rec.py:472-473)
     const int nct = (D3 + 15) >> 4;
-    int ntw = 0;
-    for (int ct = wid; ct < nct; ct += GRU_NW) ++ntw;
-    f32x4 acc[GRU_MAXT];
+    f32x4 acc[T1];
+    long long bx[T1], bh[T1];
+    unsigned mx = 0, mh = 0;
 #pragma unroll
-    for (int ti = 0; ti < GRU_MAXT; ++ti) acc[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < IN; k += 4) {
-        const float a = sY[li * ldy + k + lg];
-        const float* wrow = Wx + (size_t)(k + lg) * D3;
-#pragma unroll
-        for (int ti = 0; ti < GRU_MAXT; ++ti) {
-            if (ti < ntw) {
-                const int col = (wid + ti * GRU_NW) * 16 + li;
-                const float b = col < D3 ? wrow[col] : 0.f;
-                acc[ti] = mfma16(a, b, acc[ti]);
-            }
-        }
+    for (int ti = 0; ti < T1; ++ti) {
+        acc[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int ct = wid + ti * GRU_NW, col = ct * 16 + li;
+        bx[ti] = col < D3 ? col : -1;
+        bh[ti] = (col >= D && col < D3) ? col - D : -1;
+        if (ct < nct) { mx |= 1u << ti; if (ct * 16 + 15 >= D) mh |= 1u << ti; }
     }
-    for (int k = 0; k < D; k += 4) {
-        const float a = sH[li * ldh + k + lg];
-        const float* wrow = Wrz + (size_t)(k + lg) * (2 * D);
-#pragma unroll
-        for (int ti = 0; ti < GRU_MAXT; ++ti) {
-            if (ti < ntw) {
-                const int c0 = (wid + ti * GRU_NW) * 16;
-                if (c0 + 15 >= D) {   // wave-uniform: tile touches the r/z column blocks
-                    const int col = c0 + li;
-                    const float b = (col >= D && col < D3) ? wrow[col - D] : 0.f;
-                    acc[ti] = mfma16(a, b, acc[ti]);
-                }
-            }
-        }
-    }
+    tile_gemm_rows<T1, U1>(acc, mx, bx, sY, ldy, IN, Wx, D3, li, lg);
+    tile_gemm_rows<T1, U1>(acc, mh, bh, sH, ldh, D, Wrz, 2 * D, li, lg);
     __syncthreads();   // every wave is done reading sY before sV (same memory) is written
+    G4R_TICK(m, 0, 2);
 #pragma unroll
-    for (int ti = 0; ti < GRU_MAXT; ++ti) {
-        if (ti < ntw) {
+    for (int ti = 0; ti < T1; ++ti) {
+        if ((mx >> ti) & 1u) {
             const int col = (wid + ti * GRU_NW) * 16 + li;
             if (col < D3) {
                 const float bias = Bh[col];
@@ -157,6 +144,7 @@ __global__ __launch_bounds__(GRU_NW * 64) void k_gru_fwd(const DevModel* __restr
         }
     }
     __syncthreads();
+    G4R_TICK(m, 0, 3);
     // ---- gates: r, z = sigmoid ; sH <- H*r ; z kept in sV
     for (int e = tid; e < GRU_ROWS * D; e += GRU_NW * 64) {
         const int i = e / D, d = e - i * D, row = r0 + i;
@@ -172,29 +160,24 @@ __global__ __launch_bounds__(GRU_NW * 64) void k_gru_fwd(const DevModel* __restr
         }
     }
     __syncthreads();
+    G4R_TICK(m, 0, 4);
     // ---- phase 2: c = act((H*r) Wh + V_c) ; h = (1-z) H + z c ; dropout ; reset   (gru4rec.py:474-479)
     const int nct2 = (D + 15) >> 4;
-    int ntw2 = 0;
-    for (int ct = wid; ct < nct2; ct += GRU_NW) ++ntw2;
-    f32x4 acc2[GRU_MAXT2];
+    f32x4 acc2[T2];
+    long long b2[T2];
+    unsigned m2 = 0;
 #pragma unroll
-    for (int ti = 0; ti < GRU_MAXT2; ++ti) acc2[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < D; k += 4) {
-        const float a = sH[li * ldh + k + lg];
-        const float* wrow = Wh + (size_t)(k + lg) * D;
-#pragma unroll
-        for (int ti = 0; ti < GRU_MAXT2; ++ti) {
-            if (ti < ntw2) {
-                const int col = (wid + ti * GRU_NW) * 16 + li;
-                const float b = col < D ? wrow[col] : 0.f;
-                acc2[ti] = mfma16(a, b, acc2[ti]);
-            }
-        }
+    for (int ti = 0; ti < T2; ++ti) {
+        acc2[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int ct = wid + ti * GRU_NW, col = ct * 16 + li;
+        b2[ti] = col < D ? col : -1;
+        if (ct < nct2) m2 |= 1u << ti;
     }
-    const unsigned char* rst = train ? m.reset + t * m.B : nullptr;
+    tile_gemm_rows<T2, U2>(acc2, m2, b2, sH, ldh, D, Wh, D, li, lg);
+    const GAS unsigned char* rst = train ? m.reset + t * m.B : nullptr;
 #pragma unroll
-    for (int ti = 0; ti < GRU_MAXT2; ++ti) {
-        if (ti < ntw2) {
+    for (int ti = 0; ti < T2; ++ti) {
+        if ((m2 >> ti) & 1u) {
             const int col = (wid + ti * GRU_NW) * 16 + li;
             if (col < D) {
 #pragma unroll
@@ -221,6 +204,7 @@ __global__ __launch_bounds__(GRU_NW * 64) void k_gru_fwd(const DevModel* __restr
             }
         }
     }
+    G4R_TICK(m, 0, 5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -260,13 +244,13 @@ __global__ __launch_bounds__(256) void k_score_fwd(const DevModel* __restrict__ 
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < CT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* hsrc = m.hd[m.n_layers - 1];
+    const GAS float* hsrc = m.hd[m.n_layers - 1];
     for (int kc0 = 0; kc0 < D; kc0 += SC_KC) {
         const int kc = min(SC_KC, D - kc0), kc4 = kc >> 2;
         for (int e = tid; e < SC_BM * kc4; e += 256) {
             const int i = e / kc4, c4 = e - i * kc4, row = rbase + i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < M) v = *reinterpret_cast<const float4*>(hsrc + (size_t)row * D + kc0 + 4 * c4);
+            if (row < M) v = ld4(hsrc + (size_t)row * D + kc0 + 4 * c4);
             float2* d = reinterpret_cast<float2*>(sA + i * ldk + 4 * c4);
             d[0] = make_float2(v.x, v.y);
             d[1] = make_float2(v.z, v.w);
@@ -274,7 +258,7 @@ __global__ __launch_bounds__(256) void k_score_fwd(const DevModel* __restrict__ 
         for (int e = tid; e < TN * kc4; e += 256) {
             const int j = e / kc4, c4 = e - j * kc4, item = sItem[j];
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (item >= 0) v = *reinterpret_cast<const float4*>(m.Wy + (size_t)item * D + kc0 + 4 * c4);
+            if (item >= 0) v = ld4(m.Wy + (size_t)item * D + kc0 + 4 * c4);
             float2* d = reinterpret_cast<float2*>(sB + j * ldk + 4 * c4);
             d[0] = make_float2(v.x, v.y);
             d[1] = make_float2(v.z, v.w);
@@ -326,7 +310,7 @@ __global__ __launch_bounds__(256) void k_loss_rows(const DevModel* __restrict__ 
     if (i >= M) return;
     float* sy = smem;              // [ldSc] yhat, later d/ds
     float* red = smem + m.ldSc;    // [8]
-    float* row = m.Sc + (size_t)i * m.ldSc;
+    GAS float* row = m.Sc + (size_t)i * m.ldSc;
 #define ACTIVE(j) ((j) < M || (j) >= B)
     // ---- final activation (gru4rec.py:496)
     if (m.final_act == G4R_ACT_SOFTMAX) {
@@ -336,10 +320,11 @@ __global__ __launch_bounds__(256) void k_loss_rows(const DevModel* __restrict__ 
         mx = block_max_256(mx, red);
         float sm = 0.f;
         for (int j = tid; j < N; j += 256)
-            if (ACTIVE(j)) { const float e = expf(sy[j] - mx); sy[j] = e; sm += e; }
+            if (ACTIVE(j)) { const float e = fexp(sy[j] - mx); sy[j] = e; sm += e; }
         sm = block_sum_256(sm, red);
+        const float inv_z = 1.f / sm;
         for (int j = tid; j < N; j += 256)
-            if (ACTIVE(j)) sy[j] = sy[j] / sm;
+            if (ACTIVE(j)) sy[j] = sy[j] * inv_z;
     } else {
         for (int j = tid; j < N; j += 256)
             if (ACTIVE(j)) sy[j] = act_fwd(m.final_act, m.fa_p0, m.fa_p1, row[j]);
@@ -370,14 +355,14 @@ __global__ __launch_bounds__(256) void k_loss_rows(const DevModel* __restrict__ 
         mx = block_max_256(mx, red);
         float sm = 0.f;
         for (int j = tid; j < N; j += 256)
-            if (ACTIVE(j) && j != i) sm += expf(sy[j] - mx);
+            if (ACTIVE(j) && j != i) sm += fexp(sy[j] - mx);
         sm = block_sum_256(sm, red);
         const float inv_sm = 1.f / sm;
         float s1 = 0.f, s2 = 0.f, s3 = 0.f;
         if (m.loss == G4R_LOSS_BPR_MAX) {
             for (int j = tid; j < N; j += 256)
                 if (ACTIVE(j) && j != i) {
-                    const float y = sy[j], p = expf(y - mx) * inv_sm, sg = sigmoidf_(yd - y);
+                    const float y = sy[j], p = fexp(y - mx) * inv_sm, sg = sigmoidf_(yd - y);
                     s1 += sg * p;                 // A
                     s2 += y * y * p;              // Q
                     s3 += sg * (1.f - sg) * p;    // sum sigma' p
@@ -385,7 +370,7 @@ __global__ __launch_bounds__(256) void k_loss_rows(const DevModel* __restrict__ 
         } else {
             for (int j = tid; j < N; j += 256)
                 if (ACTIVE(j) && j != i) {
-                    const float y = sy[j], p = expf(y - mx) * inv_sm, u = sigmoidf_(y - yd), q = sigmoidf_(y * y);
+                    const float y = sy[j], p = fexp(y - mx) * inv_sm, u = sigmoidf_(y - yd), q = sigmoidf_(y * y);
                     s1 += p * (u + q);            // T
                     s3 += p * u * (1.f - u);
                 }
@@ -394,9 +379,10 @@ __global__ __launch_bounds__(256) void k_loss_rows(const DevModel* __restrict__ 
         s2 = block_sum_256(s2, red);
         s3 = block_sum_256(s3, red);
         float dyd;
+        const float inv_A = 1.f / (s1 + G4R_EPS_LOSS);
         if (m.loss == G4R_LOSS_BPR_MAX) {
             Lrow = -logf(s1 + G4R_EPS_LOSS) + m.bpreg * s2;
-            dyd = -s3 / (s1 + G4R_EPS_LOSS);
+            dyd = -s3 * inv_A;
         } else {
             Lrow = s1;
             dyd = -s3;
@@ -410,10 +396,10 @@ __global__ __launch_bounds__(256) void k_loss_rows(const DevModel* __restrict__ 
                 float d;
                 if (j == i) d = dyd;
                 else {
-                    const float p = expf(y - mx) * inv_sm;
+                    const float p = fexp(y - mx) * inv_sm;
                     if (m.loss == G4R_LOSS_BPR_MAX) {
                         const float sg = sigmoidf_(yd - y);
-                        d = -p * (sg - sg * (1.f - sg) - s1) / (s1 + G4R_EPS_LOSS) + m.bpreg * p * (2.f * y + y * y - s2);
+                        d = -p * (sg - sg * (1.f - sg) - s1) * inv_A + m.bpreg * p * (2.f * y + y * y - s2);
                     } else {
                         const float u = sigmoidf_(y - yd), q = sigmoidf_(y * y);
                         d = p * (u + q - s1) + p * (u * (1.f - u) + 2.f * y * q * (1.f - q));
@@ -446,7 +432,7 @@ __global__ __launch_bounds__(256) void k_score_bwd(const DevModel* __restrict__ 
     const StepCtx c = load_ctx(m);
     const int M = c.M, B = m.B, D = m.Dtop, N = m.N, ld = m.ldSc;
     const int ndt = (D + 15) >> 4, ndg = (ndt + SB_DG - 1) / SB_DG;
-    const float* h = m.hd[m.n_layers - 1];
+    const GAS float* h = m.hd[m.n_layers - 1];
     if ((int)blockIdx.x < nblkA) {
         const int w = blockIdx.x * 4 + wid;
         if (w >= nwavesA) return;
@@ -456,18 +442,25 @@ __global__ __launch_bounds__(256) void k_score_bwd(const DevModel* __restrict__ 
 #pragma unroll
         for (int q = 0; q < SB_DG; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
         float asum = 0.f;
-        for (int k = 0; k < M; k += 4) {
-            const int b = k + lg;
-            const float a = (b < M) ? m.Sc[(size_t)b * ld + n] : 0.f;   // n < ldSc always (padded, zero-filled)
-            asum += a;
+        constexpr int UA = 8;     // (1 + SB_DG) * UA independent loads per lane ahead of each MFMA batch
+        for (int k0 = 0; k0 < M; k0 += 4 * UA) {
+            float av[UA], bv[UA][SB_DG];
 #pragma unroll
-            for (int q = 0; q < SB_DG; ++q) {
-                const int dt = dg * SB_DG + q;
-                if (dt < ndt) {
-                    const int d = dt * 16 + li;
-                    const float bv = (b < M && d < D) ? h[(size_t)b * D + d] : 0.f;
-                    acc[q] = mfma16(a, bv, acc[q]);
+            for (int u = 0; u < UA; ++u) {
+                const int b = k0 + 4 * u + lg;
+                av[u] = (b < M) ? m.Sc[(size_t)b * ld + n] : 0.f;   // n < ldSc always (padded, zero-filled)
+#pragma unroll
+                for (int q = 0; q < SB_DG; ++q) {
+                    const int d = (dg * SB_DG + q) * 16 + li;
+                    bv[u][q] = (b < M && d < D) ? h[(size_t)b * D + d] : 0.f;
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                asum += av[u];
+#pragma unroll
+                for (int q = 0; q < SB_DG; ++q)
+                    if (dg * SB_DG + q < ndt) acc[q] = mfma16(av[u], bv[u][q], acc[q]);
             }
         }
 #pragma unroll
@@ -503,25 +496,40 @@ __global__ __launch_bounds__(256) void k_score_bwd(const DevModel* __restrict__ 
 #pragma unroll
     for (int q = 0; q < SB_DG; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int row = r0 + li;
-    for (int k0 = kbeg + 4 * lg; k0 < kend + 4 * lg; k0 += 16) {   // all 4 lane groups run the same trip count
-        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        int4 it = make_int4(-1, -1, -1, -1);
-        if (k0 < kend) {
-            if (row < M) a4 = *reinterpret_cast<const float4*>(m.Sc + (size_t)row * ld + k0);
-            it = *reinterpret_cast<const int4*>(m.col_item + k0);
+    // ds (float4 along n) and the column -> item map of the whole K-chunk first, then per 16-wide k-step
+    // all 4 * SB_DG gathered Wy operands before the MFMAs that consume them
+    constexpr int MAXIT = 4;
+    for (int kb = kbeg; kb < kend; kb += 16 * MAXIT) {
+        float4 a4[MAXIT];
+        int4 it[MAXIT];
+#pragma unroll
+        for (int s2 = 0; s2 < MAXIT; ++s2) {
+            const int k0 = kb + 16 * s2 + 4 * lg;
+            a4[s2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            it[s2] = make_int4(-1, -1, -1, -1);
+            if (k0 < kend) {
+                if (row < M) a4[s2] = ld4(m.Sc + (size_t)row * ld + k0);
+                it[s2] = ldi4(m.col_item + k0);
+            }
         }
-        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-        const int iv[4] = {it.x, it.y, it.z, it.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int s2 = 0; s2 < MAXIT; ++s2) {
+            if (kb + 16 * s2 < kend) {      // wave-uniform
+                const float av[4] = {a4[s2].x, a4[s2].y, a4[s2].z, a4[s2].w};
+                const int iv[4] = {it[s2].x, it[s2].y, it[s2].z, it[s2].w};
+                float bv[4][SB_DG];
 #pragma unroll
-            for (int q = 0; q < SB_DG; ++q) {
-                const int dt = dg * SB_DG + q;
-                if (dt < ndt) {
-                    const int d = dt * 16 + li;
-                    const float bv = (iv[e] >= 0 && d < D) ? m.Wy[(size_t)iv[e] * D + d] : 0.f;
-                    acc[q] = mfma16(av[e], bv, acc[q]);
-                }
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int q = 0; q < SB_DG; ++q) {
+                        const int d = (dg * SB_DG + q) * 16 + li;
+                        bv[e][q] = (iv[e] >= 0 && d < D) ? m.Wy[(size_t)iv[e] * D + d] : 0.f;
+                    }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int q = 0; q < SB_DG; ++q)
+                        if (dg * SB_DG + q < ndt) acc[q] = mfma16(av[e], bv[e][q], acc[q]);
             }
         }
     }
@@ -543,6 +551,7 @@ __global__ __launch_bounds__(256) void k_score_bwd(const DevModel* __restrict__ 
 // GRU backward, row-local part (no BPTT: H is a constant input, gru4rec.py:460-463,576).
 //   dz = dh (c - H) ; dc = dh z ; da = dc act'(c) ; dr = (da Wh^T) H ; d(pre-sigmoid) ; dV = [da | drp | dzp]
 //   dy = dV Wx^T  -> embedding-row gradient dSx (layer 0) or the lower layer's dh.
+template <int T2, int U2>
 __global__ __launch_bounds__(GRU_NW * 64) void k_gru_bwd_rows(const DevModel* __restrict__ mp, int l) {
     const DevModel& m = *mp;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(GRU_NW * 64) void k_gru_bwd_rows(const DevModel* __
     float* sDV = smem;   // [16][ldv]
     const int r0 = blockIdx.x * GRU_ROWS;
     if (r0 >= M) return;
-    const float* Hcur = m.H[l][c.g & 1];
+    const GAS float* Hcur = m.H[l][c.g & 1];
     const bool top = (l == m.n_layers - 1);
     const float retain_h = 1.0f - m.drop_h, retain_e = 1.0f - m.drop_e;
     for (int e = tid; e < GRU_ROWS * D; e += GRU_NW * 64) {
@@ -563,7 +572,17 @@ __global__ __launch_bounds__(GRU_NW * 64) void k_gru_bwd_rows(const DevModel* __
             float dh;
             if (top) {
                 dh = 0.f;
-                for (int kc = 0; kc < m.ksplit; ++kc) dh += m.dhpart[((size_t)kc * B + row) * D + d];
+                const GAS float* pp = m.dhpart + (size_t)row * D + d;
+                const size_t ps = (size_t)B * D;
+                int kc = 0;
+                for (; kc + 8 <= m.ksplit; kc += 8) {     // 8 independent loads in flight, fixed summation order
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = pp[(size_t)(kc + q) * ps];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) dh += v[q];
+                }
+                for (; kc < m.ksplit; ++kc) dh += pp[(size_t)kc * ps];
             } else {
                 dh = m.dyl[l][(size_t)row * D + d];
             }
@@ -578,30 +597,25 @@ __global__ __launch_bounds__(GRU_NW * 64) void k_gru_bwd_rows(const DevModel* __
         sDV[i * ldv + 2 * D + d] = dzp;
     }
     __syncthreads();
-    const float* Wx = m.dense_p + m.offWx[l];
-    const float* Wh = m.dense_p + m.offWh[l];
+    const GAS float* Wx = m.dense_p + m.offWx[l];
+    const GAS float* Wh = m.dense_p + m.offWh[l];
     // ---- dHr = da Wh^T ; drp = dHr * H * r (1 - r)
     {
         const int nct = (D + 15) >> 4;
-        int ntw = 0;
-        for (int ct = wid; ct < nct; ct += GRU_NW) ++ntw;
-        f32x4 acc[GRU_MAXT2];
+        f32x4 acc[T2];
+        long long bo[T2];
+        unsigned tm = 0;
 #pragma unroll
-        for (int ti = 0; ti < GRU_MAXT2; ++ti) acc[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < D; k += 4) {
-            const float a = sDV[li * ldv + k + lg];
-#pragma unroll
-            for (int ti = 0; ti < GRU_MAXT2; ++ti) {
-                if (ti < ntw) {
-                    const int col = (wid + ti * GRU_NW) * 16 + li;
-                    const float b = col < D ? Wh[(size_t)col * D + k + lg] : 0.f;   // B[k][j] = Wh[j][k]
-                    acc[ti] = mfma16(a, b, acc[ti]);
-                }
-            }
+        for (int ti = 0; ti < T2; ++ti) {
+            acc[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int ct = wid + ti * GRU_NW, col = ct * 16 + li;
+            bo[ti] = col < D ? (long long)col * D : -1;     // B[k][j] = Wh[j][k]
+            if (ct < nct) tm |= 1u << ti;
         }
+        tile_gemm_rows<T2, U2>(acc, tm, bo, sDV, ldv, D, Wh, 1, li, lg);
 #pragma unroll
-        for (int ti = 0; ti < GRU_MAXT2; ++ti) {
-            if (ti < ntw) {
+        for (int ti = 0; ti < T2; ++ti) {
+            if ((tm >> ti) & 1u) {
                 const int col = (wid + ti * GRU_NW) * 16 + li;
                 if (col < D) {
 #pragma unroll
@@ -628,25 +642,20 @@ __global__ __launch_bounds__(GRU_NW * 64) void k_gru_bwd_rows(const DevModel* __
     // ---- dy = dV Wx^T
     {
         const int nct = (IN + 15) >> 4;
-        int ntw = 0;
-        for (int ct = wid; ct < nct; ct += GRU_NW) ++ntw;
-        f32x4 acc[GRU_MAXT2];
+        f32x4 acc[T2];
+        long long bo[T2];
+        unsigned tm = 0;
 #pragma unroll
-        for (int ti = 0; ti < GRU_MAXT2; ++ti) acc[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < D3; k += 4) {
-            const float a = sDV[li * ldv + k + lg];
-#pragma unroll
-            for (int ti = 0; ti < GRU_MAXT2; ++ti) {
-                if (ti < ntw) {
-                    const int col = (wid + ti * GRU_NW) * 16 + li;
-                    const float b = col < IN ? Wx[(size_t)col * D3 + k + lg] : 0.f;   // B[k][j] = Wx[j][k]
-                    acc[ti] = mfma16(a, b, acc[ti]);
-                }
-            }
+        for (int ti = 0; ti < T2; ++ti) {
+            acc[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int ct = wid + ti * GRU_NW, col = ct * 16 + li;
+            bo[ti] = col < IN ? (long long)col * D3 : -1;    // B[k][j] = Wx[j][k]
+            if (ct < nct) tm |= 1u << ti;
         }
+        tile_gemm_rows<T2, U2>(acc, tm, bo, sDV, ldv, D3, Wx, 1, li, lg);
 #pragma unroll
-        for (int ti = 0; ti < GRU_MAXT2; ++ti) {
-            if (ti < ntw) {
+        for (int ti = 0; ti < T2; ++ti) {
+            if ((tm >> ti) & 1u) {
                 const int col = (wid + ti * GRU_NW) * 16 + li;
                 if (col < IN) {
 #pragma unroll
@@ -678,7 +687,7 @@ __global__ __launch_bounds__(GRU_NW * 64) void k_gru_bwd_rows(const DevModel* __
 // float offset `base` of the flat dense buffers) = X^T[., batch] * dV[batch, coff + .] ; X0/X1 = operand for
 // even/odd global step (the hidden state ping-pongs) ; X == nullptr selects the bias row (column sums of dV).
 struct DenseTile {
-    const float *X0, *X1, *dV;
+    GP(const float) X0; GP(const float) X1; GP(const float) dV;
     long long base;
     int ldx, ldv, nrows, ncols, coff, ldo, r0, c0;
 };
@@ -686,7 +695,7 @@ struct DenseTile {
 __device__ __forceinline__ void dense_adagrad(const DevModel& m, size_t off, float g) {
     const float acc = m.dense_acc[off] + g * g;
     m.dense_acc[off] = acc;
-    const float gs = g / sqrtf(acc + G4R_EPS_ADAGRAD);
+    const float gs = g * frsq(acc + G4R_EPS_ADAGRAD);
     const float p = m.dense_p[off];
     if (m.mom > 0.f) {
         const float v = m.mom * m.dense_vel[off] - m.lr * (gs + m.lmbd * p);
@@ -697,26 +706,33 @@ __device__ __forceinline__ void dense_adagrad(const DevModel& m, size_t off, flo
     }
 }
 
-__global__ __launch_bounds__(256) void k_dense_grad(const DevModel* __restrict__ mp, const DenseTile* __restrict__ tiles, int ntiles) {
+__global__ __launch_bounds__(256) void k_dense_grad(const DevModel* __restrict__ mp, const DenseTile* __restrict__ tiles_, int ntiles) {
     const DevModel& m = *mp;
+    const GAS DenseTile* tiles = (const GAS DenseTile*)tiles_;   // same mangled signature on both passes
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int w = blockIdx.x * 4 + wid;
     if (w >= ntiles) return;
     const StepCtx c = load_ctx(m);
     const DenseTile tl = tiles[w];            // fully resolved on the host: no per-layer lookups here
-    const float* X = (c.g & 1) ? tl.X1 : tl.X0;
-    const float* dV = tl.dV;
+    const GAS float* X = (c.g & 1) ? tl.X1 : tl.X0;
+    const GAS float* dV = tl.dV;
     const int M = c.M, ra = tl.r0 + li, cb = tl.c0 + li;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < M; k += 4) {
-        const int b = k + lg;
-        float a = 0.f, bv = 0.f;
-        if (b < M) {
-            if (X == nullptr) a = (li == 0) ? 1.f : 0.f;      // bias row: column sums of dV
-            else if (ra < tl.nrows) a = X[(size_t)b * tl.ldx + ra];
-            if (cb < tl.ncols) bv = dV[(size_t)b * tl.ldv + tl.coff + cb];
+    constexpr int U = 16;       // 2*U independent loads in flight per lane before the MFMAs of a batch
+    for (int k0 = 0; k0 < M; k0 += 4 * U) {
+        float av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = k0 + 4 * u + lg;
+            av[u] = 0.f; bv[u] = 0.f;
+            if (b < M) {
+                if (X == nullptr) av[u] = (li == 0) ? 1.f : 0.f;      // bias row: column sums of dV
+                else if (ra < tl.nrows) av[u] = X[(size_t)b * tl.ldx + ra];
+                if (cb < tl.ncols) bv[u] = dV[(size_t)b * tl.ldv + tl.coff + cb];
+            }
         }
-        acc = mfma16(a, bv, acc);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = mfma16(av[u], bv[u], acc);
     }
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
@@ -746,77 +762,19 @@ __global__ __launch_bounds__(256) void k_dense_apply(const DevModel* __restrict_
 // the row: it scans the occurrence list for its duplicates (ballot over 64 entries at a time) and
 // applies them in ascending order.  No atomics, no scratch state, bit-reproducible.
 // The extra last block folds the per-row losses into loss_steps[t] and advances the step state.
-#define SP_MAXCH 2   // float4 chunks per lane: row width <= 4*64*SP_MAXCH = 512
-__device__ __forceinline__ void sparse_row_update(const DevModel& m, float* P, float* A, float* V, int item, int W,
-                                                  const int* occ, int lo, int k, const float* gx, const float* gy,
-                                                  int B, int lane) {
-    // gradient row of occurrence j: j < B -> gx[j] (width W) ; else gy[j - B]
-    const int nc4 = W >> 2;
-    const bool mom = m.mom > 0.f;
-    float pc[SP_MAXCH][4], pz[SP_MAXCH][4], az[SP_MAXCH][4], vz[SP_MAXCH][4], al[SP_MAXCH][4], vl[SP_MAXCH][4];
-#pragma unroll
-    for (int q = 0; q < SP_MAXCH; ++q) {
-        const int c4 = lane + 64 * q;
-        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), a0 = p0, v0 = p0;
-        if (c4 < nc4) {
-            const size_t o = (size_t)item * W + 4 * c4;
-            p0 = *reinterpret_cast<const float4*>(P + o);
-            a0 = *reinterpret_cast<const float4*>(A + o);
-            if (mom) v0 = *reinterpret_cast<const float4*>(V + o);
-        }
-        pz[q][0] = p0.x; pz[q][1] = p0.y; pz[q][2] = p0.z; pz[q][3] = p0.w;
-        az[q][0] = a0.x; az[q][1] = a0.y; az[q][2] = a0.z; az[q][3] = a0.w;
-        vz[q][0] = v0.x; vz[q][1] = v0.y; vz[q][2] = v0.z; vz[q][3] = v0.w;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { pc[q][e] = pz[q][e]; al[q][e] = az[q][e]; vl[q][e] = vz[q][e]; }
-    }
-    // all 64 lanes take part in every ballot; the per-match work below is predicated per lane
-    for (int base = lo & ~63; base <= k; base += 64) {
-        const int j = base + lane;
-        unsigned long long mask = __ballot(j >= lo && j <= k && occ[j] == item);
-        while (mask) {   // ascending occurrence order
-            const int bit = __ffsll((unsigned long long)mask) - 1;
-            mask &= mask - 1;
-            const int jj = base + bit;
-            const float* grow = (jj < B) ? gx + (size_t)jj * W : gy + (size_t)(jj - B) * W;
-#pragma unroll
-            for (int q = 0; q < SP_MAXCH; ++q) {
-                const int c4 = lane + 64 * q;
-                if (c4 < nc4) {
-                    const float4 g4 = *reinterpret_cast<const float4*>(grow + 4 * c4);
-                    const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float an = az[q][e] + gv[e] * gv[e];
-                        const float gs = gv[e] / sqrtf(an + G4R_EPS_ADAGRAD);
-                        const float delta = (m.lmbd > 0.f) ? m.lr * (gs + m.lmbd * pz[q][e]) : m.lr * gs;
-                        al[q][e] = an;
-                        if (mom) {
-                            const float v2 = m.mom * vz[q][e] - delta;
-                            vl[q][e] = v2;
-                            pc[q][e] = pc[q][e] + v2;
-                        } else {
-                            pc[q][e] = pc[q][e] - delta;
-                        }
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < SP_MAXCH; ++q) {
-        const int c4 = lane + 64 * q;
-        if (c4 < nc4) {
-            const size_t o = (size_t)item * W + 4 * c4;
-            *reinterpret_cast<float4*>(P + o) = make_float4(pc[q][0], pc[q][1], pc[q][2], pc[q][3]);
-            *reinterpret_cast<float4*>(A + o) = make_float4(al[q][0], al[q][1], al[q][2], al[q][3]);
-            if (mom) *reinterpret_cast<float4*>(V + o) = make_float4(vl[q][0], vl[q][1], vl[q][2], vl[q][3]);
-        }
-    }
-}
+#define SP_WAVES 8   // occurrences (waves) per workgroup
 
-__global__ __launch_bounds__(256) void k_sparse_update(const DevModel* __restrict__ mp, int nblk_occ) {
+// MAXCH = float4 chunks per lane (1: row width <= 256, 2: <= 512).  One wave per occurrence k of
+// (X | Y | samples); the wave of an item's LAST occurrence owns the row and applies all of the item's
+// occurrences in ascending order (semantics: comment block above).  The occurrence list is
+// staged in LDS once per workgroup; the owner keeps its duplicate list in registers (entry i in lane i) and
+// fetches the gradient rows of up to UB duplicates together, so a hot item costs cnt/UB memory round trips
+// instead of cnt.  The extra last block folds the per-row losses into loss_steps[t] and advances the step state.
+template <int MAXCH>
+__global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update(const DevModel* __restrict__ mp, int nblk_occ) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
+    int* sOcc = reinterpret_cast<int*>(smem);     // occurrence list, padded with -2 to a multiple of 256 (+256)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const StepCtx c = load_ctx(m);
     const int B = m.B, R = m.R;
@@ -836,49 +794,171 @@ __global__ __launch_bounds__(256) void k_sparse_update(const DevModel* __restric
         }
         return;
     }
-    const int k = blockIdx.x * 4 + wid;
+    const long long t_start = m.dbgclk ? wall_clock64() : 0;
+    G4R_TICK(m, 1, 0);
+    const int Rpad = ((R + 255) & ~255) + 256;
+    for (int j = tid; j < Rpad; j += SP_WAVES * 64) sOcc[j] = j < R ? m.occ_idx[j] : -2;
+    __syncthreads();
+    G4R_TICK(m, 1, 1);
+    const int k = blockIdx.x * SP_WAVES + wid;
     if (k >= R) return;
-    const int item = m.occ_idx[k];
+    const int item = sOcc[k];
     if (item < 0) return;
     const bool constrained = (m.embed_mode == G4R_EMBED_CONSTRAINED);
     // occurrence range sharing a table with k: constrained -> all of X|Y|samples ; separate -> X alone, Y|samples alone
     const int lo = (constrained || k < B) ? 0 : B;
     const int hi = (constrained || k >= B) ? R : B;
     // ---- is there a later occurrence of the same item?  then that wave owns the row
-    for (int base = (k + 1) & ~63; base < hi; base += 64) {
-        const int j = base + lane;
-        if (__ballot(j > k && j < hi && m.occ_idx[j] == item)) return;
+    for (int base = (k + 1) & ~255; base < hi; base += 256) {
+        int v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = sOcc[base + 64 * e + lane];
+        bool later = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int j = base + 64 * e + lane; later |= (j > k && j < hi && v[e] == item); }
+        if (__ballot(later)) return;
     }
-    if (k < B && !constrained) {
-        sparse_row_update(m, m.E, m.accE, m.velE, item, m.Ein, m.occ_idx, lo, k, m.dSx, nullptr, B, lane);
-        return;
+    const long long t_own = m.dbgclk ? wall_clock64() : 0;
+    G4R_TICK(m, 1, 2);
+    // ---- row state (pre-step values; every occurrence is scaled with the pre-step accumulator)
+    const bool tableE = (k < B && !constrained);
+    GAS float* P = tableE ? m.E : m.Wy;
+    GAS float* A = tableE ? m.accE : m.accWy;
+    GAS float* V = tableE ? m.velE : m.velWy;
+    const int W = tableE ? m.Ein : m.Dtop;
+    const int nc4 = W >> 2;
+    const bool mom = m.mom > 0.f;
+    const bool bias = (k >= B);
+    float pc[MAXCH][4], pz[MAXCH][4], az[MAXCH][4], vz[MAXCH][4], al[MAXCH][4], vl[MAXCH][4];
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) {
+        const int c4 = lane + 64 * q;
+        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), a0 = p0, v0 = p0;
+        if (c4 < nc4) {
+            const size_t o = (size_t)item * W + 4 * c4;
+            p0 = ld4(P + o);
+            a0 = ld4(A + o);
+            if (mom) v0 = ld4(V + o);
+        }
+        pz[q][0] = p0.x; pz[q][1] = p0.y; pz[q][2] = p0.z; pz[q][3] = p0.w;
+        az[q][0] = a0.x; az[q][1] = a0.y; az[q][2] = a0.z; az[q][3] = a0.w;
+        vz[q][0] = v0.x; vz[q][1] = v0.y; vz[q][2] = v0.z; vz[q][3] = v0.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pc[q][e] = pz[q][e]; al[q][e] = az[q][e]; vl[q][e] = vz[q][e]; }
     }
-    sparse_row_update(m, m.Wy, m.accWy, m.velWy, item, m.Dtop, m.occ_idx, lo, k, m.dSx, m.dSy, B, lane);
-    if (k >= B) {
-        // ---- output bias By: occurrences among Y|samples only (gru4rec.py:486-489)
-        float p = m.By[item];
-        const float pz = p, az = m.accBy[item], vz = (m.mom > 0.f) ? m.velBy[item] : 0.f;
-        float al = az, vl = vz;
-        for (int base = B & ~63; base <= k; base += 64) {
-            const int j = base + lane;
-            unsigned long long mask = __ballot(j >= B && j <= k && m.occ_idx[j] == item);
+    // output bias By: occurrences among Y|samples only (gru4rec.py:486-489)
+    float bp = 0.f, bpz = 0.f, baz = 0.f, bvz = 0.f, bal = 0.f, bvl = 0.f;
+    if (bias) {
+        bp = m.By[item]; bpz = bp; baz = m.accBy[item]; bal = baz;
+        if (mom) { bvz = m.velBy[item]; bvl = bvz; }
+    }
+    constexpr int UB = (MAXCH == 1) ? 16 : 8;
+    // apply the duplicates listed one-per-lane in myj[0..cnt), ascending occurrence order.  Branch-free per batch:
+    // the UB x 4 x MAXCH scale factors of a batch are independent, only the parameter subtraction is a chain.
+    auto apply = [&](int myj, int cnt) {
+        const int jb = (lane < cnt && myj >= B) ? myj : -1;
+        float dlt_b = 0.f, an_b = 0.f;     // lane i: bias update of duplicate i
+        if (bias) {
+            const float gb = (jb >= 0) ? m.dSBy[jb - B] : 0.f;     // all bias gradients of the list in one round
+            an_b = baz + gb * gb;
+            const float gs = gb * frsq(an_b + G4R_EPS_ADAGRAD);
+            dlt_b = (m.lmbd > 0.f) ? m.lr * (gs + m.lmbd * bpz) : m.lr * gs;
+        }
+        for (int i0 = 0; i0 < cnt; i0 += UB) {
+            float4 g[UB][MAXCH];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {          // gradient rows of up to UB duplicates in flight together
+                const int jj = __builtin_amdgcn_readlane(myj, (i0 + u) & 63);
+#pragma unroll
+                for (int q = 0; q < MAXCH; ++q) {
+                    const int c4 = lane + 64 * q;
+                    g[u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (i0 + u < cnt && c4 < nc4) {
+                        const GAS float* grow = (jj < B) ? m.dSx + (size_t)jj * W : m.dSy + (size_t)(jj - B) * W;
+                        g[u][q] = ld4(grow + 4 * c4);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const bool valid = (i0 + u < cnt);
+#pragma unroll
+                for (int q = 0; q < MAXCH; ++q) {
+                    const float gv[4] = {g[u][q].x, g[u][q].y, g[u][q].z, g[u][q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float an = az[q][e] + gv[e] * gv[e];
+                        const float gs = gv[e] * frsq(an + G4R_EPS_ADAGRAD);
+                        float delta = (m.lmbd > 0.f) ? m.lr * (gs + m.lmbd * pz[q][e]) : m.lr * gs;
+                        delta = valid ? delta : 0.f;
+                        al[q][e] = valid ? an : al[q][e];
+                        if (mom) {
+                            const float v2 = m.mom * vz[q][e] - delta;
+                            vl[q][e] = valid ? v2 : vl[q][e];
+                            pc[q][e] = pc[q][e] + (valid ? v2 : 0.f);
+                        } else {
+                            pc[q][e] = pc[q][e] - delta;
+                        }
+                    }
+                }
+            }
+        }
+        if (bias) {
+            for (int i = 0; i < cnt; ++i) {          // ordered chain over scalar (SGPR) broadcasts
+                const int jj = __builtin_amdgcn_readlane(jb, i);
+                if (jj < 0) continue;
+                const float delta = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlt_b), i));
+                bal = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, an_b), i));
+                if (mom) { const float v2 = m.mom * bvz - delta; bvl = v2; bp = bp + v2; }
+                else bp = bp - delta;
+            }
+        }
+    };
+    // ---- collect this item's occurrences in [lo, k] (ascending) 64 at a time and apply them
+    int myj = -1, cnt = 0, total = 0;
+    for (int base = lo & ~255; base <= k; base += 256) {
+        int v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = sOcc[base + 64 * e + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = base + 64 * e + lane;
+            unsigned long long mask = __ballot(j >= lo && j <= k && v[e] == item);
             while (mask) {
                 const int bit = __ffsll((unsigned long long)mask) - 1;
                 mask &= mask - 1;
-                const float g = m.dSBy[base + bit - B];
-                const float an = az + g * g;
-                const float gs = g / sqrtf(an + G4R_EPS_ADAGRAD);
-                const float delta = (m.lmbd > 0.f) ? m.lr * (gs + m.lmbd * pz) : m.lr * gs;
-                al = an;
-                if (m.mom > 0.f) { const float v2 = m.mom * vz - delta; vl = v2; p = p + v2; }
-                else p = p - delta;
+                if (lane == cnt) myj = base + 64 * e + bit;
+                ++total;
+                if (++cnt == 64) { apply(myj, 64); cnt = 0; myj = -1; }
             }
         }
-        if (lane == 0) {
-            m.By[item] = p;
-            m.accBy[item] = al;
-            if (m.mom > 0.f) m.velBy[item] = vl;
+    }
+    const long long t_col = m.dbgclk ? wall_clock64() : 0;
+    G4R_TICK(m, 1, 3);
+    if (cnt) apply(myj, cnt);
+    const long long t_app = m.dbgclk ? wall_clock64() : 0;
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) {
+        const int c4 = lane + 64 * q;
+        if (c4 < nc4) {
+            const size_t o = (size_t)item * W + 4 * c4;
+            st4(P + o, make_float4(pc[q][0], pc[q][1], pc[q][2], pc[q][3]));
+            st4(A + o, make_float4(al[q][0], al[q][1], al[q][2], al[q][3]));
+            if (mom) st4(V + o, make_float4(vl[q][0], vl[q][1], vl[q][2], vl[q][3]));
         }
+    }
+    if (bias && lane == 0) {
+        m.By[item] = bp;
+        m.accBy[item] = bal;
+        if (mom) m.velBy[item] = bvl;
+    }
+    G4R_TICK(m, 1, 4);
+    if (m.dbgclk && lane == 0) {
+        const long long t_end = wall_clock64();
+        const long long dur = t_end - t_start;
+        GAS long long* tr = m.dbgclk + 64 + 8 * k;
+        tr[0] = t_start; tr[1] = t_own; tr[2] = t_col; tr[3] = t_app; tr[4] = t_end; tr[5] = total; tr[6] = 0; tr[7] = item;
+        (void)dur;
     }
 }
 

@@ -1,0 +1,32 @@
+"""In-kernel phase timing (debug): G4R_CLK=1 python tools/clk.py"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+cfg = bench.CONFIGS['cfg2']
+plan, support = bench.make_plan(cfg, 400, 0, 1)
+m = bench.create_model(cfg, support, 0, 1, 0, None, use_graph=False)
+for k in ('in_idx', 'out_idx', 'reset', 'M'):
+    plan[k] = plan[k][:400]
+plan['T'] = 400; plan['n_compact'] = 0
+m.set_plan(plan); m.reset_hidden()
+m.train_steps(0, 200)
+for rep in range(5):
+    m.train_steps(200 + rep, 1)
+    R = 2 * cfg['batch_size'] + cfg['n_sample']
+    raw = m.get_debug('dbgclk', (2 * (64 + 8 * R),)).view(np.int64)
+    g = raw[0:6]; s = raw[16:21]
+    mx = raw[32]
+    print('gru_fwd phases (us):', np.round(np.diff(g) / 100.0, 2), ' sparse b0w0 (us):', np.round(np.diff(s) / 100.0, 2),
+          '| slowest owner wave: %.2f us with %d dups | owners %d, occurrences %d, max dups %d' % (
+              (mx >> 20) / 100.0, mx & 0xFFFFF, raw[33], raw[34], raw[35]))
+    tr = raw[64:].reshape(R, 8)
+    tr = tr[tr[:, 4] > 0]
+    t0 = tr[:, 0].min()
+    d = (tr[:, 4] - tr[:, 0]) / 100.0
+    o = np.argsort(-d)[:6]
+    print('  kernel span %.1f us; block start spread %.1f us' % ((tr[:, 4].max() - t0) / 100.0, (tr[:, 0].max() - t0) / 100.0))
+    for q in o:
+        a = tr[q]
+        print('   wave item %6d dups %3d: stage+scan %.1f  collect %.1f  apply %.1f [pre %.1f rows %.1f bias %.1f] store %.1f' % (
+            a[7], a[5], (a[1] - a[0]) / 100.0, (a[2] - a[1]) / 100.0, (a[3] - a[2]) / 100.0, (a[6] >> 40) / 100.0, ((a[6] >> 20) & 0xFFFFF) / 100.0, (a[6] & 0xFFFFF) / 100.0, (a[4] - a[3]) / 100.0))
