@@ -284,6 +284,7 @@ class GRU4Rec:
         self._data_items = data.ItemIdx.values.astype(np.int32)
         self._plan_key = None
         self.loss_history = []
+        self.step_costs = []          # per-epoch arrays of the per-mini-batch cost (gru4rec.py:623)
 
     def _epoch_plan(self):
         n_sessions = len(self._offsets) - 1
@@ -338,6 +339,7 @@ class GRU4Rec:
         dt = time.time() - t0
         print('Epoch{} --> loss: {:.6f} \t({:.2f}s) \t[{:.2f} mb/s | {:.0f} e/s]'.format(epoch + 1, avgc, dt, T / dt, np.sum(cc) / dt))
         self.loss_history.append(float(avgc))
+        self.step_costs.append(costs)
         self.last_epoch_stats = dict(steps=int(T), events=int(np.sum(cc)), seconds=dt, loss=float(avgc))
         return costs, cc
 

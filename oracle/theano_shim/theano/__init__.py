@@ -83,6 +83,7 @@ class Var:
     def __ge__(self, o): return self._bin(o, 'ge')
     def __lt__(self, o): return self._bin(o, 'lt')
     def __le__(self, o): return self._bin(o, 'le')
+    def __eq__(self, o): return self._bin(o, 'eq')
     __hash__ = object.__hash__
 
     # ---- structure
@@ -158,6 +159,7 @@ def shared(value, borrow=False, name=None):
 
 # ---------------------------------------------------------------------------------------------- evaluation
 RNG_HOOK = [None]    # callable(kind, node_serial_rank, call_count, shape, attrs) -> ndarray
+CALL_LOG = []        # (function id, outputs) of every compiled-function call, for the golden generator
 _rng_nodes = []      # creation order of random nodes
 
 
@@ -166,10 +168,10 @@ def _to_t(x, float_dt=torch.float32):
         return x
     a = np.asarray(x)
     if a.dtype.kind == 'f':
-        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(float_dt)
+        return torch.from_numpy(np.array(a, dtype=np.float32, order='C')).to(float_dt)
     if a.dtype.kind == 'b':
-        return torch.from_numpy(np.ascontiguousarray(a))
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64))
+        return torch.from_numpy(np.array(a, order='C'))
+    return torch.from_numpy(np.array(a, dtype=np.int64, order='C'))
 
 
 class _Ctx:
@@ -225,6 +227,7 @@ def _ev1(v, c):
         if fn == 'ge': return a >= b
         if fn == 'lt': return a < b
         if fn == 'le': return a <= b
+        if fn == 'eq': return a == b
         if fn == 'maximum': return torch.maximum(a, b if isinstance(b, torch.Tensor) else torch.tensor(b))
         raise NotImplementedError(fn)
     if op == 'elem1':
@@ -277,7 +280,10 @@ def _ev1(v, c):
         parts = [_ev(p, c) for p in I]
         if any(p.is_floating_point() for p in parts):
             parts = [p.float() for p in parts]
-        return torch.cat(parts, dim=v.attrs['axis'])
+        try:
+            return torch.cat(parts, dim=v.attrs['axis'])
+        except RuntimeError as e:
+            raise RuntimeError('%s ; parts: %s ; ops: %s' % (e, [tuple(p.shape) for p in parts], [(q.op, q.attrs.get('spec'), [tuple(_ev(z, c).shape) if z is not None else None for z in q.inputs]) for q in I]))
     if op == 'diag':
         return torch.diagonal(_ev(I[0], c))
     if op == 'subtensor':
@@ -393,8 +399,10 @@ class Function:
             k.value = np.array(a, dtype=k.value.dtype).reshape(a.shape)
         self.calls += 1
         if self.no_out:
+            CALL_LOG.append((id(self), None))
             return None
         res = [o.detach().numpy() if isinstance(o, torch.Tensor) else np.asarray(o) for o in outs]
+        CALL_LOG.append((id(self), res[0] if self.single else res))
         return res[0] if self.single else res
 
 
