@@ -41,7 +41,7 @@ SYMBOLS = [
     'g4r_sample_store_rows', 'g4r_build_plan', 'g4r_set_plan', 'g4r_train_steps', 'g4r_get_losses',
     'g4r_synchronize', 'g4r_global_step', 'g4r_kernel_time', 'g4r_profile', 'g4r_reset_hidden',
     'g4r_predict_begin', 'g4r_predict_hidden', 'g4r_predict_step', 'g4r_rank_targets', 'g4r_comm_unique_id',
-    'g4r_comm_init', 'g4r_comm_sync_sparse', 'g4r_get_debug', 'g4r_selftest_mfma',
+    'g4r_comm_init', 'g4r_comm_sync_sparse', 'g4r_comm_min_i64', 'g4r_get_debug', 'g4r_selftest_mfma',
 ]
 
 _lib = None
@@ -93,6 +93,7 @@ def lib():
     L.g4r_comm_unique_id.argtypes = [C.c_char_p]
     L.g4r_comm_init.argtypes = [vp, C.c_char_p, i32, i32]
     L.g4r_comm_sync_sparse.argtypes = [vp]
+    L.g4r_comm_min_i64.argtypes = [vp, i64p]
     L.g4r_get_debug.argtypes = [vp, C.c_char_p, f32p, i64]
     L.g4r_selftest_mfma.argtypes = [f32p]
     if L.g4r_sizeof_config() != C.sizeof(G4RConfig):
@@ -301,6 +302,11 @@ class Model:
 
     def comm_sync_sparse(self):
         _chk(lib().g4r_comm_sync_sparse(self.h))
+
+    def comm_min(self, value):
+        v = C.c_int64(int(value))
+        _chk(lib().g4r_comm_min_i64(self.h, C.byref(v)))
+        return int(v.value)
 
 
 def comm_unique_id():

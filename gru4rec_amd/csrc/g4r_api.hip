@@ -824,6 +824,21 @@ static int allreduce_avg(g4r_model* m, float* p, long long n) {
     hipLaunchKernelGGL(k_scale, dim3(cdiv(n, 256)), dim3(256), 0, m->stream, p, n, 1.0f / (float)m->cfg.nranks);
     return 0;
 }
+int g4r_comm_min_i64(g4r_model* m, int64_t* value) {
+    if (!m || !value) return fail("null argument");
+    if (m->cfg.nranks <= 1) return 0;
+    if (!m->comm_ready) return fail("g4r_comm_init first");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    long long* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, sizeof(long long)));
+    HIPCHK(hipMemcpyAsync(d, value, sizeof(long long), hipMemcpyHostToDevice, m->stream));
+    ncclResult_t r = ncclAllReduce(d, d, 1, ncclInt64, ncclMin, m->comm, m->stream);
+    if (r != ncclSuccess) { (void)hipFree(d); return fail(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); }
+    HIPCHK(hipMemcpyAsync(value, d, sizeof(long long), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    (void)hipFree(d);
+    return 0;
+}
 int g4r_comm_sync_sparse(g4r_model* m) {
     if (!m) return fail("null model");
     if (m->cfg.nranks <= 1) return 0;

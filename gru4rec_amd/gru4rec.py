@@ -16,6 +16,7 @@ import numpy as np
 import pandas as pd
 
 from . import _native, datatools
+from .plan import build_rank_plan
 
 _PLAIN_ACTS = ('linear', 'relu', 'tanh', 'softmax')
 
@@ -288,23 +289,22 @@ class GRU4Rec:
 
     def _epoch_plan(self):
         n_sessions = len(self._offsets) - 1
-        order = np.random.permutation(n_sessions) if self.train_random_order else self._base_order
-        if self._dist:
-            order = order[self._dist['rank']::self._dist['nranks']]
+        order_all = np.random.permutation(n_sessions) if self.train_random_order else self._base_order
         key = None if self.train_random_order else 'static'
         if key is not None and self._plan_key == key:
             return self._plan
-        offs = self._offsets
         if self._dist:
-            # a rank sees only its own sessions: remap them to a dense 0..n-1 range for the scheduler
-            lens = (offs[1:] - offs[:-1])[order]
-            sub_off = np.zeros(len(order) + 1, dtype=np.int32)
-            sub_off[1:] = np.cumsum(lens)
-            idx = np.concatenate([np.arange(offs[s], offs[s + 1]) for s in order]) if len(order) else np.zeros(0, dtype=np.int64)
-            items = self._data_items[idx]
-            plan = _native.build_plan(sub_off, np.arange(len(order)), items, self.batch_size, self.n_sample)
+            plan = build_rank_plan(self._offsets, order_all, self._data_items, self.batch_size, self.n_sample,
+                                   self._dist['rank'], self._dist['nranks'])
+            # every rank must issue the same number of all-reduces: truncate to the shortest plan
+            T = self._model.comm_min(plan['T'])
+            for k in ('in_idx', 'out_idx', 'reset', 'M'):
+                plan[k] = plan[k][:T]
+            keep = plan['compact_steps'] < T
+            plan['compact_steps'], plan['compact_maps'] = plan['compact_steps'][keep], plan['compact_maps'][keep]
+            plan['T'], plan['n_compact'] = int(T), int(keep.sum())
         else:
-            plan = _native.build_plan(offs, order, self._data_items, self.batch_size, self.n_sample)
+            plan = build_rank_plan(self._offsets, order_all, self._data_items, self.batch_size, self.n_sample)
         self._model.set_plan(plan)
         self._plan = plan
         self._plan_key = key

@@ -132,6 +132,7 @@ int g4r_rank_targets(g4r_model* m, const int32_t* target_col, int32_t mrows, int
 int g4r_comm_unique_id(char* out128);                         /* rank 0: ncclGetUniqueId */
 int g4r_comm_init(g4r_model* m, const char* id128, int32_t nranks, int32_t rank);
 int g4r_comm_sync_sparse(g4r_model* m);                        /* average GPU-local embedding replicas */
+int g4r_comm_min_i64(g4r_model* m, int64_t* value);            /* in-place min over ranks (plan lengths must agree) */
 
 /* ---- debugging / tests ---------------------------------------------------------------------- */
 /* copy a named intermediate of the most recent step (e.g. "scores", "dS", "dV0", "hd0") */

@@ -380,6 +380,9 @@ class OracleGRU4Rec:
         if return_debug:
             dbg = dict(Sx=Sx, Sy=Sy, s=s, yhat=yhat, ds=ds, dSy=dSy, dSBy=dSBy, dtop=dtop, dSx=dSx,
                        caches=caches, dense_grads=dense_grads, Yp=Yp, cost=cost)
+        # data-parallel hook (not in the reference): all-reduce of the dense GRU gradients across ranks
+        if getattr(self, 'dense_grad_hook', None) is not None:
+            dense_grads = self.dense_grad_hook(dense_grads)
         # ---- updates: everything reads pre-step values (Theano updates are simultaneous)
         newH = []
         for i in range(len(L)):
