@@ -53,8 +53,11 @@ def algorithmic_cost(cfg):
         # dSy = ds^T h and dh = ds Sy
         'k_score_bwd': dict(bound='mfma', flops=4.0 * B * D * N, bytes=2 * B * N * 4 + 2 * N * D * 4 + B * D * 4),
         'k_loss_rows': dict(bound='hbm', bytes=2 * B * N * 4),
-        'k_gru_fwd': dict(bound='mfma', flops=2.0 * B * 6 * D * D, bytes=B * D * 4 * 6 + 6 * D * D * 4),
-        'k_gru_bwd_rows': dict(bound='mfma', flops=2.0 * B * 4 * D * D, bytes=B * D * 4 * 8 + 4 * D * D * 4),
+        'k_gru_p1': dict(bound='mfma', flops=2.0 * B * 5 * D * D, bytes=B * D * 4 * 6 + 5 * D * D * 4),
+        'k_gru_p2': dict(bound='mfma', flops=2.0 * B * D * D, bytes=B * D * 4 * 6 + D * D * 4),
+        'k_gru_bwd_pre': dict(bound='hbm', bytes=B * D * 4 * 6),
+        'k_gru_bwd_a': dict(bound='mfma', flops=2.0 * B * D * D, bytes=B * D * 4 * 4 + D * D * 4),
+        'k_gru_bwd_b': dict(bound='mfma', flops=2.0 * B * 3 * D * D, bytes=B * D * 4 * 4 + 3 * D * D * 4),
         'k_dense_grad': dict(bound='mfma', flops=2.0 * B * 6 * D * D, bytes=B * D * 4 * 6 + 3 * 6 * D * D * 4),
     }
 

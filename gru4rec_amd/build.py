@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'g4r_api.hip')
 OUT = os.path.join(HERE, 'libgru4rec_hip.so')
-DEPS = [os.path.join(HERE, 'csrc', f) for f in ('g4r_api.hip', 'g4r_device.cuh', 'g4r_train_kernels.cuh',
+DEPS = [os.path.join(HERE, 'csrc', f) for f in ('g4r_api.hip', 'g4r_device.cuh', 'g4r_gemm.cuh', 'g4r_step_kernels.cuh',
                                                  'g4r_eval_kernels.cuh')] + \
        [os.path.join(os.path.dirname(HERE), 'include', 'gru4rec_hip.h')]
 

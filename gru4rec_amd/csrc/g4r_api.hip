@@ -31,10 +31,11 @@ static int fail(const std::string& s) { g_err = s; return -1; }
             return fail(std::string(#x) + ": " + ncclGetErrorString(e_) + " @" + std::to_string(__LINE__)); \
     } while (0)
 
-enum { KN_GRU_FWD = 0, KN_SCORE_FWD, KN_LOSS, KN_SCORE_BWD, KN_GRU_BWD, KN_DENSE, KN_ALLREDUCE, KN_DENSE_APPLY,
-       KN_SPARSE, KN_COUNT };
-static const char* KN_NAMES[KN_COUNT] = {"k_gru_fwd", "k_score_fwd", "k_loss_rows", "k_score_bwd", "k_gru_bwd_rows",
-                                         "k_dense_grad", "rccl_allreduce", "k_dense_apply", "k_sparse_update"};
+enum { KN_GRU_P1 = 0, KN_GRU_P2, KN_SCORE_FWD, KN_LOSS, KN_SCORE_BWD, KN_BWD_PRE, KN_BWD_A, KN_BWD_B, KN_DENSE, KN_ALLREDUCE,
+       KN_DENSE_APPLY, KN_SPARSE, KN_COUNT };
+static const char* KN_NAMES[KN_COUNT] = {"k_gru_p1", "k_gru_p2", "k_score_fwd", "k_loss_rows", "k_score_bwd", "k_gru_bwd_pre",
+                                         "k_gru_bwd_a", "k_gru_bwd_b", "k_dense_grad", "rccl_allreduce", "k_dense_apply",
+                                         "k_sparse_update"};
 
 struct g4r_model {
     g4r_config cfg;
@@ -57,9 +58,8 @@ struct g4r_model {
     int64_t gstep = 0;
     // launch geometry
     DenseTile* d_tiles = nullptr;
-    int ntiles = 0, tn = 32, nwavesA = 0, nblkA = 0, nblkB = 0, nblk_occ = 0;
-    size_t smem_gru_fwd[G4R_MAX_LAYERS], smem_gru_bwd[G4R_MAX_LAYERS], smem_score = 0, smem_loss = 0, smem_sparse = 0;
-    int gru_cls[G4R_MAX_LAYERS];
+    int ntiles = 0, nblkA = 0, nblkB = 0, ndtA = 0, ndtB = 0, nrtB = 0, nblk_occ = 0;
+    size_t smem_score = 0, smem_loss = 0, smem_sparse = 0;
     float* d_tmpH = nullptr;
     // graph
     hipGraphExec_t gexec = nullptr;
@@ -73,6 +73,7 @@ struct g4r_model {
     int pbatch = 0, ppar = 0;
     float* pH[G4R_MAX_LAYERS][2] = {{nullptr}};
     float* phout[G4R_MAX_LAYERS] = {nullptr};
+    float *pVc[G4R_MAX_LAYERS] = {nullptr}, *pz[G4R_MAX_LAYERS] = {nullptr}, *pHr[G4R_MAX_LAYERS] = {nullptr};
     int *p_in = nullptr, *p_items = nullptr, *p_tgt = nullptr, *p_keep = nullptr;
     unsigned char* p_zero = nullptr;
     float *p_scores = nullptr, *p_ranks = nullptr;
@@ -100,20 +101,13 @@ static void dfree(g4r_model* m, void* p) {
 }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// GRU row kernels are instantiated per width class (see g4r_train_kernels.cuh)
-typedef void (*gru_fwd_fn)(const DevModel*, int, int, int, GruFwdPredict);
-typedef void (*gru_bwd_fn)(const DevModel*, int);
-static inline int width_class(int w) { return w <= 128 ? 0 : (w <= 256 ? 1 : 2); }
-static gru_fwd_fn gru_fwd_kernel(int cls) {
-    if (cls == 0) return k_gru_fwd<3, 16, 1, 16>;
-    if (cls == 1) return k_gru_fwd<6, 8, 2, 16>;
-    return k_gru_fwd<12, 4, 4, 8>;
-}
-static gru_bwd_fn gru_bwd_kernel(int cls) {
-    if (cls == 0) return k_gru_bwd_rows<1, 16>;
-    if (cls == 1) return k_gru_bwd_rows<2, 16>;
-    return k_gru_bwd_rows<4, 8>;
-}
+// dynamic LDS of the tile-GEMM kernels (g4r_gemm.cuh)
+template <int BM, int BN, int BK, bool AKM, bool BNK>
+static constexpr size_t tile_smem() { return (size_t)TileCfg<BM, BN, BK, AKM, BNK>::SMEM_FLOATS * sizeof(float); }
+static const size_t SMEM_NN = tile_smem<GT_BM, GT_BN, GT_BK, false, false>() + GT_BM * sizeof(int);   // A [m][k], B [k][n] (+ row items)
+static const size_t SMEM_NT = tile_smem<GT_BM, GT_BN, GT_BK, false, true>() + GT_BM * sizeof(int);    // A [m][k], B [n][k] (+ row items)
+static const size_t SMEM_TN = tile_smem<GT_BM, GT_BN, GT_BK, true, false>();    // A [k][m], B [k][n]
+static const size_t SMEM_SF = tile_smem<SF_BM, GT_BN, GT_BK, false, true>() + GT_BN * sizeof(int);
 // publish the host descriptor to the device copy (stream-ordered; pageable source is staged before return)
 static int sync_dm(g4r_model* m) {
     HIPCHK(hipMemcpyAsync(m->d_dm, &m->dm, sizeof(DevModel), hipMemcpyHostToDevice, m->stream));
@@ -198,25 +192,26 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         maxD = std::max(maxD, d.D[l]);
         DA(d.H[l][0], bd); DA(d.H[l][1], bd);
         DA(d.r[l], bd); DA(d.z[l], bd); DA(d.c[l], bd); DA(d.hd[l], bd); DA(d.Hr[l], bd);
-        DA(d.dV[l], bd * 3); DA(d.dyl[l], bd);
+        DA(d.dV[l], bd * 3); DA(d.dyl[l], bd); DA(d.Vc[l], bd);
     }
     DA(m->d_tmpH, (size_t)B * maxD);
     DA(d.yin0, (size_t)B * d.Ein);
     DA(d.Sc, (size_t)B * d.ldSc);
     DA(d.dSx, (size_t)B * d.Ein); DA(d.dSy, (size_t)d.ldSc * d.Dtop); DA(d.dSBy, d.ldSc);
+    DA(d.dAx, (size_t)B * d.Ein); DA(d.dAy, (size_t)d.ldSc * d.Dtop); DA(d.dABy, d.ldSc);
     DA(d.lossrow, B);
     DA(d.occ_idx, d.R + 64); DA(d.col_item, d.ldSc);
     DA(d.st, 1);
-    // split-K of dh = ds * Sy: enough (row-tile x d-group x k-chunk) waves to fill the chip
+    // scoring backward geometry: role A tiles (n x d, one spare d column for dSBy), role B tiles (b x d x k-chunk)
     {
-        const int ndt = cdiv(d.Dtop, 16), ndg = cdiv(ndt, SB_DG), nrt = cdiv(B, 16);
-        int ks = std::max(1, std::min(cdiv(2048, nrt * ndg), cdiv(d.ldSc, 64)));
-        d.kch = ((cdiv(d.ldSc, ks) + 15) / 16) * 16;
-        d.ksplit = cdiv(d.ldSc, d.kch);
+        d.kch = GT_BK;
+        d.ksplit = cdiv(d.ldSc, GT_BK);
         DA(d.dhpart, (size_t)d.ksplit * B * d.Dtop);
-        m->nwavesA = cdiv(d.N, 16) * ndg;
-        m->nblkA = cdiv(m->nwavesA, 4);
-        m->nblkB = cdiv((long long)d.ksplit * nrt * ndg, 4);
+        m->ndtA = cdiv(d.Dtop + 1, GT_BN);
+        m->nblkA = cdiv(d.ldSc, GT_BM) * m->ndtA;
+        m->ndtB = cdiv(d.Dtop, GT_BN);
+        m->nrtB = cdiv(B, GT_BM);
+        m->nblkB = d.ksplit * m->nrtB * m->ndtB;
         m->nblk_occ = cdiv(d.R, SP_WAVES);
         m->smem_sparse = (size_t)(((d.R + 255) & ~255) + 256) * sizeof(int);
     }
@@ -228,15 +223,15 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         for (int l = 0; l < L; ++l) {
             const int D = d.D[l], IN = d.IN[l];
             auto add = [&](const float* x0, const float* x1, int ldx, int nrows, int ncols, int coff, int ldo, long long base) {
-                for (int r = 0; r < nrows; r += 16)
-                    for (int c = 0; c < ncols; c += 16) {
+                for (int r = 0; r < nrows; r += GT_BM)
+                    for (int c = 0; c < ncols; c += GT_BN) {
                         DenseTile t;
                         t.X0 = x0; t.X1 = x1; t.dV = d.dV[l]; t.base = base; t.ldx = ldx; t.ldv = 3 * D; t.nrows = nrows;
-                        t.ncols = ncols; t.coff = coff; t.ldo = ldo; t.r0 = r; t.c0 = c;
+                        t.ncols = ncols; t.coff = coff; t.ldo = ldo; t.r0 = r; t.c0 = c; t.gather = (x0 == nullptr && nrows > 1) ? 1 : 0; t.pad = 0;
                         tiles.push_back(t);
                     }
             };
-            const float* yin = (l == 0) ? d.yin0 : d.hd[l - 1];
+            const float* yin = (l == 0) ? nullptr : d.hd[l - 1];     // layer 0: gathered in the kernel
             add(yin, yin, IN, IN, 3 * D, 0, 3 * D, d.offWx[l]);                   // dWx  = yin^T dV
             add(d.Hr[l], d.Hr[l], D, D, D, 0, D, d.offWh[l]);                     // dWh  = (H r)^T dV[:, :D]
             add(d.H[l][0], d.H[l][1], D, D, 2 * D, D, 2 * D, d.offWrz[l]);        // dWrz = H^T dV[:, D:]
@@ -250,25 +245,19 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         if (hipStreamSynchronize(m->stream) != hipSuccess) { g4r_destroy(m); return fail("sync"); }
     }
 #undef DA
-    // launch geometry + LDS opt-in
-    for (int l = 0; l < L; ++l) {
-        const int D = d.D[l], IN = d.IN[l];
-        m->smem_gru_fwd[l] = (size_t)GRU_ROWS * ((D + 2) + std::max(IN + 2, 3 * D + 2)) * sizeof(float);
-        m->smem_gru_bwd[l] = (size_t)GRU_ROWS * (3 * D + 2) * sizeof(float);
-        m->gru_cls[l] = width_class(std::max(D, IN));
-    }
-    m->tn = (cdiv(d.N, 32) * cdiv(B, SC_BM) >= 128) ? 32 : 16;
+    // LDS opt-in
     m->smem_score = ((size_t)(SC_BM + 32) * (SC_KC + 2) + 32) * sizeof(float);
     m->smem_loss = (size_t)(d.ldSc + 8) * sizeof(float);
     const int big = 160 * 1024;
-    for (int cls = 0; cls < 3; ++cls) {
-        (void)hipFuncSetAttribute((const void*)gru_fwd_kernel(cls), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-        (void)hipFuncSetAttribute((const void*)gru_bwd_kernel(cls), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    }
+    (void)hipFuncSetAttribute((const void*)k_gru_p1, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)k_gru_p2, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)k_score_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)k_score_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)k_gru_bwd_a, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)k_gru_bwd_b, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)k_dense_grad, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void*)k_sparse_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void*)k_sparse_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)k_score_fwd<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)k_score_fwd<16>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void*)k_score_all<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void*)k_loss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel"); }
@@ -456,7 +445,7 @@ int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
     dfree(m, m->d_in); dfree(m, m->d_out); dfree(m, m->d_reset); dfree(m, m->d_M); dfree(m, m->d_cmaps);
     m->d_in = m->d_out = m->d_M = m->d_cmaps = nullptr; m->d_reset = nullptr;
     if (dalloc(m, &m->d_in, (size_t)T * B, false) || dalloc(m, &m->d_out, (size_t)T * B, false) ||
-        dalloc(m, &m->d_reset, (size_t)T * B, false) || dalloc(m, &m->d_M, (size_t)T, false))
+        dalloc(m, &m->d_reset, (size_t)T * B, false) || dalloc(m, &m->d_M, (size_t)T + 1, true))
         return -1;
     HIPCHK(hipMemcpyAsync(m->d_in, in_idx, (size_t)T * B * sizeof(int), hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemcpyAsync(m->d_out, out_idx, (size_t)T * B * sizeof(int), hipMemcpyHostToDevice, m->stream));
@@ -517,31 +506,38 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
         }
     };
 #define begin begin_t
+    const DevModel* dmp = (const DevModel*)m->d_dm;
+    StepState* stp = (StepState*)d.st;
     for (int l = 0; l < L; ++l) {
-        begin(KN_GRU_FWD);
-        hipLaunchKernelGGL(gru_fwd_kernel(m->gru_cls[l]), dim3(cdiv(B, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_fwd[l], s, (const DevModel*)m->d_dm, l, 1, l == 0 ? 1 : 0, nopa);
+        begin(KN_GRU_P1);
+        hipLaunchKernelGGL(k_gru_p1, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_NN, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
+        end();
+        begin(KN_GRU_P2);
+        hipLaunchKernelGGL(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_NN, s, dmp, stp, l, 1, nopa);
         end();
     }
     begin(KN_SCORE_FWD);
-    {
-        const size_t sm = ((size_t)(SC_BM + m->tn) * (SC_KC + 2) + m->tn) * sizeof(float);
-        if (m->tn == 32) hipLaunchKernelGGL(k_score_fwd<32>, dim3(cdiv(d.N, 32), cdiv(B, SC_BM)), dim3(256), sm, s, (const DevModel*)m->d_dm);
-        else hipLaunchKernelGGL(k_score_fwd<16>, dim3(cdiv(d.N, 16), cdiv(B, SC_BM)), dim3(256), sm, s, (const DevModel*)m->d_dm);
-    }
+    hipLaunchKernelGGL(k_score_fwd, dim3(cdiv(d.ldSc, GT_BN), cdiv(B, SF_BM)), dim3(256), SMEM_SF, s, dmp, stp);
     end();
     begin(KN_LOSS);
-    hipLaunchKernelGGL(k_loss_rows, dim3(B), dim3(256), m->smem_loss, s, (const DevModel*)m->d_dm);
+    hipLaunchKernelGGL(k_loss_rows, dim3(B), dim3(256), m->smem_loss, s, dmp, stp);
     end();
     begin(KN_SCORE_BWD);
-    hipLaunchKernelGGL(k_score_bwd, dim3(m->nblkA + m->nblkB), dim3(256), 0, s, (const DevModel*)m->d_dm, m->nwavesA, m->nblkA);
+    hipLaunchKernelGGL(k_score_bwd, dim3(m->nblkA + m->nblkB), dim3(256), std::max(SMEM_TN, SMEM_NN) + GT_BK * sizeof(int), s, dmp, stp, m->nblkA, m->ndtA, m->ndtB, m->nrtB);
     end();
     for (int l = L - 1; l >= 0; --l) {
-        begin(KN_GRU_BWD);
-        hipLaunchKernelGGL(gru_bwd_kernel(m->gru_cls[l]), dim3(cdiv(B, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_bwd[l], s, (const DevModel*)m->d_dm, l);
+        begin(KN_BWD_PRE);
+        hipLaunchKernelGGL(k_gru_bwd_pre, dim3(cdiv((long long)B * d.D[l], 256)), dim3(256), 0, s, dmp, stp, l);
+        end();
+        begin(KN_BWD_A);
+        hipLaunchKernelGGL(k_gru_bwd_a, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_NT, s, dmp, stp, l);
+        end();
+        begin(KN_BWD_B);
+        hipLaunchKernelGGL(k_gru_bwd_b, dim3(cdiv(d.IN[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_NT, s, dmp, stp, l);
         end();
     }
     begin(KN_DENSE);
-    hipLaunchKernelGGL(k_dense_grad, dim3(cdiv(m->ntiles, 4)), dim3(256), 0, s, (const DevModel*)m->d_dm, (const DenseTile*)m->d_tiles, m->ntiles);
+    hipLaunchKernelGGL(k_dense_grad, dim3(m->ntiles), dim3(256), SMEM_TN + (size_t)B * sizeof(int), s, dmp, stp, (const DenseTile*)m->d_tiles);
     end();
     if (!d.apply_dense_inplace) {
         if (!m->comm_ready) return fail("nranks > 1 but g4r_comm_init was not called");
@@ -553,8 +549,8 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
         end();
     }
     begin(KN_SPARSE);
-    if (std::max(d.Dtop, d.Ein) <= 256) hipLaunchKernelGGL(k_sparse_update<1>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, (const DevModel*)m->d_dm, m->nblk_occ);
-    else hipLaunchKernelGGL(k_sparse_update<2>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, (const DevModel*)m->d_dm, m->nblk_occ);
+    if (std::max(d.Dtop, d.Ein) <= 256) hipLaunchKernelGGL(k_sparse_update<1>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
+    else hipLaunchKernelGGL(k_sparse_update<2>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
     end();
 #undef begin
     HIPCHK(hipGetLastError());
@@ -595,7 +591,7 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
     if (t0 < 0 || n_steps < 0 || t0 + n_steps > m->T) return fail("step range outside the plan");
     if (m->dm.ns > 0 && !m->have_pop && !m->store_frozen) return fail("negative sampling needs g4r_set_popularity first");
     HIPCHK(hipSetDevice(m->cfg.device));
-    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(1), 0, m->stream, m->dm.st, (long long)t0, (long long)m->gstep);
+    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(1), 0, m->stream, (StepState*)m->dm.st, (long long)t0, (long long)m->gstep, (const int*)m->d_M);
     const bool use_graph = m->cfg.use_graph && !m->profiling && m->dm.apply_dense_inplace;
     size_t ci = std::lower_bound(m->compact_steps.begin(), m->compact_steps.end(), t0) - m->compact_steps.begin();
     int64_t t = t0;
@@ -682,6 +678,10 @@ int g4r_predict_begin(g4r_model* m, int32_t batch) {
     if (batch != m->pbatch) {
         for (int l = 0; l < d.n_layers; ++l) {
             dfree(m, m->pH[l][0]); dfree(m, m->pH[l][1]); dfree(m, m->phout[l]);
+            dfree(m, m->pVc[l]); dfree(m, m->pz[l]); dfree(m, m->pHr[l]);
+            if (dalloc(m, &m->pVc[l], (size_t)batch * d.D[l]) || dalloc(m, &m->pz[l], (size_t)batch * d.D[l]) ||
+                dalloc(m, &m->pHr[l], (size_t)batch * d.D[l]))
+                return -1;
             if (dalloc(m, &m->pH[l][0], (size_t)batch * d.D[l]) || dalloc(m, &m->pH[l][1], (size_t)batch * d.D[l]) ||
                 dalloc(m, &m->phout[l], (size_t)batch * d.D[l]))
                 return -1;
@@ -758,13 +758,17 @@ int g4r_predict_step(g4r_model* m, const int32_t* in_idx, int32_t mrows, const i
     }
     for (int l = 0; l < d.n_layers; ++l) {
         GruFwdPredict pa;
-        pa.in_idx = m->p_in;
-        pa.ysrc = l > 0 ? m->phout[l - 1] : nullptr;
-        pa.Hcur = m->pH[l][m->ppar];
-        pa.Hnext = m->pH[l][m->ppar ^ 1];
-        pa.hout = m->phout[l];
+        pa.in_idx = (GP(const int))m->p_in;
+        pa.ysrc = (GP(const float))(l > 0 ? m->phout[l - 1] : nullptr);
+        pa.Hcur = (GP(const float))m->pH[l][m->ppar];
+        pa.Hnext = (GP(float))m->pH[l][m->ppar ^ 1];
+        pa.hout = (GP(float))m->phout[l];
+        pa.Vc = (GP(float))m->pVc[l]; pa.z = (GP(float))m->pz[l]; pa.Hr = (GP(float))m->pHr[l];
         pa.M = mrows;
-        hipLaunchKernelGGL(gru_fwd_kernel(m->gru_cls[l]), dim3(cdiv(mrows, GRU_ROWS)), dim3(GRU_NW * 64), m->smem_gru_fwd[l], m->stream, (const DevModel*)m->d_dm, l, 0, 0, pa);
+        hipLaunchKernelGGL(k_gru_p1, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(256), SMEM_NN, m->stream,
+                           (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, 0, pa);
+        hipLaunchKernelGGL(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(256), SMEM_NN, m->stream,
+                           (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, pa);
     }
     m->ppar ^= 1;
     const bool sm = (d.final_act == G4R_ACT_SOFTMAX);

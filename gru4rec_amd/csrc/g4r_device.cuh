@@ -35,6 +35,18 @@ __device__ __forceinline__ int4 ldi4(const GAS int* p) { return *(const GAS int4
 __device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
 __device__ __forceinline__ void st4(float* p, float4 v) { *(float4*)p = v; }
 #endif
+// Guarded loads WITHOUT a branch around the load: the address is clamped to the (always valid) base and the value
+// is masked when it is consumed.  `cond ? load : 0` would make the zero a write-after-write hazard on the load's
+// destination registers, and hipcc then puts an s_waitcnt vmcnt(0) behind every load of a batch (one full memory
+// round trip per load instead of one per batch).
+__device__ __forceinline__ float4 ld4_if(const GAS float* base, size_t off, bool ok) {
+    const float4 v = ld4(base + (ok ? off : (size_t)0));
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+__device__ __forceinline__ float ldf_if(const GAS float* base, size_t off, bool ok) {
+    const float v = base[ok ? off : (size_t)0];
+    return ok ? v : 0.f;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Device-resident step state.  The step index lives on the device so that a captured hipGraph of
@@ -44,6 +56,8 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *(float4*)p = v; }
 struct StepState {
     long long t_a, t_b;   // plan step within the epoch
     long long g_a, g_b;   // global step (drives sample-store row, dropout counters, H ping-pong parity)
+    int M_a, M_b;         // active batch rows of the step (plan M[t]), carried here so that a kernel needs ONE
+                          // memory round trip (this struct, passed as a kernel argument) to know its context
     int nan_flag;
     int pad;
 };
@@ -71,10 +85,13 @@ struct DevModel {
     GP(float) H[G4R_MAX_LAYERS][2];
     GP(float) r[G4R_MAX_LAYERS]; GP(float) z[G4R_MAX_LAYERS]; GP(float) c[G4R_MAX_LAYERS];
     GP(float) hd[G4R_MAX_LAYERS]; GP(float) Hr[G4R_MAX_LAYERS];
-    GP(float) dV[G4R_MAX_LAYERS]; GP(float) dyl[G4R_MAX_LAYERS];
+    GP(float) dV[G4R_MAX_LAYERS]; GP(float) dyl[G4R_MAX_LAYERS]; GP(float) Vc[G4R_MAX_LAYERS];
     GP(float) yin0;
     // ---- scoring / loss
     GP(float) Sc; GP(float) dSx; GP(float) dSy; GP(float) dSBy; GP(float) dhpart; GP(float) lossrow; GP(float) loss_steps;
+    // per-occurrence Adagrad pieces written by the gradient producers: dS* hold lr * g / sqrt(acc_pre + g^2 + eps)
+    // (the scaled step), dA* hold acc_pre + g^2 (the accumulator value the LAST occurrence leaves behind)
+    GP(float) dAx; GP(float) dAy; GP(float) dABy;
     int ksplit, kch;
     GP(int) occ_idx;   // [R] item of each gathered-row occurrence (X | Y | samples), -1 = inactive
     GP(int) col_item;  // [ldSc] item of each score column, -1 = inactive

@@ -1,11 +1,14 @@
 // Prediction / evaluation kernels (gfx950): replaces the compiled `self.predict` of
 // gru4rec.py:691-711 and the evaluate function of evaluation.py:54-76.
-//   k_gru_fwd (train = 0)   forward GRU step without dropout / reset        (g4r_train_kernels.cuh)
+//   k_gru_p1/p2 (train = 0) forward GRU step without dropout / reset        (g4r_step_kernels.cuh)
 //   k_score_all             scores[m, n_sel] = h Wy[items]^T + By[items]     gru4rec.py:499-505
 //   k_softmax_rows          final_act == softmax over the selected items     gru4rec.py:193-195
 //   k_rank_rows             rank of the target among the other scores        evaluation.py:56-65
 #pragma once
-#include "g4r_train_kernels.cuh"
+#include "g4r_step_kernels.cuh"
+
+#define SC_BM 128
+#define SC_KC 128
 
 template <int TN>
 __global__ __launch_bounds__(256) void k_score_all(const DevModel* __restrict__ mp, const float* h, int mrows, const int* item_idx,
@@ -139,14 +142,6 @@ __global__ void k_scale(float* p, long long n, float s) {
 }
 
 // explicit instantiations: the launching host code is not visible to the device pass
-template __global__ void k_gru_fwd<3, 16, 1, 16>(const DevModel*, int, int, int, GruFwdPredict);
-template __global__ void k_gru_fwd<6, 8, 2, 16>(const DevModel*, int, int, int, GruFwdPredict);
-template __global__ void k_gru_fwd<12, 4, 4, 8>(const DevModel*, int, int, int, GruFwdPredict);
-template __global__ void k_gru_bwd_rows<1, 16>(const DevModel*, int);
-template __global__ void k_gru_bwd_rows<2, 16>(const DevModel*, int);
-template __global__ void k_gru_bwd_rows<4, 8>(const DevModel*, int);
-template __global__ void k_sparse_update<1>(const DevModel*, int);
-template __global__ void k_sparse_update<2>(const DevModel*, int);
-template __global__ void k_score_fwd<32>(const DevModel*);
-template __global__ void k_score_fwd<16>(const DevModel*);
+template __global__ void k_sparse_update<1>(const DevModel*, StepState*, int);
+template __global__ void k_sparse_update<2>(const DevModel*, StepState*, int);
 template __global__ void k_score_all<32>(const DevModel*, const float*, int, const int*, long long, float*, long long, int);

@@ -1,0 +1,925 @@
+// Training / prediction step kernels (gfx950), second generation: every GEMM of the step is an LDS-staged
+// fp32 MFMA tile GEMM (g4r_gemm.cuh) split over >= 100 workgroups, with gathers, dropout, gates and optimizer
+// updates fused into the operand providers / epilogues.  One training step (reference: the Theano function built
+// at gru4rec.py:572-584 and called at :623) for one GRU layer is 10 launches:
+//   k_gru_p1      V = [y | H] [Wx ; Wrz] + Bh, gates r z, H*r        gather + embedding dropout fused  gru4rec.py:438-473
+//   k_gru_p2      c = act((H*r) Wh + V_c), h, hidden dropout, reset                                     gru4rec.py:474-479
+//   k_score_fwd   Sc = h Wy[Y | samples]^T + By - logq lq            gathered rows through LDS          gru4rec.py:480-495
+//   k_loss_rows   final activation + loss + d cost / d s per row                                        gru4rec.py:193-248,496
+//   k_score_bwd   dSy = ds^T h, dSBy ; split-K slabs of dh = ds Sy                                      (T.grad, :383-384)
+//   k_gru_bwd_pre dh = sum of slabs, dropout mask, da, dz'  (element-wise)
+//   k_gru_bwd_a   dr' = (da Wh^T) H r (1 - r)
+//   k_gru_bwd_b   dy = dV Wx^T  -> dSx (embedding-row gradient) or the lower layer's dh
+//   k_dense_grad  dWx / dWh / dWrz / dBh over the batch + fused dense Adagrad(+momentum)                gru4rec.py:390-406
+//   k_sparse_update  per-occurrence Adagrad on the touched Wy / By / E rows + step bookkeeping          gru4rec.py:407-431
+#pragma once
+#include <type_traits>
+
+#include "g4r_gemm.cuh"
+
+struct StepCtx { long long t, g; int M; };
+
+// `st` is passed to every step kernel as a kernel argument (not read through the descriptor), so these loads
+// are issued together with the descriptor-field loads: one round trip to know (t, g, M).
+__device__ __forceinline__ StepCtx load_ctx_first(StepState* st_) {
+    GAS StepState* st = (GAS StepState*)st_;
+    StepCtx c;
+    c.t = st->t_a; c.g = st->g_a; c.M = st->M_a;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { st->t_b = c.t; st->g_b = c.g; st->M_b = c.M; }
+    return c;
+}
+__device__ __forceinline__ StepCtx load_ctx(StepState* st_) {
+    const GAS StepState* st = (const GAS StepState*)st_;
+    StepCtx c;
+    c.t = st->t_b; c.g = st->g_b; c.M = st->M_b;
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Arguments of the GRU kernels in prediction mode (train = 0; gru4rec.py:433 predict=True): explicit state
+// instead of the device step state, no dropout, no reset switch, nothing saved for a backward pass.
+struct GruFwdPredict {
+    GP(const int) in_idx;    // layer 0 gather indices
+    GP(const float) ysrc;    // layer > 0 input rows
+    GP(const float) Hcur;
+    GP(float) Hnext;
+    GP(float) hout;          // [rows][D]
+    GP(float) Vc; GP(float) z; GP(float) Hr;   // scratch [rows][D]
+    int M;
+};
+
+#define GT_BM 32
+#define GT_BN 32
+#define GT_BK 128
+
+// ---------------------------------------------------------------------------------------------
+// GRU phase 1: V[B, 3D] = [y | H] * [Wx ; 0|Wrz] + Bh over 32x32 tiles, K = IN + D.
+// Epilogue per column block: [0,D) -> Vc (candidate pre-activation part), [D,2D) -> r = sigmoid, Hr = H*r,
+// [2D,3D) -> z = sigmoid.  For layer 0 the A provider gathers Wy[X] / E[X] rows and applies embedding dropout.
+__global__ __launch_bounds__(256) void k_gru_p1(const DevModel* __restrict__ mp, StepState* st, int l, int train, int first, GruFwdPredict pa) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevModel& m = *mp;
+    const int tid = threadIdx.x;
+    const int D = m.D[l], IN = m.IN[l], D3 = 3 * D, K = IN + D;
+    long long t = 0, g = 0;
+    int M;
+    const GAS float *Hcur, *ysrc = nullptr;
+    const GAS int* gidx = nullptr;
+    GAS float *Vc, *zb, *Hrb, *rb = nullptr;
+    if (train) {
+        const StepCtx c = first ? load_ctx_first(st) : load_ctx(st);
+        t = c.t; g = c.g; M = c.M;
+        Hcur = m.H[l][g & 1];
+        if (l == 0) gidx = m.in_idx + t * m.B; else ysrc = m.hd[l - 1];
+        Vc = m.Vc[l]; zb = m.z[l]; Hrb = m.Hr[l]; rb = m.r[l];
+    } else {
+        M = pa.M; Hcur = pa.Hcur; gidx = pa.in_idx; ysrc = pa.ysrc; Vc = pa.Vc; zb = pa.z; Hrb = pa.Hr;
+    }
+    const int m0 = blockIdx.y * GT_BM, n0 = blockIdx.x * GT_BN;
+    // gather indices of the tile's rows go to LDS first: the row loads must not chain behind index loads
+    int* sRow = reinterpret_cast<int*>(smem + TileCfg<GT_BM, GT_BN, GT_BK, false, false>::SMEM_FLOATS);
+    if (tid < GT_BM) {
+        const int row = m0 + tid;
+        const int item = (l == 0 && row < M) ? gidx[row] : -1;
+        sRow[tid] = item;
+        if (train && l == 0 && blockIdx.x == 0 && row < m.B) m.occ_idx[row] = item;
+    }
+    if (m0 >= M) return;
+    __syncthreads();
+    const GAS float* table = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.Wy : m.E;
+    const GAS float* Wx = m.dense_p + m.offWx[l];
+    const GAS float* Wrz = m.dense_p + m.offWrz[l];
+    const GAS float* Bh = m.dense_p + m.offBh[l];
+    const float retain_e = 1.0f - m.drop_e;
+    const float drop_e = m.drop_e;
+    const unsigned long long seed = m.seed;
+    auto aload = [&](int kk, int r, int c) -> float4 {
+        const int row = m0 + r, k = kk + c;
+        const bool ok = row < M && k < K, isy = k < IN;
+        const GAS float* src = isy ? ((l == 0) ? table + (size_t)max(sRow[r], 0) * IN : ysrc + (size_t)row * IN)
+                                   : Hcur + (size_t)row * D;
+        float4 v = ld4_if(src, isy ? k : k - IN, ok);
+        if (train && l == 0 && drop_e > 0.f && ok && isy) {
+            const float4 mk = drop_mult4(seed, (unsigned)g, G4R_STREAM_DROP_EMBED, row, k >> 2, retain_e);
+            v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
+        }
+        return v;
+    };
+    auto bload = [&](int kk, int r, int c) -> float4 {
+        const int k = kk + r, n = n0 + c;
+        const bool isx = k < IN;
+        const bool ok = k < K && n < D3 && (isx || n >= D);
+        return ld4_if(isx ? Wx : Wrz, isx ? (size_t)k * D3 + n : (size_t)(k - IN) * (2 * D) + (n - D), ok);
+    };
+    auto pre = [&](int row, int n) -> float4 {      // bias and (for the r block) the hidden value
+        const bool ok = row < M && n < D3;
+        return make_float4(ldf_if(Bh, n, ok), ldf_if(Hcur, (size_t)row * D + (n - D), ok && n >= D && n < 2 * D), 0.f, 0.f);
+    };
+    auto epi = [&](int row, int n, float v, float4 p) {
+        if (row >= M || n >= D3) return;
+        v += p.x;
+        if (n < D) { Vc[(size_t)row * D + n] = v; return; }
+        if (n < 2 * D) {
+            const size_t o = (size_t)row * D + (n - D);
+            const float rr = sigmoidf_(v);
+            if (train) rb[o] = rr;
+            Hrb[o] = p.y * rr;
+            return;
+        }
+        zb[(size_t)row * D + (n - 2 * D)] = sigmoidf_(v);
+    };
+    gemm_tile<GT_BM, GT_BN, GT_BK, false, false>(m0, n0, K, aload, bload, pre, epi, smem);
+}
+
+// GRU phase 2: c = act(Hr * Wh + Vc) ; h = (1 - z) H + z c ; hidden dropout ; reset switch (gru4rec.py:474-479)
+__global__ __launch_bounds__(256) void k_gru_p2(const DevModel* __restrict__ mp, StepState* st, int l, int train, GruFwdPredict pa) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevModel& m = *mp;
+    const int D = m.D[l];
+    long long t = 0, g = 0;
+    int M;
+    const GAS float *Hcur, *Vc, *zb, *Hrb;
+    GAS float *Hnext, *hout;
+    if (train) {
+        const StepCtx c = load_ctx(st);
+        t = c.t; g = c.g; M = c.M;
+        Hcur = m.H[l][g & 1]; Hnext = m.H[l][(g + 1) & 1]; hout = m.hd[l];
+        Vc = m.Vc[l]; zb = m.z[l]; Hrb = m.Hr[l];
+    } else {
+        M = pa.M; Hcur = pa.Hcur; Hnext = pa.Hnext; hout = pa.hout; Vc = pa.Vc; zb = pa.z; Hrb = pa.Hr;
+    }
+    const int m0 = blockIdx.y * GT_BM, n0 = blockIdx.x * GT_BN;
+    if (m0 >= M) return;
+    const GAS float* Wh = m.dense_p + m.offWh[l];
+    const GAS unsigned char* rst = train ? m.reset + t * m.B : nullptr;
+    const float retain_h = 1.0f - m.drop_h, drop_h = m.drop_h, hp0 = m.ha_p0, hp1 = m.ha_p1;
+    const int hact = m.hidden_act;
+    const unsigned long long seed = m.seed;
+    GAS float* cl = m.c[l];
+    auto aload = [&](int kk, int r, int c) -> float4 {
+        const int row = m0 + r, k = kk + c;
+        return ld4_if(Hrb, (size_t)row * D + k, row < M && k < D);
+    };
+    auto bload = [&](int kk, int r, int c) -> float4 {
+        const int k = kk + r, n = n0 + c;
+        return ld4_if(Wh, (size_t)k * D + n, k < D && n < D);
+    };
+    auto pre = [&](int row, int n) -> float4 {
+        const bool ok = row < M && n < D;
+        const size_t o = (size_t)row * D + n;
+        float4 p = make_float4(ldf_if(Vc, o, ok), ldf_if(zb, o, ok), ldf_if(Hcur, o, ok), 0.f);
+        if (train) p.w = rst[ok ? row : 0] ? 1.f : 0.f;
+        return p;
+    };
+    auto epi = [&](int row, int n, float v, float4 p) {
+        if (row >= M || n >= D) return;
+        const size_t o = (size_t)row * D + n;
+        const float cc = act_fwd(hact, hp0, hp1, v + p.x);
+        const float zz = p.y;
+        float h = (1.0f - zz) * p.z + zz * cc;
+        if (train) {
+            if (drop_h > 0.f) h *= drop_mult(seed, (unsigned)g, G4R_STREAM_DROP_HIDDEN + l, row, n, retain_h);
+            cl[o] = cc;
+            hout[o] = h;
+            Hnext[o] = p.w != 0.f ? 0.f : h;
+        } else {
+            hout[o] = h;
+            Hnext[o] = h;
+        }
+    };
+    gemm_tile<GT_BM, GT_BN, GT_BK, false, false>(m0, n0, D, aload, bload, pre, epi, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scoring GEMM: Sc[B, N] = h[B, D] * Wy[items]^T + By[items] - logq * lq[items]    (gru4rec.py:493-495)
+// 64 x 32 tiles; the B provider gathers the TN output-embedding rows of the tile's columns (in-batch targets,
+// then the step's row of the negative-sample store).  Publishes the column -> item map for the later kernels.
+#define SF_BM 64
+__global__ __launch_bounds__(256) void k_score_fwd(const DevModel* __restrict__ mp, StepState* st) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevModel& m = *mp;
+    using C = TileCfg<SF_BM, GT_BN, GT_BK, false, true>;
+    int* sItem = reinterpret_cast<int*>(smem + C::SMEM_FLOATS);   // [GT_BN]
+    const int tid = threadIdx.x;
+    const StepCtx c = load_ctx(st);
+    const int M = c.M, B = m.B, D = m.Dtop, N = m.N;
+    const int n0 = blockIdx.x * GT_BN, m0 = blockIdx.y * SF_BM;
+    if (tid < GT_BN) {
+        const int n = n0 + tid;
+        int item = -1;
+        if (n < M) item = m.out_idx[c.t * B + n];
+        else if (n >= B && n < N) item = m.ST[(size_t)(c.g % m.gl) * m.ns + (n - B)];
+        sItem[tid] = item;
+        if (blockIdx.y == 0 && n < m.ldSc) {
+            m.col_item[n] = item;
+            if (n < N) m.occ_idx[B + n] = item;
+        }
+    }
+    if (m0 >= M) return;
+    __syncthreads();
+    const GAS float* hsrc = m.hd[m.n_layers - 1];
+    const GAS float *Wy = m.Wy, *By = m.By, *lq_tgt = m.lq_tgt, *lq_smp = m.lq_smp;
+    GAS float* Sc = m.Sc;
+    const float logq = m.logq;
+    const int ldSc = m.ldSc;
+    auto aload = [&](int kk, int r, int cc) -> float4 {
+        const int row = m0 + r, k = kk + cc;
+        return ld4_if(hsrc, (size_t)row * D + k, row < M && k < D);
+    };
+    auto bload = [&](int kk, int r, int cc) -> float4 {
+        const int item = sItem[r], k = kk + cc;
+        return ld4_if(Wy, (size_t)max(item, 0) * D + k, item >= 0 && k < D);
+    };
+    auto pre = [&](int row, int n) -> float4 {      // bias - logQ correction of the column's item
+        const int item = (n < N) ? sItem[n - n0] : -1;
+        const bool ok = item >= 0;
+        float x = ldf_if(By, max(item, 0), ok);
+        const bool lq = ok && logq != 0.f;      // branch-free: the logQ table is only touched when it exists
+        x -= logq * ldf_if(lq ? (n < B ? lq_tgt : lq_smp) : By, max(item, 0), lq);
+        return make_float4(x, 0.f, 0.f, 0.f);
+    };
+    auto epi = [&](int row, int n, float v, float4 p) {
+        if (row >= M || n >= N) return;
+        Sc[(size_t)row * ldSc + n] = v + p.x;
+    };
+    gemm_tile<SF_BM, GT_BN, GT_BK, false, true>(m0, n0, D, aload, bload, pre, epi, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-row final activation, loss and d cost / d s, in place in Sc.  One 256-thread workgroup per
+// batch row; the row (N <= ~40K floats) is staged in LDS; row statistics via wave64 shuffles.
+// Column j is active iff j < M (in-batch targets) or j >= B (sampled negatives); row i's positive is
+// column i.  Losses: gru4rec.py:225-230 (cross_entropy), :239-241 (bpr_max), :245-248 (top1_max),
+// softmax_neg :199-203.  The gradient goes through the softmax weights, as T.grad does.
+__global__ __launch_bounds__(256) void k_loss_rows(const DevModel* __restrict__ mp, StepState* st) {
+    const DevModel& m = *mp;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const StepCtx c = load_ctx(st);
+    const int M = c.M, B = m.B, N = m.N, i = blockIdx.x;
+    const int fact = m.final_act, lossk = m.loss, ldSc = m.ldSc;    // snapshot: used inside the loops below
+    const float fp0 = m.fa_p0, fp1 = m.fa_p1, invB = m.inv_B, bpreg = m.bpreg;
+    if (i >= M) return;
+    float* sy = smem;              // [ldSc] yhat, later d/ds
+    float* red = smem + ldSc;    // [8]
+    GAS float* row = m.Sc + (size_t)i * ldSc;
+#define ACTIVE(j) ((j) < M || (j) >= B)
+    // ---- final activation (gru4rec.py:496)
+    if (fact == G4R_ACT_SOFTMAX) {
+        float mx = -INFINITY;
+        for (int j = tid; j < N; j += 256)
+            if (ACTIVE(j)) { const float v = row[j]; sy[j] = v; mx = fmaxf(mx, v); }
+        mx = block_max_256(mx, red);
+        float sm = 0.f;
+        for (int j = tid; j < N; j += 256)
+            if (ACTIVE(j)) { const float e = fexp(sy[j] - mx); sy[j] = e; sm += e; }
+        sm = block_sum_256(sm, red);
+        const float inv_z = 1.f / sm;
+        for (int j = tid; j < N; j += 256)
+            if (ACTIVE(j)) sy[j] = sy[j] * inv_z;
+    } else {
+        for (int j = tid; j < N; j += 256)
+            if (ACTIVE(j)) sy[j] = act_fwd(fact, fp0, fp1, row[j]);
+    }
+    __syncthreads();
+    const float yd = sy[i];
+    float Lrow = 0.f;
+    // ---- loss and d L / d yhat (kept in registers per strided element, written back to sy)
+    if (lossk == G4R_LOSS_XE) {
+        Lrow = -logf(yd + G4R_EPS_LOSS);
+        __syncthreads();
+        if (fact == G4R_ACT_SOFTMAX) {
+            // ds_k = yhat_k * (dy_k - sum_j dy_j yhat_j) with dy = -delta_ik / (yd + eps)
+            const float coef = yd / (yd + G4R_EPS_LOSS);
+            for (int j = tid; j < N; j += 256)
+                if (ACTIVE(j)) sy[j] = coef * (sy[j] - (j == i ? 1.f : 0.f)) * invB;
+        } else {
+            const float dyd = -1.f / (yd + G4R_EPS_LOSS);
+            for (int j = tid; j < N; j += 256)
+                if (ACTIVE(j))
+                    sy[j] = (j == i) ? dyd * act_bwd_from_out(fact, fp0, fp1, yd) * invB : 0.f;
+        }
+    } else {
+        // softmax over the negatives, with the positive zeroed first (so the max includes a 0)
+        float mx = 0.f;
+        for (int j = tid; j < N; j += 256)
+            if (ACTIVE(j) && j != i) mx = fmaxf(mx, sy[j]);
+        mx = block_max_256(mx, red);
+        float sm = 0.f;
+        for (int j = tid; j < N; j += 256)
+            if (ACTIVE(j) && j != i) sm += fexp(sy[j] - mx);
+        sm = block_sum_256(sm, red);
+        const float inv_sm = 1.f / sm;
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (lossk == G4R_LOSS_BPR_MAX) {
+            for (int j = tid; j < N; j += 256)
+                if (ACTIVE(j) && j != i) {
+                    const float y = sy[j], p = fexp(y - mx) * inv_sm, sg = sigmoidf_(yd - y);
+                    s1 += sg * p;                 // A
+                    s2 += y * y * p;              // Q
+                    s3 += sg * (1.f - sg) * p;    // sum sigma' p
+                }
+        } else {
+            for (int j = tid; j < N; j += 256)
+                if (ACTIVE(j) && j != i) {
+                    const float y = sy[j], p = fexp(y - mx) * inv_sm, u = sigmoidf_(y - yd), q = sigmoidf_(y * y);
+                    s1 += p * (u + q);            // T
+                    s3 += p * u * (1.f - u);
+                }
+        }
+        s1 = block_sum_256(s1, red);
+        s2 = block_sum_256(s2, red);
+        s3 = block_sum_256(s3, red);
+        float dyd;
+        const float inv_A = 1.f / (s1 + G4R_EPS_LOSS);
+        if (lossk == G4R_LOSS_BPR_MAX) {
+            Lrow = -logf(s1 + G4R_EPS_LOSS) + bpreg * s2;
+            dyd = -s3 * inv_A;
+        } else {
+            Lrow = s1;
+            dyd = -s3;
+        }
+        // d L / d yhat_j, written over yhat_j (the softmax final-act branch needs yhat again: keep a copy in row[])
+        const bool fsm = (fact == G4R_ACT_SOFTMAX);
+        float inner = 0.f;
+        for (int j = tid; j < N; j += 256)
+            if (ACTIVE(j)) {
+                const float y = sy[j];
+                float d;
+                if (j == i) d = dyd;
+                else {
+                    const float p = fexp(y - mx) * inv_sm;
+                    if (lossk == G4R_LOSS_BPR_MAX) {
+                        const float sg = sigmoidf_(yd - y);
+                        d = -p * (sg - sg * (1.f - sg) - s1) * inv_A + bpreg * p * (2.f * y + y * y - s2);
+                    } else {
+                        const float u = sigmoidf_(y - yd), q = sigmoidf_(y * y);
+                        d = p * (u + q - s1) + p * (u * (1.f - u) + 2.f * y * q * (1.f - q));
+                    }
+                }
+                if (fsm) { row[j] = y; inner += d * y; sy[j] = d; }
+                else sy[j] = d * act_bwd_from_out(fact, fp0, fp1, y) * invB;
+            }
+        if (fsm) {
+            inner = block_sum_256(inner, red);
+            for (int j = tid; j < N; j += 256)
+                if (ACTIVE(j)) { const float y = row[j]; sy[j] = y * (sy[j] - inner) * invB; }
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < ldSc; j += 256) row[j] = (j < N && ACTIVE(j)) ? sy[j] : 0.f;
+    if (tid == 0) m.lossrow[i] = Lrow;
+#undef ACTIVE
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scoring backward, two roles in one launch (block ranges):
+//   role A (blockIdx.x < nblkA): dSy[N, D] = ds^T h over 32x32 tiles (A = ds read as [k = b][m = n]); the spare
+//          column d == D of the last d-tile carries a ones column of h, so it accumulates dSBy = colsum(ds).
+//   role B: split-K slabs of dh = ds * Sy: tile (32 rows b, 32 cols d) x one 128-wide chunk of score columns,
+//          B provider = gathered Wy rows of the chunk's columns.  Slabs are summed (fixed order) by k_gru_bwd_pre.
+__global__ __launch_bounds__(256) void k_score_bwd(const DevModel* __restrict__ mp, StepState* st, int nblkA, int ndtA, int ndtB, int nrtB) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevModel& m = *mp;
+    const StepCtx c = load_ctx(st);
+    const int M = c.M, B = m.B, D = m.Dtop, N = m.N, ld = m.ldSc, tid = threadIdx.x;
+    const GAS float* h = m.hd[m.n_layers - 1];
+    const GAS float* Sc = m.Sc;
+    const GAS float* Wy = m.Wy;
+    // column -> item map of the tile's score columns, staged in LDS (the gathers must not chain behind index loads)
+    int* sIt = reinterpret_cast<int*>(smem + max(TileCfg<GT_BM, GT_BN, GT_BK, true, false>::SMEM_FLOATS,
+                                                  TileCfg<GT_BM, GT_BN, GT_BK, false, false>::SMEM_FLOATS));
+    if ((int)blockIdx.x < nblkA) {
+        const int nt = blockIdx.x / ndtA, dt = blockIdx.x - nt * ndtA;
+        const int n0 = nt * GT_BM, d0 = dt * GT_BN;
+        if (tid < GT_BM) sIt[tid] = (n0 + tid < N) ? m.col_item[n0 + tid] : -1;
+        __syncthreads();
+        auto aload = [&](int kk, int r, int cc) -> float4 {      // staging tile [k = b][m = n]
+            const int b = kk + r, n = n0 + cc;
+            return ld4_if(Sc, (size_t)b * ld + n, b < M && n < ld);
+        };
+        auto bload = [&](int kk, int r, int cc) -> float4 {      // [k = b][n = d], ones in column d == D
+            const int b = kk + r, d = d0 + cc;
+            float4 v = ld4_if(h, (size_t)b * D + d, b < M && d < D);
+            if (b < M && d == D) v.x = 1.f;
+            return v;
+        };
+        // the per-occurrence Adagrad scaling (gru4rec.py:335-340) happens here, in parallel over all occurrences:
+        // every occurrence uses the PRE-step accumulator of its item, so the steps are independent; the sparse
+        // kernel only has to add them up in occurrence order.
+        const GAS float *accWy = m.accWy, *accBy = m.accBy;
+        GAS float *dSy = m.dSy, *dAy = m.dAy, *dSBy = m.dSBy, *dABy = m.dABy;
+        const float lr = m.lr;
+        auto pre = [&](int n, int d) -> float4 {
+            const int item = (n - n0 < GT_BM) ? sIt[n - n0] : -1;
+            const bool ok = item >= 0 && d <= D;
+            const float a = (d < D) ? ldf_if(accWy, (size_t)max(item, 0) * D + d, ok) : ldf_if(accBy, max(item, 0), ok);
+            return make_float4(a, ok ? 1.f : 0.f, 0.f, 0.f);
+        };
+        auto epi = [&](int n, int d, float g, float4 p) {
+            if (n >= N || d > D) return;
+            const float an = p.x + g * g;
+            const float step = (p.y != 0.f) ? lr * g * frsq(an + G4R_EPS_ADAGRAD) : 0.f;
+            if (d < D) { dSy[(size_t)n * D + d] = step; dAy[(size_t)n * D + d] = an; }
+            else { dSBy[n] = step; dABy[n] = an; }
+        };
+        gemm_tile<GT_BM, GT_BN, GT_BK, true, false>(n0, d0, M, aload, bload, pre, epi, smem);
+        return;
+    }
+    const int w = blockIdx.x - nblkA;
+    const int per_kc = nrtB * ndtB;
+    const int kc = w / per_kc, rem = w - kc * per_kc, rt = rem / ndtB, dt = rem - rt * ndtB;
+    const int m0 = rt * GT_BM, d0 = dt * GT_BN, kbeg = kc * GT_BK;
+    if (m0 >= M) return;
+    if (tid < GT_BK) sIt[tid] = (kbeg + tid < ld) ? m.col_item[kbeg + tid] : -1;
+    __syncthreads();
+    GAS float* dhpart = m.dhpart;
+    auto aload = [&](int kk, int r, int cc) -> float4 {
+        const int b = m0 + r, n = kbeg + kk + cc;
+        return ld4_if(Sc, (size_t)b * ld + n, b < M && n < ld);
+    };
+    auto bload = [&](int kk, int r, int cc) -> float4 {
+        const int item = sIt[kk + r], d = d0 + cc;
+        return ld4_if(Wy, (size_t)max(item, 0) * D + d, item >= 0 && d < D);
+    };
+    auto epi = [&](int b, int d, float v, float4) {
+        if (b < M && d < D) dhpart[((size_t)kc * B + b) * D + d] = v;
+    };
+    gemm_tile<GT_BM, GT_BN, GT_BK, false, false>(m0, d0, min(GT_BK, ld - kbeg), aload, bload, NoPre(), epi, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GRU backward (no BPTT: H is a constant input, gru4rec.py:460-463,576), element-wise head:
+//   dh = sum of split-K slabs (top layer) or the upper layer's dy ; hidden-dropout mask ;
+//   dz = dh (c - H) ; dc = dh z ; da = dc act'(c) ; dz' = dz z (1 - z)      -> dV[:, 0:D] = da, dV[:, 2D:3D] = dz'
+__global__ __launch_bounds__(256) void k_gru_bwd_pre(const DevModel* __restrict__ mp, StepState* st, int l) {
+    const DevModel& m = *mp;
+    const StepCtx c = load_ctx(st);
+    const int M = c.M, B = m.B, D = m.D[l], D3 = 3 * D;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * D) return;
+    const int row = e / D, d = e - row * D;
+    const size_t o = (size_t)row * D + d;
+    float dh = 0.f;
+    if (l == m.n_layers - 1) {
+        const GAS float* pp = m.dhpart + o;
+        const size_t ps = (size_t)B * D;
+        int kc = 0;
+        for (; kc + 8 <= m.ksplit; kc += 8) {     // 8 independent loads in flight, fixed summation order
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = pp[(size_t)(kc + q) * ps];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dh += v[q];
+        }
+        for (; kc < m.ksplit; ++kc) dh += pp[(size_t)kc * ps];
+    } else {
+        dh = m.dyl[l][o];
+    }
+    if (m.drop_h > 0.f) dh *= drop_mult(m.seed, (unsigned)c.g, G4R_STREAM_DROP_HIDDEN + l, row, d, 1.0f - m.drop_h);
+    const float hv = m.H[l][c.g & 1][o], zz = m.z[l][o], cc = m.c[l][o];
+    const float dz = dh * (cc - hv), dc = dh * zz;
+    m.dV[l][(size_t)row * D3 + d] = dc * act_bwd_from_out(m.hidden_act, m.ha_p0, m.ha_p1, cc);
+    m.dV[l][(size_t)row * D3 + 2 * D + d] = dz * zz * (1.f - zz);
+}
+
+// dr' = (da Wh^T) * H * r (1 - r)  -> dV[:, D:2D]      (B provider reads Wh rows: B[k][n] = Wh[n][k])
+__global__ __launch_bounds__(256) void k_gru_bwd_a(const DevModel* __restrict__ mp, StepState* st, int l) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevModel& m = *mp;
+    const StepCtx c = load_ctx(st);
+    const int M = c.M, D = m.D[l], D3 = 3 * D;
+    const int m0 = blockIdx.y * GT_BM, n0 = blockIdx.x * GT_BN;
+    if (m0 >= M) return;
+    const GAS float* Wh = m.dense_p + m.offWh[l];
+    const GAS float* Hcur = m.H[l][c.g & 1];
+    GAS float* dV = m.dV[l];
+    const GAS float* rl = m.r[l];
+    auto aload = [&](int kk, int r, int cc) -> float4 {
+        const int row = m0 + r, k = kk + cc;
+        return ld4_if(dV, (size_t)row * D3 + k, row < M && k < D);
+    };
+    auto bload = [&](int kk, int r, int cc) -> float4 {
+        const int n = n0 + r, k = kk + cc;
+        return ld4_if(Wh, (size_t)n * D + k, n < D && k < D);
+    };
+    auto pre = [&](int row, int n) -> float4 {
+        const bool ok = row < M && n < D;
+        const size_t o = (size_t)row * D + n;
+        return make_float4(ldf_if(rl, o, ok), ldf_if(Hcur, o, ok), 0.f, 0.f);
+    };
+    auto epi = [&](int row, int n, float v, float4 p) {
+        if (row >= M || n >= D) return;
+        dV[(size_t)row * D3 + D + n] = v * p.y * p.x * (1.f - p.x);
+    };
+    gemm_tile<GT_BM, GT_BN, GT_BK, false, true>(m0, n0, D, aload, bload, pre, epi, smem);
+}
+
+// dy = dV Wx^T -> embedding-row gradient dSx (layer 0, through the embedding-dropout mask) or the lower layer's dh
+__global__ __launch_bounds__(256) void k_gru_bwd_b(const DevModel* __restrict__ mp, StepState* st, int l) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevModel& m = *mp;
+    const StepCtx c = load_ctx(st);
+    const int M = c.M, D = m.D[l], IN = m.IN[l], D3 = 3 * D;
+    const int m0 = blockIdx.y * GT_BM, n0 = blockIdx.x * GT_BN;
+    if (m0 >= M) return;
+    const GAS float* Wx = m.dense_p + m.offWx[l];
+    const GAS float* dV = m.dV[l];
+    int* sRow = reinterpret_cast<int*>(smem + TileCfg<GT_BM, GT_BN, GT_BK, false, true>::SMEM_FLOATS);
+    if (threadIdx.x < GT_BM) sRow[threadIdx.x] = (l == 0 && m0 + threadIdx.x < M) ? m.occ_idx[m0 + threadIdx.x] : -1;
+    __syncthreads();
+    auto aload = [&](int kk, int r, int cc) -> float4 {
+        const int row = m0 + r, k = kk + cc;
+        return ld4_if(dV, (size_t)row * D3 + k, row < M && k < D3);
+    };
+    auto bload = [&](int kk, int r, int cc) -> float4 {
+        const int n = n0 + r, k = kk + cc;
+        return ld4_if(Wx, (size_t)n * D3 + k, n < IN && k < D3);
+    };
+    const GAS float* accT = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.accWy : m.accE;
+    const float lr = m.lr, drop_e = m.drop_e;
+    const unsigned long long seed = m.seed;
+    GAS float *dSx = m.dSx, *dAx = m.dAx, *dylo = (l > 0) ? m.dyl[l - 1] : nullptr;
+    auto pre = [&](int row, int n) -> float4 {      // pre-step accumulator of the input item's row (layer 0)
+        const int item = (row - m0 < GT_BM) ? sRow[row - m0] : -1;
+        return make_float4(ldf_if(accT, (size_t)max(item, 0) * IN + n, item >= 0 && n < IN), 0.f, 0.f, 0.f);
+    };
+    auto epi = [&](int row, int n, float v, float4 p) {
+        if (row >= M || n >= IN) return;
+        if (l == 0) {
+            if (drop_e > 0.f) v *= drop_mult(seed, (unsigned)c.g, G4R_STREAM_DROP_EMBED, row, n, 1.0f - drop_e);
+            const float an = p.x + v * v;
+            dSx[(size_t)row * IN + n] = lr * v * frsq(an + G4R_EPS_ADAGRAD);
+            dAx[(size_t)row * IN + n] = an;
+        } else {
+            dylo[(size_t)row * IN + n] = v;
+        }
+    };
+    gemm_tile<GT_BM, GT_BN, GT_BK, false, true>(m0, n0, D3, aload, bload, pre, epi, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense gradients: contractions over the batch, one wave per 16x16 output tile of
+//   dWx = yin^T dV ; dWh = (H r)^T dV[:, :D] ; dWrz = H^T dV[:, D:] ; dBh = colsum(dV)
+// with the dense Adagrad(+momentum) update (gru4rec.py:330-334,390-406) fused into the epilogue when
+// no all-reduce is needed (single GPU); otherwise the gradient goes to dense_g for RCCL.
+// One 16x16 output tile of a dense GRU gradient, resolved on the host: out[r0.., c0..] (leading dim ldo, at
+// float offset `base` of the flat dense buffers) = X^T[., batch] * dV[batch, coff + .] ; X0/X1 = operand for
+// even/odd global step (the hidden state ping-pongs) ; X == nullptr selects the bias row (column sums of dV).
+struct DenseTile {
+    GP(const float) X0; GP(const float) X1; GP(const float) dV;
+    long long base;
+    int ldx, ldv, nrows, ncols, coff, ldo, r0, c0;
+    int gather, pad;     // gather = 1: X rows are the step's input embedding rows table[in_idx[b]] (+ embedding dropout)
+};
+
+__device__ __forceinline__ void dense_adagrad(const DevModel& m, size_t off, float g) {
+    const float acc = m.dense_acc[off] + g * g;
+    m.dense_acc[off] = acc;
+    const float gs = g * frsq(acc + G4R_EPS_ADAGRAD);
+    const float p = m.dense_p[off];
+    if (m.mom > 0.f) {
+        const float v = m.mom * m.dense_vel[off] - m.lr * (gs + m.lmbd * p);
+        m.dense_vel[off] = v;
+        m.dense_p[off] = p + v;
+    } else {
+        m.dense_p[off] = p * (1.0f - m.lr * m.lmbd) - m.lr * gs;
+    }
+}
+
+// One workgroup per 32x32 output tile of a dense GRU gradient (contraction over the batch):
+//   dWx = yin^T dV ; dWh = (H r)^T dV[:, :D] ; dWrz = H^T dV[:, D:] ; dBh = colsum(dV)
+// with the dense Adagrad(+momentum) update (gru4rec.py:330-334,390-406) fused into the epilogue when no all-reduce
+// is needed (single GPU); otherwise the gradient goes to dense_g for RCCL.
+__global__ __launch_bounds__(256) void k_dense_grad(const DevModel* __restrict__ mp, StepState* st, const DenseTile* __restrict__ tiles_) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevModel& m = *mp;
+    const GAS DenseTile* tiles = (const GAS DenseTile*)tiles_;   // same mangled signature on both passes
+    const StepCtx c = load_ctx(st);
+    const DenseTile tl = tiles[blockIdx.x];    // fully resolved on the host: no per-layer lookups here
+    const GAS float* X = (c.g & 1) ? tl.X1 : tl.X0;
+    const GAS float* dV = tl.dV;
+    const int M = c.M, tid = threadIdx.x;
+    const bool ones = (X == nullptr) && !tl.gather;          // bias row: column sums of dV
+    // layer-0 input rows are re-gathered (and re-masked) here instead of being written out by the forward kernel
+    int* sIdx = reinterpret_cast<int*>(smem + TileCfg<GT_BM, GT_BN, GT_BK, true, false>::SMEM_FLOATS);   // [B]
+    const GAS float* table = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.Wy : m.E;
+    if (tl.gather) {
+        for (int b = tid; b < M; b += 256) sIdx[b] = m.in_idx[c.t * m.B + b];
+        __syncthreads();
+    }
+    const float drop_e = m.drop_e, lr = m.lr, momc = m.mom, lmbd = m.lmbd;
+    const unsigned long long seed = m.seed;
+    const int inplace = m.apply_dense_inplace;
+    GAS float *dp = m.dense_p, *dacc = m.dense_acc, *dvel = m.dense_vel, *dg = m.dense_g;
+    auto aload = [&](int kk, int r, int cc) -> float4 {      // staging tile [k = b][m = output row]
+        const int b = kk + r, rr = tl.r0 + cc;
+        const bool ok = b < M && rr < tl.nrows;
+        if (ones) return make_float4((ok && rr == 0) ? 1.f : 0.f, 0.f, 0.f, 0.f);
+        if (tl.gather) {
+            float4 v = ld4_if(table, (size_t)sIdx[ok ? b : 0] * tl.ldx + rr, ok);
+            if (drop_e > 0.f && ok) {
+                const float4 mk = drop_mult4(seed, (unsigned)c.g, G4R_STREAM_DROP_EMBED, b, rr >> 2, 1.0f - drop_e);
+                v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
+            }
+            return v;
+        }
+        return ld4_if(X, (size_t)b * tl.ldx + rr, ok);
+    };
+    auto bload = [&](int kk, int r, int cc) -> float4 {
+        const int b = kk + r, col = tl.c0 + cc;
+        return ld4_if(dV, (size_t)b * tl.ldv + tl.coff + col, b < M && col < tl.ncols);
+    };
+    auto pre = [&](int row, int col) -> float4 {      // optimizer state of the element (accumulator, parameter, velocity)
+        const bool ok = inplace && row < tl.nrows && col < tl.ncols;
+        const size_t off = (size_t)tl.base + (size_t)row * tl.ldo + col;
+        return make_float4(ldf_if(dacc, off, ok), ldf_if(dp, off, ok), ldf_if(dvel, off, ok && momc > 0.f), 0.f);
+    };
+    auto epi = [&](int row, int col, float g, float4 p) {
+        if (row >= tl.nrows || col >= tl.ncols) return;
+        const size_t off = (size_t)tl.base + (size_t)row * tl.ldo + col;
+        if (!inplace) { dg[off] = g; return; }
+        const float acc = p.x + g * g;            // gru4rec.py:330-334,390-406
+        dacc[off] = acc;
+        const float gs = g * frsq(acc + G4R_EPS_ADAGRAD);
+        if (momc > 0.f) {
+            const float v = momc * p.z - lr * (gs + lmbd * p.y);
+            dvel[off] = v;
+            dp[off] = p.y + v;
+        } else {
+            dp[off] = p.y * (1.0f - lr * lmbd) - lr * gs;
+        }
+    };
+    gemm_tile<GT_BM, GT_BN, GT_BK, true, false>(tl.r0, tl.c0, M, aload, bload, pre, epi, smem);
+}
+
+// after the RCCL all-reduce: element-wise dense Adagrad on the averaged gradient
+__global__ __launch_bounds__(256) void k_dense_apply(const DevModel* __restrict__ mp) {
+    const DevModel& m = *mp;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < m.dense_count) dense_adagrad(m, (size_t)i, m.dense_g[i] * m.grad_scale);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sparse Adagrad(+momentum) on the gathered rows, gru4rec.py:335-340,407-431, with the reference's
+// duplicate-index semantics made deterministic:
+//   - every occurrence is scaled with the PRE-step accumulator: g~ = g / sqrt(acc_old + g^2 + eps)
+//   - parameter increments of duplicates accumulate, in occurrence order (inc_subtensor)
+//   - accumulator / velocity take the value of the LAST occurrence (set_subtensor, NumPy order)
+// One wave per occurrence k of (X | Y | samples).  The wave of the last occurrence of an item owns
+// the row: it scans the occurrence list for its duplicates (ballot over 64 entries at a time) and
+// applies them in ascending order.  No atomics, no scratch state, bit-reproducible.
+// The extra last block folds the per-row losses into loss_steps[t] and advances the step state.
+#define SP_WAVES 8   // occurrences (waves) per workgroup
+
+// MAXCH = float4 chunks per lane (1: row width <= 256, 2: <= 512).  One wave per occurrence k of
+// (X | Y | samples); the wave of an item's LAST occurrence owns the row and applies all of the item's
+// occurrences in ascending order (semantics: comment block above).  The occurrence list is
+// staged in LDS once per workgroup; the owner keeps its duplicate list in registers (entry i in lane i) and
+// fetches the gradient rows of up to UB duplicates together, so a hot item costs cnt/UB memory round trips
+// instead of cnt.  The extra last block folds the per-row losses into loss_steps[t] and advances the step state.
+template <int MAXCH>
+__global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevModel* __restrict__ mp, StepState* st, int nblk_occ) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevModel& m = *mp;
+    int* sOcc = reinterpret_cast<int*>(smem);     // occurrence list, padded with -2 to a multiple of 256 (+256)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const StepCtx c = load_ctx(st);
+    const int B = m.B, R = m.R;
+    // descriptor fields used inside loops are snapshotted into registers: re-reading them through `mp` costs a
+    // scalar-memory round trip per iteration (the compiler does not hoist them across the global stores)
+    const float lr = m.lr, momc = m.mom, lmbd = m.lmbd;
+    const GAS float *g_dSx = m.dSx, *g_dSy = m.dSy, *g_dAx = m.dAx, *g_dAy = m.dAy, *g_dSBy = m.dSBy, *g_dABy = m.dABy;
+    if ((int)blockIdx.x == nblk_occ) {
+        // ---- bookkeeping block: cost = sum_i L_i / batch_size (gru4rec.py:577), NaN flag (:626), advance state
+        if (wid == 0) {
+            float s = 0.f;
+            for (int i = lane; i < c.M; i += 64) s += m.lossrow[i];
+            s = wave_sum(s);
+            if (lane == 0) {
+                const float cost = s * m.inv_B;
+                m.loss_steps[c.t] = cost;
+                GAS StepState* sg = (GAS StepState*)st;
+                if (isnan(cost)) sg->nan_flag = 1;
+                sg->t_a = c.t + 1;
+                sg->g_a = c.g + 1;
+                sg->M_a = m.Mplan[c.t + 1];     // the plan carries one trailing entry
+            }
+        }
+        return;
+    }
+    const long long t_start = m.dbgclk ? wall_clock64() : 0;
+    G4R_TICK(m, 1, 0);
+    const int Rpad = ((R + 255) & ~255) + 256;
+    for (int j = tid; j < Rpad; j += SP_WAVES * 64) sOcc[j] = j < R ? m.occ_idx[j] : -2;
+    __syncthreads();
+    G4R_TICK(m, 1, 1);
+    const int k = blockIdx.x * SP_WAVES + wid;
+    if (k >= R) return;
+    const int item = sOcc[k];
+    if (item < 0) return;
+    const bool constrained = (m.embed_mode == G4R_EMBED_CONSTRAINED);
+    // occurrence range sharing a table with k: constrained -> all of X|Y|samples ; separate -> X alone, Y|samples alone
+    const int lo = (constrained || k < B) ? 0 : B;
+    const int hi = (constrained || k >= B) ? R : B;
+    // ---- is there a later occurrence of the same item?  then that wave owns the row
+    for (int base = (k + 1) & ~255; base < hi; base += 256) {
+        int v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = sOcc[base + 64 * e + lane];
+        bool later = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int j = base + 64 * e + lane; later |= (j > k && j < hi && v[e] == item); }
+        if (__ballot(later)) return;
+    }
+    const long long t_own = m.dbgclk ? wall_clock64() : 0;
+    G4R_TICK(m, 1, 2);
+    // ---- row state (pre-step values; every occurrence is scaled with the pre-step accumulator)
+    const bool tableE = (k < B && !constrained);
+    GAS float* P = tableE ? m.E : m.Wy;
+    GAS float* A = tableE ? m.accE : m.accWy;
+    GAS float* V = tableE ? m.velE : m.velWy;
+    const int W = tableE ? m.Ein : m.Dtop;
+    const int nc4 = W >> 2;
+    const bool mom = momc > 0.f;
+    const bool bias = (k >= B);
+    float pc[MAXCH][4], pz[MAXCH][4], az[MAXCH][4], vz[MAXCH][4], al[MAXCH][4], vl[MAXCH][4];
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) {
+        const int c4 = lane + 64 * q;
+        const size_t o = (size_t)item * W + 4 * min(c4, nc4 - 1);
+        const float4 p0 = ld4(P + o);      // the accumulator row itself is not needed: dA* carries acc_pre + g^2
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), v0 = a0;
+        if (mom) v0 = ld4(V + o);
+        pz[q][0] = p0.x; pz[q][1] = p0.y; pz[q][2] = p0.z; pz[q][3] = p0.w;
+        az[q][0] = a0.x; az[q][1] = a0.y; az[q][2] = a0.z; az[q][3] = a0.w;
+        vz[q][0] = v0.x; vz[q][1] = v0.y; vz[q][2] = v0.z; vz[q][3] = v0.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pc[q][e] = pz[q][e]; al[q][e] = az[q][e]; vl[q][e] = vz[q][e]; }
+    }
+    // output bias By: occurrences among Y|samples only (gru4rec.py:486-489)
+    float bp = 0.f, bpz = 0.f, baz = 0.f, bvz = 0.f, bal = 0.f, bvl = 0.f;
+    if (bias) {
+        bp = m.By[item]; bpz = bp;
+        if (mom) { bvz = m.velBy[item]; bvl = bvz; }
+    }
+    constexpr int UB = (MAXCH == 1) ? 16 : 8;     // keeps the kernel at <= 128 VGPRs: every workgroup must be resident at once
+    // apply the duplicates listed one-per-lane in myj[0..cnt), ascending occurrence order.  The gradient producers
+    // already turned every occurrence's gradient row into its scaled step (dS*) and left acc_pre + g^2 in dA*, so
+    // what remains here is the ordered accumulation into the parameter row and "last occurrence wins" for the state.
+    auto apply = [&](int myj, int cnt) {
+        const int jb = (lane < cnt && myj >= B) ? myj : -1;
+        float dlt_b = 0.f, an_b = 0.f;     // lane i: bias step of duplicate i
+        if (bias && jb >= 0) { dlt_b = g_dSBy[jb - B]; an_b = g_dABy[jb - B]; }
+        const int jlast = __builtin_amdgcn_readlane(myj, (cnt - 1) & 63);
+        // one batch = the step rows of up to UB duplicates fetched together (one memory round trip), then added in
+        // occurrence order; all branches on the duplicate count are wave-uniform, so a singleton costs one row
+        for (int i0 = 0; i0 < cnt; i0 += UB) {
+            float4 g[UB][MAXCH];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (i0 + u < cnt) {       // wave-uniform; the loads themselves are unconditional (clamped chunk index)
+                    const int jj = __builtin_amdgcn_readlane(myj, (i0 + u) & 63);
+                    const GAS float* srow = (jj < B) ? g_dSx + (size_t)jj * W : g_dSy + (size_t)(jj - B) * W;
+#pragma unroll
+                    for (int q = 0; q < MAXCH; ++q) g[u][q] = ld4(srow + 4 * min(lane + 64 * q, nc4 - 1));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (i0 + u < cnt) {
+#pragma unroll
+                    for (int q = 0; q < MAXCH; ++q) {
+                        const float sv[4] = {g[u][q].x, g[u][q].y, g[u][q].z, g[u][q].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float delta = (lmbd > 0.f) ? sv[e] + lr * lmbd * pz[q][e] : sv[e];
+                            if (mom) {
+                                const float v2 = momc * vz[q][e] - delta;
+                                vl[q][e] = v2;
+                                pc[q][e] = pc[q][e] + v2;
+                            } else {
+                                pc[q][e] = pc[q][e] - delta;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // accumulator: value left by the last occurrence of this batch of the list
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) {
+            const int c4 = lane + 64 * q;
+            {
+                const GAS float* arow = (jlast < B) ? g_dAx + (size_t)jlast * W : g_dAy + (size_t)(jlast - B) * W;
+                const float4 a4 = ld4(arow + 4 * min(c4, nc4 - 1));
+                al[q][0] = a4.x; al[q][1] = a4.y; al[q][2] = a4.z; al[q][3] = a4.w;
+            }
+        }
+        if (bias) {
+            for (int i = 0; i < cnt; ++i) {          // ordered chain over scalar (SGPR) broadcasts
+                const int jj = __builtin_amdgcn_readlane(jb, i);
+                if (jj < 0) continue;
+                float delta = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlt_b), i));
+                if (lmbd > 0.f) delta += lr * lmbd * bpz;
+                bal = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, an_b), i));
+                if (mom) { const float v2 = momc * bvz - delta; bvl = v2; bp = bp + v2; }
+                else bp = bp - delta;
+            }
+        }
+    };
+    // ---- collect this item's occurrences in [lo, k] (ascending), 64 per pass (one list entry per lane), and apply
+    // them.  The scan loop is kept tiny (the big apply body sits outside of it: instruction-cache friendly); items
+    // with more than 64 occurrences in one step simply take another pass.
+    int total = 0;
+    for (int pass = 0;; ++pass) {
+        int myj = -1, idx = 0;
+        const int lo_i = 64 * pass;
+        for (int base = lo & ~255; base <= k; base += 256) {
+            int v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = sOcc[base + 64 * e + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = base + 64 * e + lane;
+                unsigned long long mask = __ballot(j >= lo && j <= k && v[e] == item);
+                while (mask) {
+                    const int bit = __ffsll((unsigned long long)mask) - 1;
+                    mask &= mask - 1;
+                    if (lane == idx - lo_i) myj = base + 64 * e + bit;
+                    ++idx;
+                }
+            }
+        }
+        total = idx;
+        const int n_here = min(idx - lo_i, 64);
+        if (n_here > 0) apply(myj, n_here);
+        if (idx <= lo_i + 64) break;
+    }
+    const long long t_col = m.dbgclk ? wall_clock64() : 0;
+    G4R_TICK(m, 1, 3);
+    const long long t_app = t_col;
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) {
+        const int c4 = lane + 64 * q;
+        if (c4 < nc4) {
+            const size_t o = (size_t)item * W + 4 * c4;
+            st4(P + o, make_float4(pc[q][0], pc[q][1], pc[q][2], pc[q][3]));
+            st4(A + o, make_float4(al[q][0], al[q][1], al[q][2], al[q][3]));
+            if (mom) st4(V + o, make_float4(vl[q][0], vl[q][1], vl[q][2], vl[q][3]));
+        }
+    }
+    if (bias && lane == 0) {
+        m.By[item] = bp;
+        m.accBy[item] = bal;
+        if (mom) m.velBy[item] = bvl;
+    }
+    G4R_TICK(m, 1, 4);
+    if (m.dbgclk && lane == 0) {
+        const long long t_end = wall_clock64();
+        const long long dur = t_end - t_start;
+        GAS long long* tr = m.dbgclk + 64 + 8 * k;
+        tr[0] = t_start; tr[1] = t_own; tr[2] = t_col; tr[3] = t_app; tr[4] = t_end; tr[5] = total; tr[6] = 0; tr[7] = item;
+        (void)dur;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Negative-sample store refill: ST[e] = upper_bound(P, u_e) with the end clamps of the reference's
+// GpuBinarySearchSorted (custom_theano_ops.py:318-349); uniforms from Philox (one call per 4 samples).
+__global__ __launch_bounds__(256) void k_sample_refill(int* ST, long long n, const float* P, int n_items,
+                                                       unsigned long long seed, unsigned refill_no) {
+    const long long cidx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (cidx * 4 >= n) return;
+    const Philox4 p = philox4x32_10((unsigned)cidx, refill_no, 0u, G4R_STREAM_SAMPLE, (unsigned)seed,
+                                    (unsigned)(seed >> 32));
+    const unsigned xs[4] = {p.x, p.y, p.z, p.w};
+    const float minv = P[0], maxv = P[n_items - 1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long long idx = cidx * 4 + e;
+        if (idx >= n) break;
+        const float val = u32_to_unit(xs[e]);
+        long long a = 0, b = n_items - 1;
+        if (val > maxv) { a = n_items; b = n_items; }
+        else if (val <= minv) { a = 0; b = 0; }
+        while (b - a > 0) {
+            const long long hmid = (a + b) / 2;
+            if (val < P[hmid]) b = hmid; else a = hmid + 1;
+        }
+        ST[idx] = (int)b;
+    }
+}
+
+// hidden-state row compaction (gru4rec.py:647-651): dst[j] = src[map[j]] (map < 0 -> zeros)
+__global__ __launch_bounds__(256) void k_gather_rows(float* dst, const float* src, const int* map, int nrows, int W) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nrows * W) return;
+    const int j = e / W, d = e - j * W, s = map[j];
+    dst[e] = s >= 0 ? src[(size_t)s * W + d] : 0.f;
+}
+
+__global__ void k_set_state(StepState* st, long long t, long long g, const int* Mplan) {
+    st->t_a = t; st->t_b = t; st->g_a = g; st->g_b = g;
+    st->M_a = Mplan[t]; st->M_b = Mplan[t];
+}
