@@ -107,6 +107,8 @@ static constexpr size_t tile_smem() { return (size_t)TileCfg<BM, BN, BK, AKM, BN
 static const size_t SMEM_NN = tile_smem<GT_BM, GT_BN, GT_BK, false, false>() + GT_BM * sizeof(int);   // A [m][k], B [k][n] (+ row items)
 static const size_t SMEM_NT = tile_smem<GT_BM, GT_BN, GT_BK, false, true>() + GT_BM * sizeof(int);    // A [m][k], B [n][k] (+ row items)
 static const size_t SMEM_TN = tile_smem<GT_BM, GT_BN, GT_BK, true, false>();    // A [k][m], B [k][n]
+static const size_t SMEM_P1 = tile_smem<GT_BM, GT_BN, P1_BK, false, false>() + GT_BM * sizeof(int);
+static const size_t SMEM_BB = tile_smem<GT_BM, GT_BN, BB_BK, false, true>() + GT_BM * sizeof(int);
 static const size_t SMEM_SF = tile_smem<SF_BM, GT_BN, GT_BK, false, true>() + GT_BN * sizeof(int);
 // publish the host descriptor to the device copy (stream-ordered; pageable source is staged before return)
 static int sync_dm(g4r_model* m) {
@@ -510,7 +512,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
     StepState* stp = (StepState*)d.st;
     for (int l = 0; l < L; ++l) {
         begin(KN_GRU_P1);
-        hipLaunchKernelGGL(k_gru_p1, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_NN, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
+        hipLaunchKernelGGL(k_gru_p1, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_P1, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
         end();
         begin(KN_GRU_P2);
         hipLaunchKernelGGL(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_NN, s, dmp, stp, l, 1, nopa);
@@ -533,7 +535,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
         hipLaunchKernelGGL(k_gru_bwd_a, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_NT, s, dmp, stp, l);
         end();
         begin(KN_BWD_B);
-        hipLaunchKernelGGL(k_gru_bwd_b, dim3(cdiv(d.IN[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_NT, s, dmp, stp, l);
+        hipLaunchKernelGGL(k_gru_bwd_b, dim3(cdiv(d.IN[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_BB, s, dmp, stp, l);
         end();
     }
     begin(KN_DENSE);
@@ -765,7 +767,7 @@ int g4r_predict_step(g4r_model* m, const int32_t* in_idx, int32_t mrows, const i
         pa.hout = (GP(float))m->phout[l];
         pa.Vc = (GP(float))m->pVc[l]; pa.z = (GP(float))m->pz[l]; pa.Hr = (GP(float))m->pHr[l];
         pa.M = mrows;
-        hipLaunchKernelGGL(k_gru_p1, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(256), SMEM_NN, m->stream,
+        hipLaunchKernelGGL(k_gru_p1, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(256), SMEM_P1, m->stream,
                            (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, 0, pa);
         hipLaunchKernelGGL(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(256), SMEM_NN, m->stream,
                            (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, pa);

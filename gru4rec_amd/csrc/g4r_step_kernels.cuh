@@ -51,6 +51,8 @@ struct GruFwdPredict {
 #define GT_BM 32
 #define GT_BN 32
 #define GT_BK 128
+#define P1_BK 256     // K = IN + D of GRU phase 1 in one chunk up to IN + D = 256
+#define BB_BK 320     // K = 3D of dy = dV Wx^T in one chunk up to D = 106
 
 // ---------------------------------------------------------------------------------------------
 // GRU phase 1: V[B, 3D] = [y | H] * [Wx ; 0|Wrz] + Bh over 32x32 tiles, K = IN + D.
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void k_gru_p1(const DevModel* __restrict__ mp,
     }
     const int m0 = blockIdx.y * GT_BM, n0 = blockIdx.x * GT_BN;
     // gather indices of the tile's rows go to LDS first: the row loads must not chain behind index loads
-    int* sRow = reinterpret_cast<int*>(smem + TileCfg<GT_BM, GT_BN, GT_BK, false, false>::SMEM_FLOATS);
+    int* sRow = reinterpret_cast<int*>(smem + TileCfg<GT_BM, GT_BN, P1_BK, false, false>::SMEM_FLOATS);
     if (tid < GT_BM) {
         const int row = m0 + tid;
         const int item = (l == 0 && row < M) ? gidx[row] : -1;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void k_gru_p1(const DevModel* __restrict__ mp,
         }
         zb[(size_t)row * D + (n - 2 * D)] = sigmoidf_(v);
     };
-    gemm_tile<GT_BM, GT_BN, GT_BK, false, false>(m0, n0, K, aload, bload, pre, epi, smem);
+    gemm_tile<GT_BM, GT_BN, P1_BK, false, false>(m0, n0, K, aload, bload, pre, epi, smem);
 }
 
 // GRU phase 2: c = act(Hr * Wh + Vc) ; h = (1 - z) H + z c ; hidden dropout ; reset switch (gru4rec.py:474-479)
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(256) void k_gru_bwd_b(const DevModel* __restrict__ 
     if (m0 >= M) return;
     const GAS float* Wx = m.dense_p + m.offWx[l];
     const GAS float* dV = m.dV[l];
-    int* sRow = reinterpret_cast<int*>(smem + TileCfg<GT_BM, GT_BN, GT_BK, false, true>::SMEM_FLOATS);
+    int* sRow = reinterpret_cast<int*>(smem + TileCfg<GT_BM, GT_BN, BB_BK, false, true>::SMEM_FLOATS);
     if (threadIdx.x < GT_BM) sRow[threadIdx.x] = (l == 0 && m0 + threadIdx.x < M) ? m.occ_idx[m0 + threadIdx.x] : -1;
     __syncthreads();
     auto aload = [&](int kk, int r, int cc) -> float4 {
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(256) void k_gru_bwd_b(const DevModel* __restrict__ 
             dylo[(size_t)row * IN + n] = v;
         }
     };
-    gemm_tile<GT_BM, GT_BN, GT_BK, false, true>(m0, n0, D3, aload, bload, pre, epi, smem);
+    gemm_tile<GT_BM, GT_BN, BB_BK, false, true>(m0, n0, D3, aload, bload, pre, epi, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -689,6 +691,11 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevMod
     // descriptor fields used inside loops are snapshotted into registers: re-reading them through `mp` costs a
     // scalar-memory round trip per iteration (the compiler does not hoist them across the global stores)
     const float lr = m.lr, momc = m.mom, lmbd = m.lmbd;
+    const bool constrained = (m.embed_mode == G4R_EMBED_CONSTRAINED);
+    GAS float *tE = m.E, *tWy = m.Wy, *tvE = m.velE, *tvWy = m.velWy, *tBy = m.By, *taBy = m.accBy, *tvBy = m.velBy,
+              *taE = m.accE, *taWy = m.accWy;
+    const int wE = m.Ein, wY = m.Dtop;
+    const GAS int* g_occ = m.occ_idx;
     const GAS float *g_dSx = m.dSx, *g_dSy = m.dSy, *g_dAx = m.dAx, *g_dAy = m.dAy, *g_dSBy = m.dSBy, *g_dABy = m.dABy;
     if ((int)blockIdx.x == nblk_occ) {
         // ---- bookkeeping block: cost = sum_i L_i / batch_size (gru4rec.py:577), NaN flag (:626), advance state
@@ -711,14 +718,22 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevMod
     const long long t_start = m.dbgclk ? wall_clock64() : 0;
     G4R_TICK(m, 1, 0);
     const int Rpad = ((R + 255) & ~255) + 256;
-    for (int j = tid; j < Rpad; j += SP_WAVES * 64) sOcc[j] = j < R ? m.occ_idx[j] : -2;
+    for (int j0 = 0; j0 < Rpad; j0 += 4 * SP_WAVES * 64) {     // 4 independent loads in flight per thread
+        int v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = g_occ[min(j0 + q * SP_WAVES * 64 + tid, R - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + q * SP_WAVES * 64 + tid;
+            if (j < Rpad) sOcc[j] = j < R ? v[q] : -2;
+        }
+    }
     __syncthreads();
     G4R_TICK(m, 1, 1);
     const int k = blockIdx.x * SP_WAVES + wid;
     if (k >= R) return;
     const int item = sOcc[k];
     if (item < 0) return;
-    const bool constrained = (m.embed_mode == G4R_EMBED_CONSTRAINED);
     // occurrence range sharing a table with k: constrained -> all of X|Y|samples ; separate -> X alone, Y|samples alone
     const int lo = (constrained || k < B) ? 0 : B;
     const int hi = (constrained || k >= B) ? R : B;
@@ -736,10 +751,10 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevMod
     G4R_TICK(m, 1, 2);
     // ---- row state (pre-step values; every occurrence is scaled with the pre-step accumulator)
     const bool tableE = (k < B && !constrained);
-    GAS float* P = tableE ? m.E : m.Wy;
-    GAS float* A = tableE ? m.accE : m.accWy;
-    GAS float* V = tableE ? m.velE : m.velWy;
-    const int W = tableE ? m.Ein : m.Dtop;
+    GAS float* P = tableE ? tE : tWy;
+    GAS float* A = tableE ? taE : taWy;
+    GAS float* V = tableE ? tvE : tvWy;
+    const int W = tableE ? wE : wY;
     const int nc4 = W >> 2;
     const bool mom = momc > 0.f;
     const bool bias = (k >= B);
@@ -760,8 +775,8 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevMod
     // output bias By: occurrences among Y|samples only (gru4rec.py:486-489)
     float bp = 0.f, bpz = 0.f, baz = 0.f, bvz = 0.f, bal = 0.f, bvl = 0.f;
     if (bias) {
-        bp = m.By[item]; bpz = bp;
-        if (mom) { bvz = m.velBy[item]; bvl = bvz; }
+        bp = tBy[item]; bpz = bp;
+        if (mom) { bvz = tvBy[item]; bvl = bvz; }
     }
     constexpr int UB = (MAXCH == 1) ? 16 : 8;     // keeps the kernel at <= 128 VGPRs: every workgroup must be resident at once
     // apply the duplicates listed one-per-lane in myj[0..cnt), ascending occurrence order.  The gradient producers
@@ -870,16 +885,16 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevMod
         }
     }
     if (bias && lane == 0) {
-        m.By[item] = bp;
-        m.accBy[item] = bal;
-        if (mom) m.velBy[item] = bvl;
+        tBy[item] = bp;
+        taBy[item] = bal;
+        if (mom) tvBy[item] = bvl;
     }
     G4R_TICK(m, 1, 4);
     if (m.dbgclk && lane == 0) {
         const long long t_end = wall_clock64();
         const long long dur = t_end - t_start;
         GAS long long* tr = m.dbgclk + 64 + 8 * k;
-        tr[0] = t_start; tr[1] = t_own; tr[2] = t_col; tr[3] = t_app; tr[4] = t_end; tr[5] = total; tr[6] = 0; tr[7] = item;
+        tr[0] = t_start; tr[1] = t_own; tr[2] = t_col; tr[3] = t_app; tr[4] = t_end; tr[5] = total; tr[6] = c.t; tr[7] = item;
         (void)dur;
     }
 }

@@ -21,7 +21,7 @@ for rep in range(5):
           '| slowest owner wave: %.2f us with %d dups | owners %d, occurrences %d, max dups %d' % (
               (mx >> 20) / 100.0, mx & 0xFFFFF, raw[33], raw[34], raw[35]))
     tr = raw[64:].reshape(R, 8)
-    tr = tr[tr[:, 4] > 0]
+    tr = tr[(tr[:, 4] > 0) & (tr[:, 6] == 200 + rep)]
     t0 = tr[:, 0].min()
     d = (tr[:, 4] - tr[:, 0]) / 100.0
     o = np.argsort(-d)[:6]
