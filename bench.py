@@ -107,6 +107,8 @@ def create_model(cfg, support, rank, nranks, device, unique_id, use_graph=True, 
         rank=rank, nranks=nranks, use_graph=1 if use_graph else 0)
     if nranks > 1:
         m.comm_init(unique_id, nranks, rank)
+    elif os.environ.get('G4R_FORCE_STAGED'):      # diagnostic: the N > 1 data path with a one-rank communicator
+        m.comm_init(_native.comm_unique_id(), 1, 0)
     # reference initialisation (gru4rec.py:252-294): uniform(-s, s), s = sqrt(6 / (fan_in + fan_out)) per block
     rng = np.random.RandomState(42)
 
@@ -273,9 +275,11 @@ def main():
         out['dominant_kernel'] = dom[0]
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, plan, support)
-    if rank == 0:
-        print(json.dumps(out))
     m.close()
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

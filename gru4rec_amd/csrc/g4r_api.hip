@@ -42,6 +42,8 @@ struct g4r_model {
     DevModel dm;                 // host master copy of the device-resident model descriptor
     DevModel* d_dm = nullptr;    // what the kernels read (passed by pointer: 8-byte kernarg)
     hipStream_t stream = nullptr;
+    hipStream_t comm_stream = nullptr;           // all-reduce + dense Adagrad next to the sparse update (nranks > 1)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<void*> allocs;
     // plan
     int *d_in = nullptr, *d_out = nullptr, *d_M = nullptr, *d_cmaps = nullptr;
@@ -148,6 +150,9 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     g4r_model* m = new g4r_model();
     m->cfg = *cfg;
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return fail("stream create"); }
+    if (hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) { g4r_destroy(m); return fail("stream create"); }
     DevModel& d = m->dm;
     memset(&d, 0, sizeof(d));
     const int L = cfg->n_layers, B = cfg->batch_size;
@@ -177,7 +182,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         d.offBh[l] = off; off += 3 * d.D[l];
     }
     d.dense_count = off;
-    d.apply_dense_inplace = (cfg->nranks <= 1) ? 1 : 0;
+    // G4R_FORCE_STAGED=1: exercise the multi-rank data path (gradient staging -> RCCL -> k_dense_apply) on one GPU
+    d.apply_dense_inplace = (cfg->nranks <= 1 && !getenv("G4R_FORCE_STAGED")) ? 1 : 0;
     d.grad_scale = 1.0f / (float)std::max(cfg->nranks, 1);
     const size_t I = cfg->n_items;
 #define DA(p, n) if (dalloc(m, &(p), (n))) { g4r_destroy(m); return -1; }
@@ -203,6 +209,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     DA(d.dAx, (size_t)B * d.Ein); DA(d.dAy, (size_t)d.ldSc * d.Dtop); DA(d.dABy, d.ldSc);
     DA(d.lossrow, B);
     DA(d.occ_idx, d.R + 64); DA(d.col_item, d.ldSc);
+    DA(d.occ_fl, (size_t)(cfg->embed_mode == G4R_EMBED_SEPARATE ? 2 : 1) * I * 4);
     DA(d.st, 1);
     // scoring backward geometry: role A tiles (n x d, one spare d column for dSBy), role B tiles (b x d x k-chunk)
     {
@@ -215,7 +222,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         m->nrtB = cdiv(B, GT_BM);
         m->nblkB = d.ksplit * m->nrtB * m->ndtB;
         m->nblk_occ = cdiv(d.R, SP_WAVES);
-        m->smem_sparse = (size_t)(((d.R + 255) & ~255) + 256) * sizeof(int);
+        m->smem_sparse = (size_t)(((d.R + 255) & ~255) + 256) * sizeof(int) + (2 + 64) * SP_WAVES * sizeof(int) +
+                         (size_t)SP_WAVES * (std::max(d.Dtop, d.Ein) + 4) * sizeof(float);
     }
     if (ns > 0) DA(m->d_ST, (size_t)gl * ns);
     d.ST = m->d_ST;
@@ -250,19 +258,20 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     // LDS opt-in
     m->smem_score = ((size_t)(SC_BM + 32) * (SC_KC + 2) + 32) * sizeof(float);
     m->smem_loss = (size_t)(d.ldSc + 8) * sizeof(float);
-    const int big = 160 * 1024;
-    (void)hipFuncSetAttribute((const void*)k_gru_p1, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)k_gru_p2, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)k_score_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)k_score_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)k_gru_bwd_a, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)k_gru_bwd_b, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)k_dense_grad, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)k_sparse_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)k_sparse_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)k_score_all<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)k_loss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    const int big = 156 * 1024;      // leaves room for the few bytes of static LDS some kernels use (__syncthreads_or)
+    HIPCHK(hipFuncSetAttribute((const void*)k_gru_p1, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gru_p2, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_a, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_b, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_dense_grad, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_score_all<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel"); }
+    if (getenv("G4R_DBG_MODE")) d.dbg_mode = atoi(getenv("G4R_DBG_MODE"));
     if (getenv("G4R_CLK")) { if (dalloc(m, &d.dbgclk, 64 + 8 * (size_t)d.R)) { g4r_destroy(m); return -1; } }
     if (dalloc(m, &m->d_dm, 1) || sync_dm(m)) { g4r_destroy(m); return -1; }
     *out = m;
@@ -273,10 +282,14 @@ void g4r_destroy(g4r_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->cfg.device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->comm_stream) (void)hipStreamSynchronize(m->comm_stream);
     if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
     if (m->comm_ready) (void)ncclCommDestroy(m->comm);
     for (auto e : m->evs) (void)hipEventDestroy(e);
     for (void* p : m->allocs) (void)hipFree(p);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    if (m->comm_stream) (void)hipStreamDestroy(m->comm_stream);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -541,19 +554,25 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
     begin(KN_DENSE);
     hipLaunchKernelGGL(k_dense_grad, dim3(m->ntiles), dim3(256), SMEM_TN + (size_t)B * sizeof(int), s, dmp, stp, (const DenseTile*)m->d_tiles);
     end();
+    // multi-rank: the dense-gradient all-reduce and the dense Adagrad run on their own stream next to the sparse
+    // embedding update (which touches item rows only), and join before the next step reads the GRU weights
+    const bool overlap = !d.apply_dense_inplace && !recs && !trace;
     if (!d.apply_dense_inplace) {
         if (!m->comm_ready) return fail("nranks > 1 but g4r_comm_init was not called");
-        begin(KN_ALLREDUCE);
-        NCCLCHK(ncclAllReduce(d.dense_g, d.dense_g, d.dense_count, ncclFloat, ncclSum, m->comm, s));
-        end();
-        begin(KN_DENSE_APPLY);
-        hipLaunchKernelGGL(k_dense_apply, dim3(cdiv(d.dense_count, 256)), dim3(256), 0, s, (const DevModel*)m->d_dm);
-        end();
+        hipStream_t cs = overlap ? m->comm_stream : s;
+        if (overlap) { HIPCHK(hipEventRecord(m->ev_fork, s)); HIPCHK(hipStreamWaitEvent(cs, m->ev_fork, 0)); }
+        if (!overlap) begin(KN_ALLREDUCE);
+        NCCLCHK(ncclAllReduce(d.dense_g, d.dense_g, d.dense_count, ncclFloat, ncclSum, m->comm, cs));
+        if (!overlap) { end(); begin(KN_DENSE_APPLY); }
+        hipLaunchKernelGGL(k_dense_apply, dim3(cdiv(d.dense_count, 256)), dim3(256), 0, cs, (const DevModel*)m->d_dm);
+        if (!overlap) end();
+        if (overlap) HIPCHK(hipEventRecord(m->ev_join, cs));
     }
     begin(KN_SPARSE);
     if (std::max(d.Dtop, d.Ein) <= 256) hipLaunchKernelGGL(k_sparse_update<1>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
     else hipLaunchKernelGGL(k_sparse_update<2>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
     end();
+    if (overlap) HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0));
 #undef begin
     HIPCHK(hipGetLastError());
     return 0;
@@ -822,6 +841,7 @@ int g4r_comm_init(g4r_model* m, const char* id128, int32_t nranks, int32_t rank)
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     NCCLCHK(ncclCommInitRank(&m->comm, nranks, id, rank));
+    fflush(stdout);      // RCCL's version banner must not surface after the caller's own output at exit
     m->comm_ready = true;
     return 0;
 }
@@ -832,7 +852,7 @@ static int allreduce_avg(g4r_model* m, float* p, long long n) {
 }
 int g4r_comm_min_i64(g4r_model* m, int64_t* value) {
     if (!m || !value) return fail("null argument");
-    if (m->cfg.nranks <= 1) return 0;
+    if (m->cfg.nranks <= 1 && !m->comm_ready) return 0;
     if (!m->comm_ready) return fail("g4r_comm_init first");
     HIPCHK(hipSetDevice(m->cfg.device));
     long long* d = nullptr;
@@ -847,7 +867,7 @@ int g4r_comm_min_i64(g4r_model* m, int64_t* value) {
 }
 int g4r_comm_sync_sparse(g4r_model* m) {
     if (!m) return fail("null model");
-    if (m->cfg.nranks <= 1) return 0;
+    if (m->cfg.nranks <= 1 && !m->comm_ready) return 0;
     if (!m->comm_ready) return fail("g4r_comm_init first");
     HIPCHK(hipSetDevice(m->cfg.device));
     DevModel& d = m->dm;

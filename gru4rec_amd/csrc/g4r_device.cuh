@@ -95,6 +95,10 @@ struct DevModel {
     int ksplit, kch;
     GP(int) occ_idx;   // [R] item of each gathered-row occurrence (X | Y | samples), -1 = inactive
     GP(int) col_item;  // [ldSc] item of each score column, -1 = inactive
+    // [tables][n_items][4]: (last occurrence + 1, R - first occurrence, count, 0) of every item touched this step, written
+    // with atomics by the kernels that publish occ_idx and zeroed again by the row's owner in k_sparse_update
+    // (table 0: Wy / By rows, table 1: separate input embedding E)
+    GP(int) occ_fl;
     // ---- plan + samples
     GP(const int) in_idx; GP(const int) out_idx; GP(const int) Mplan;
     GP(const unsigned char) reset;
@@ -102,6 +106,7 @@ struct DevModel {
     int gl;
     GP(const float) lq_tgt; GP(const float) lq_smp;
     GP(StepState) st;
+    int dbg_mode, dbg_pad;  // G4R_DBG_MODE experiments (0 in production)
     GP(long long) dbgclk;   // optional [kernel][16] phase timestamps (100 MHz wall clock), block 0 only
 };
 

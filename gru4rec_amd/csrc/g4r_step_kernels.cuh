@@ -84,7 +84,15 @@ __global__ __launch_bounds__(256) void k_gru_p1(const DevModel* __restrict__ mp,
         const int row = m0 + tid;
         const int item = (l == 0 && row < M) ? gidx[row] : -1;
         sRow[tid] = item;
-        if (train && l == 0 && blockIdx.x == 0 && row < m.B) m.occ_idx[row] = item;
+        if (train && l == 0 && blockIdx.x == 0 && row < m.B) {
+            m.occ_idx[row] = item;
+            if (item >= 0) {      // first / last occurrence of the item in this step's gathered-row list (k_sparse_update)
+                int* fl = (int*)m.occ_fl + 4 * ((m.embed_mode == G4R_EMBED_CONSTRAINED ? 0 : (size_t)m.n_items) + item);
+                atomicMax(fl, row + 1);
+                atomicMax(fl + 1, m.R - row);
+                atomicAdd(fl + 2, 1);
+            }
+        }
     }
     if (m0 >= M) return;
     __syncthreads();
@@ -214,7 +222,15 @@ __global__ __launch_bounds__(256) void k_score_fwd(const DevModel* __restrict__ 
         sItem[tid] = item;
         if (blockIdx.y == 0 && n < m.ldSc) {
             m.col_item[n] = item;
-            if (n < N) m.occ_idx[B + n] = item;
+            if (n < N) {
+                m.occ_idx[B + n] = item;
+                if (item >= 0) {
+                    int* fl = (int*)m.occ_fl + 4 * (size_t)item;
+                    atomicMax(fl, B + n + 1);
+                    atomicMax(fl + 1, m.R - (B + n));
+                    atomicAdd(fl + 2, 1);
+                }
+            }
         }
     }
     if (m0 >= M) return;
@@ -666,25 +682,29 @@ __global__ __launch_bounds__(256) void k_dense_apply(const DevModel* __restrict_
 // Sparse Adagrad(+momentum) on the gathered rows, gru4rec.py:335-340,407-431, with the reference's
 // duplicate-index semantics made deterministic:
 //   - every occurrence is scaled with the PRE-step accumulator: g~ = g / sqrt(acc_old + g^2 + eps)
-//   - parameter increments of duplicates accumulate, in occurrence order (inc_subtensor)
+//     (done by the gradient producers: dS* hold the scaled steps, dA* hold acc_old + g^2)
+//   - parameter increments of duplicates accumulate (inc_subtensor)
 //   - accumulator / velocity take the value of the LAST occurrence (set_subtensor, NumPy order)
-// One wave per occurrence k of (X | Y | samples).  The wave of the last occurrence of an item owns
-// the row: it scans the occurrence list for its duplicates (ballot over 64 entries at a time) and
-// applies them in ascending order.  No atomics, no scratch state, bit-reproducible.
+// so for an item with n occurrences, S = sum of its step rows and s_k = the step row of its last occurrence k:
+//   no momentum:  P = P0 - (S + n*reg)                      reg = lr*lmbd*P0
+//   momentum:     P = P0 + n*mom*V0 - (S + n*reg) ,  V = mom*V0 - (s_k + reg)
+//   A = dA[k]
+// One wave per occurrence k of (X | Y | samples); the wave of an item's LAST occurrence owns the row, so the
+// row state, s_k and dA[k] can be requested before anything is known about duplicates.  The occurrence list is
+// staged in LDS once per workgroup and scanned with ballots.  Up to SP_UB earlier occurrences are summed by the
+// owner in one batch of loads (one round trip); hotter items (popularity-sampled negatives repeat the head of
+// the catalogue dozens of times per step) are summed by all SP_WAVES waves of the workgroup together, wave w taking
+// every SP_WAVES-th occurrence, partial sums combined through LDS in wave order.  No atomics, bit-reproducible.
 // The extra last block folds the per-row losses into loss_steps[t] and advances the step state.
 #define SP_WAVES 8   // occurrences (waves) per workgroup
+#define SP_UB 8      // float4 step-row chunks one lane fetches together; items with more earlier occurrences are "hot"
 
-// MAXCH = float4 chunks per lane (1: row width <= 256, 2: <= 512).  One wave per occurrence k of
-// (X | Y | samples); the wave of an item's LAST occurrence owns the row and applies all of the item's
-// occurrences in ascending order (semantics: comment block above).  The occurrence list is
-// staged in LDS once per workgroup; the owner keeps its duplicate list in registers (entry i in lane i) and
-// fetches the gradient rows of up to UB duplicates together, so a hot item costs cnt/UB memory round trips
-// instead of cnt.  The extra last block folds the per-row losses into loss_steps[t] and advances the step state.
+// MAXCH = float4 chunks per lane (1: row width <= 256, 2: <= 512).
 template <int MAXCH>
 __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevModel* __restrict__ mp, StepState* st, int nblk_occ) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
-    int* sOcc = reinterpret_cast<int*>(smem);     // occurrence list, padded with -2 to a multiple of 256 (+256)
+    constexpr int UB = SP_UB / MAXCH;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const StepCtx c = load_ctx(st);
     const int B = m.B, R = m.R;
@@ -715,41 +735,24 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevMod
         }
         return;
     }
+    if (m.dbg_mode == 1) return;
     const long long t_start = m.dbgclk ? wall_clock64() : 0;
-    G4R_TICK(m, 1, 0);
+    // LDS: occurrence list padded with -2 to a multiple of 256 (+256) | hot-item slots | per-wave match lists |
+    // per-wave partial sums
     const int Rpad = ((R + 255) & ~255) + 256;
-    for (int j0 = 0; j0 < Rpad; j0 += 4 * SP_WAVES * 64) {     // 4 independent loads in flight per thread
-        int v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = g_occ[min(j0 + q * SP_WAVES * 64 + tid, R - 1)];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = j0 + q * SP_WAVES * 64 + tid;
-            if (j < Rpad) sOcc[j] = j < R ? v[q] : -2;
-        }
-    }
-    __syncthreads();
-    G4R_TICK(m, 1, 1);
+    const int PW = max(wE, wY) + 4;               // partial row: W floats + (bias partial, count, count among Y|samples, pad)
+    int* sOcc = reinterpret_cast<int*>(smem);
+    int* sHot = sOcc + Rpad;                      // [SP_WAVES] item, [SP_WAVES] first occurrence
+    int* sList = sHot + 2 * SP_WAVES;             // [SP_WAVES][64]
+    float* sPart = reinterpret_cast<float*>(sList + 64 * SP_WAVES);   // [SP_WAVES][PW]
+    int* myList = sList + 64 * wid;
+    GAS int* g_fl = m.occ_fl;
+    const int nI = m.n_items;
     const int k = blockIdx.x * SP_WAVES + wid;
-    if (k >= R) return;
-    const int item = sOcc[k];
-    if (item < 0) return;
+    int item = g_occ[min(k, R - 1)];
+    if (k >= R) item = -1;
     // occurrence range sharing a table with k: constrained -> all of X|Y|samples ; separate -> X alone, Y|samples alone
     const int lo = (constrained || k < B) ? 0 : B;
-    const int hi = (constrained || k >= B) ? R : B;
-    // ---- is there a later occurrence of the same item?  then that wave owns the row
-    for (int base = (k + 1) & ~255; base < hi; base += 256) {
-        int v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = sOcc[base + 64 * e + lane];
-        bool later = false;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const int j = base + 64 * e + lane; later |= (j > k && j < hi && v[e] == item); }
-        if (__ballot(later)) return;
-    }
-    const long long t_own = m.dbgclk ? wall_clock64() : 0;
-    G4R_TICK(m, 1, 2);
-    // ---- row state (pre-step values; every occurrence is scaled with the pre-step accumulator)
     const bool tableE = (k < B && !constrained);
     GAS float* P = tableE ? tE : tWy;
     GAS float* A = tableE ? taE : taWy;
@@ -758,144 +761,207 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevMod
     const int nc4 = W >> 2;
     const bool mom = momc > 0.f;
     const bool bias = (k >= B);
-    float pc[MAXCH][4], pz[MAXCH][4], az[MAXCH][4], vz[MAXCH][4], al[MAXCH][4], vl[MAXCH][4];
+    // ---- the item's (last, first, count) entry (published with atomics by k_gru_p1 / k_score_fwd), the row state and
+    // the last occurrence's step / accumulator rows: one round trip (unconditional loads with clamped indices:
+    // what a non-owner fetches is simply not used)
+    const int item_c = max(item, 0), k_c = min(k, R - 1);
+    GAS int* flp = g_fl + 4 * ((tableE ? (size_t)nI : 0) + item_c);
+    const int4 fl = ldi4(flp);
+    const GAS float* srow_k = (k_c < B) ? g_dSx + (size_t)k_c * W : g_dSy + (size_t)(k_c - B) * W;
+    const GAS float* arow_k = (k_c < B) ? g_dAx + (size_t)k_c * W : g_dAy + (size_t)(k_c - B) * W;
+    float4 pz[MAXCH], vz[MAXCH], sk[MAXCH], ak[MAXCH];
 #pragma unroll
     for (int q = 0; q < MAXCH; ++q) {
-        const int c4 = lane + 64 * q;
-        const size_t o = (size_t)item * W + 4 * min(c4, nc4 - 1);
-        const float4 p0 = ld4(P + o);      // the accumulator row itself is not needed: dA* carries acc_pre + g^2
-        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), v0 = a0;
-        if (mom) v0 = ld4(V + o);
-        pz[q][0] = p0.x; pz[q][1] = p0.y; pz[q][2] = p0.z; pz[q][3] = p0.w;
-        az[q][0] = a0.x; az[q][1] = a0.y; az[q][2] = a0.z; az[q][3] = a0.w;
-        vz[q][0] = v0.x; vz[q][1] = v0.y; vz[q][2] = v0.z; vz[q][3] = v0.w;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { pc[q][e] = pz[q][e]; al[q][e] = az[q][e]; vl[q][e] = vz[q][e]; }
+        const int cc = 4 * min(lane + 64 * q, nc4 - 1);
+        pz[q] = ld4(P + (size_t)item_c * W + cc);
+        sk[q] = ld4(srow_k + cc);
+        ak[q] = ld4(arow_k + cc);
+        vz[q] = mom ? ld4(V + (size_t)item_c * W + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // output bias By: occurrences among Y|samples only (gru4rec.py:486-489)
-    float bp = 0.f, bpz = 0.f, baz = 0.f, bvz = 0.f, bal = 0.f, bvl = 0.f;
+    float bpz = 0.f, bvz = 0.f, bsk = 0.f, bak = 0.f;
     if (bias) {
-        bp = tBy[item]; bpz = bp;
-        if (mom) { bvz = tvBy[item]; bvl = bvz; }
+        bpz = tBy[item_c]; bsk = g_dSBy[k_c - B]; bak = g_dABy[k_c - B];
+        if (mom) bvz = tvBy[item_c];
     }
-    constexpr int UB = (MAXCH == 1) ? 16 : 8;     // keeps the kernel at <= 128 VGPRs: every workgroup must be resident at once
-    // apply the duplicates listed one-per-lane in myj[0..cnt), ascending occurrence order.  The gradient producers
-    // already turned every occurrence's gradient row into its scaled step (dS*) and left acc_pre + g^2 in dA*, so
-    // what remains here is the ordered accumulation into the parameter row and "last occurrence wins" for the state.
-    auto apply = [&](int myj, int cnt) {
-        const int jb = (lane < cnt && myj >= B) ? myj : -1;
-        float dlt_b = 0.f, an_b = 0.f;     // lane i: bias step of duplicate i
-        if (bias && jb >= 0) { dlt_b = g_dSBy[jb - B]; an_b = g_dABy[jb - B]; }
-        const int jlast = __builtin_amdgcn_readlane(myj, (cnt - 1) & 63);
-        // one batch = the step rows of up to UB duplicates fetched together (one memory round trip), then added in
-        // occurrence order; all branches on the duplicate count are wave-uniform, so a singleton costs one row
-        for (int i0 = 0; i0 < cnt; i0 += UB) {
-            float4 g[UB][MAXCH];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                if (i0 + u < cnt) {       // wave-uniform; the loads themselves are unconditional (clamped chunk index)
-                    const int jj = __builtin_amdgcn_readlane(myj, (i0 + u) & 63);
-                    const GAS float* srow = (jj < B) ? g_dSx + (size_t)jj * W : g_dSy + (size_t)(jj - B) * W;
-#pragma unroll
-                    for (int q = 0; q < MAXCH; ++q) g[u][q] = ld4(srow + 4 * min(lane + 64 * q, nc4 - 1));
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                if (i0 + u < cnt) {
-#pragma unroll
-                    for (int q = 0; q < MAXCH; ++q) {
-                        const float sv[4] = {g[u][q].x, g[u][q].y, g[u][q].z, g[u][q].w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float delta = (lmbd > 0.f) ? sv[e] + lr * lmbd * pz[q][e] : sv[e];
-                            if (mom) {
-                                const float v2 = momc * vz[q][e] - delta;
-                                vl[q][e] = v2;
-                                pc[q][e] = pc[q][e] + v2;
-                            } else {
-                                pc[q][e] = pc[q][e] - delta;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        // accumulator: value left by the last occurrence of this batch of the list
-#pragma unroll
-        for (int q = 0; q < MAXCH; ++q) {
-            const int c4 = lane + 64 * q;
-            {
-                const GAS float* arow = (jlast < B) ? g_dAx + (size_t)jlast * W : g_dAy + (size_t)(jlast - B) * W;
-                const float4 a4 = ld4(arow + 4 * min(c4, nc4 - 1));
-                al[q][0] = a4.x; al[q][1] = a4.y; al[q][2] = a4.z; al[q][3] = a4.w;
-            }
-        }
-        if (bias) {
-            for (int i = 0; i < cnt; ++i) {          // ordered chain over scalar (SGPR) broadcasts
-                const int jj = __builtin_amdgcn_readlane(jb, i);
-                if (jj < 0) continue;
-                float delta = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dlt_b), i));
-                if (lmbd > 0.f) delta += lr * lmbd * bpz;
-                bal = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, an_b), i));
-                if (mom) { const float v2 = momc * bvz - delta; bvl = v2; bp = bp + v2; }
-                else bp = bp - delta;
-            }
-        }
-    };
-    // ---- collect this item's occurrences in [lo, k] (ascending), 64 per pass (one list entry per lane), and apply
-    // them.  The scan loop is kept tiny (the big apply body sits outside of it: instruction-cache friendly); items
-    // with more than 64 occurrences in one step simply take another pass.
-    int total = 0;
-    for (int pass = 0;; ++pass) {
-        int myj = -1, idx = 0;
-        const int lo_i = 64 * pass;
-        for (int base = lo & ~255; base <= k; base += 256) {
+    // the wave of the item's last occurrence owns the row (and clears the item's entry for the next step)
+    const bool owner = item >= 0 && fl.x == k + 1;
+    const int first_j = max(lo, R - fl.y);
+    const bool dup = owner && fl.z > 1;
+    const bool hot = owner && fl.z - 1 > UB;
+    if (owner && lane == 0) *(GAS int4*)flp = make_int4(0, 0, 0, 0);
+    const long long t_own = m.dbgclk ? wall_clock64() : 0;
+
+    // scan of sOcc[a, b) for `it`: match number i (ascending) goes to myList[i - 64 * pass]; returns the
+    // number of matches, nb = those among Y|samples
+    auto scan = [&](int it, int a, int b, int pass, int& nb) {
+        int idx = 0;
+        nb = 0;
+        for (int base = a & ~255; base < b; base += 256) {
             int v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = sOcc[base + 64 * e + lane];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                if (__ballot(v[e] == it) == 0) continue;       // the common case costs a compare and a scalar branch
                 const int j = base + 64 * e + lane;
-                unsigned long long mask = __ballot(j >= lo && j <= k && v[e] == item);
-                while (mask) {
-                    const int bit = __ffsll((unsigned long long)mask) - 1;
-                    mask &= mask - 1;
-                    if (lane == idx - lo_i) myj = base + 64 * e + bit;
-                    ++idx;
-                }
+                const bool hit = j >= a && j < b && v[e] == it;
+                const unsigned long long mask = __ballot(hit);
+                const int ord = idx - 64 * pass +
+                                (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (hit && ord >= 0 && ord < 64) myList[ord] = j;
+                idx += __popcll(mask);
+                nb += __popcll(__ballot(hit && j >= B));
             }
         }
-        total = idx;
-        const int n_here = min(idx - lo_i, 64);
-        if (n_here > 0) apply(myj, n_here);
-        if (idx <= lo_i + 64) break;
-    }
-    const long long t_col = m.dbgclk ? wall_clock64() : 0;
-    G4R_TICK(m, 1, 3);
-    const long long t_app = t_col;
+        return idx;
+    };
+
+    // S = sum of the step rows of the item's occurrences before k, Sb = the same for the output bias
+    float4 S[MAXCH];
+    float Sb = 0.f;
+    int n_e = 0, nb_e = 0;
 #pragma unroll
-    for (int q = 0; q < MAXCH; ++q) {
-        const int c4 = lane + 64 * q;
-        if (c4 < nc4) {
-            const size_t o = (size_t)item * W + 4 * c4;
-            st4(P + o, make_float4(pc[q][0], pc[q][1], pc[q][2], pc[q][3]));
-            st4(A + o, make_float4(al[q][0], al[q][1], al[q][2], al[q][3]));
-            if (mom) st4(V + o, make_float4(vl[q][0], vl[q][1], vl[q][2], vl[q][3]));
+    for (int q = 0; q < MAXCH; ++q) S[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane == 0) { sHot[wid] = hot ? item : -1; sHot[SP_WAVES + wid] = first_j; }
+    const bool any_dup = __syncthreads_or(dup ? 1 : 0) != 0;
+    long long t_col = t_own, t_app = t_own;
+    if (any_dup) {
+        // ---- some wave of this workgroup owns an item with earlier occurrences: stage the occurrence list
+        for (int j0 = 0; j0 < Rpad; j0 += 4 * SP_WAVES * 64) {     // 4 independent loads in flight per thread
+            int v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = g_occ[min(j0 + q * SP_WAVES * 64 + tid, R - 1)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = j0 + q * SP_WAVES * 64 + tid;
+                if (j < Rpad) sOcc[j] = j < R ? v[q] : -2;
+            }
+        }
+        __syncthreads();
+        if (m.dbgclk) t_col = wall_clock64();
+        // one code path for both kinds of work (rarely executed code is instruction-cache cold, so it is kept small):
+        //   h = -1 : a wave sums the (<= UB) earlier occurrences of its own item, range [first, k)
+        //   h >= 0 : hot item of wave h; every wave sums the occurrences found in its slice of [first, k_h), the
+        //            partial sums are combined through LDS in wave (= occurrence) order
+        for (int h = -1; h < SP_WAVES; ++h) {
+            int it = item, a = first_j, b = k, tW = W, tnc4 = nc4;
+            bool tb = bias, active = dup && !hot;
+            if (h >= 0) {
+                it = sHot[h];
+                if (it < 0) continue;             // workgroup-uniform
+                const int hk = blockIdx.x * SP_WAVES + h, hlo = sHot[SP_WAVES + h];
+                const int slice = (((hk - hlo + SP_WAVES - 1) / SP_WAVES) + 63) & ~63;
+                a = hlo + wid * slice; b = min(hk, a + slice);
+                tW = (hk < B && !constrained) ? wE : wY; tnc4 = tW >> 2;
+                tb = hk >= B; active = true;
+            }
+            float4 T[MAXCH];
+            float Tb = 0.f;
+            int n_w = 0, nb_w = 0;
+#pragma unroll
+            for (int q = 0; q < MAXCH; ++q) T[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (active) {
+                for (int pass = 0;; ++pass) {
+                    n_w = scan(it, a, b, pass, nb_w);
+                    const int cnt = min(n_w - 64 * pass, 64);
+                    const int myj = lane < cnt ? myList[lane] : -1;
+                    const float bd = (tb && myj >= B) ? g_dSBy[max(myj - B, 0)] : 0.f;
+                    for (int i0 = 0; i0 < cnt; i0 += UB) {        // UB step rows per round trip
+                        float4 g[UB][MAXCH];
+                        float w[UB];
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+                            // branch-free: slots past the end re-read the last row with weight 0
+                            w[u] = (i0 + u < cnt) ? 1.f : 0.f;
+                            const int jj = __builtin_amdgcn_readlane(myj, min(i0 + u, cnt - 1) & 63);
+                            const GAS float* srow = (jj < B) ? g_dSx + (size_t)jj * tW : g_dSy + (size_t)(jj - B) * tW;
+#pragma unroll
+                            for (int q = 0; q < MAXCH; ++q) g[u][q] = ld4(srow + 4 * min(lane + 64 * q, tnc4 - 1));
+                        }
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+#pragma unroll
+                            for (int q = 0; q < MAXCH; ++q) {
+                                T[q].x = fmaf(w[u], g[u][q].x, T[q].x); T[q].y = fmaf(w[u], g[u][q].y, T[q].y);
+                                T[q].z = fmaf(w[u], g[u][q].z, T[q].z); T[q].w = fmaf(w[u], g[u][q].w, T[q].w);
+                            }
+                        }
+                    }
+                    if (tb) Tb += wave_sum(bd);
+                    if (n_w <= 64 * (pass + 1)) break;
+                }
+            }
+            if (h < 0) {
+                if (active) {
+#pragma unroll
+                    for (int q = 0; q < MAXCH; ++q) S[q] = T[q];
+                    Sb = Tb; n_e = n_w; nb_e = nb_w;
+                }
+                if (m.dbgclk) t_app = wall_clock64();
+                continue;
+            }
+            float* part = sPart + wid * PW;
+#pragma unroll
+            for (int q = 0; q < MAXCH; ++q) {
+                const int c4 = lane + 64 * q;
+                if (c4 < tnc4) *reinterpret_cast<float4*>(part + 4 * c4) = T[q];
+            }
+            if (lane == 0) { part[PW - 4] = Tb; part[PW - 3] = __int_as_float(n_w); part[PW - 2] = __int_as_float(nb_w); }
+            __syncthreads();
+            if (wid == h) {
+                for (int w = 0; w < SP_WAVES; ++w) {
+#pragma unroll
+                    for (int q = 0; q < MAXCH; ++q) {
+                        const float4 x = *reinterpret_cast<const float4*>(sPart + w * PW + 4 * min(lane + 64 * q, nc4 - 1));
+                        S[q].x += x.x; S[q].y += x.y; S[q].z += x.z; S[q].w += x.w;
+                    }
+                    Sb += sPart[w * PW + PW - 4];
+                    n_e += __float_as_int(sPart[w * PW + PW - 3]);
+                    nb_e += __float_as_int(sPart[w * PW + PW - 2]);
+                }
+            }
+            __syncthreads();
         }
     }
-    if (bias && lane == 0) {
-        tBy[item] = bp;
-        taBy[item] = bal;
-        if (mom) tvBy[item] = bvl;
+    // ---- final row values from S + s_k (sum over all occurrences) and the last occurrence's rows, and the stores
+    if (owner) {
+        const int n = n_e + 1, nb = nb_e + (bias ? 1 : 0);
+        const float fn = (float)n;
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) {
+            const int c4 = lane + 64 * q;
+            const float p0[4] = {pz[q].x, pz[q].y, pz[q].z, pz[q].w}, v0[4] = {vz[q].x, vz[q].y, vz[q].z, vz[q].w};
+            const float sl[4] = {sk[q].x, sk[q].y, sk[q].z, sk[q].w};
+            const float ss[4] = {S[q].x + sk[q].x, S[q].y + sk[q].y, S[q].z + sk[q].z, S[q].w + sk[q].w};
+            float pn[4], vn[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float reg = (lmbd > 0.f) ? lr * lmbd * p0[e] : 0.f;
+                const float tot = (lmbd > 0.f) ? ss[e] + fn * reg : ss[e];
+                if (mom) { vn[e] = momc * v0[e] - (sl[e] + reg); pn[e] = p0[e] + (fn * (momc * v0[e]) - tot); }
+                else { vn[e] = 0.f; pn[e] = p0[e] - tot; }
+            }
+            if (c4 < nc4) {
+                const size_t o = (size_t)item * W + 4 * c4;
+                st4(P + o, make_float4(pn[0], pn[1], pn[2], pn[3]));
+                st4(A + o, ak[q]);
+                if (mom) st4(V + o, make_float4(vn[0], vn[1], vn[2], vn[3]));
+            }
+        }
+        if (bias && lane == 0) {     // output bias By: occurrences among Y|samples only (gru4rec.py:486-489)
+            const float fb = (float)nb;
+            const float reg = (lmbd > 0.f) ? lr * lmbd * bpz : 0.f;
+            const float sb = Sb + bsk;
+            const float tot = (lmbd > 0.f) ? sb + fb * reg : sb;
+            if (mom) { tBy[item] = bpz + (fb * (momc * bvz) - tot); tvBy[item] = momc * bvz - (bsk + reg); }
+            else tBy[item] = bpz - tot;
+            taBy[item] = bak;
+        }
     }
-    G4R_TICK(m, 1, 4);
-    if (m.dbgclk && lane == 0) {
+    if (m.dbgclk && lane == 0 && k < R) {
         const long long t_end = wall_clock64();
-        const long long dur = t_end - t_start;
         GAS long long* tr = m.dbgclk + 64 + 8 * k;
-        tr[0] = t_start; tr[1] = t_own; tr[2] = t_col; tr[3] = t_app; tr[4] = t_end; tr[5] = total; tr[6] = c.t; tr[7] = item;
-        (void)dur;
+        tr[0] = t_start; tr[1] = t_own; tr[2] = t_col; tr[3] = t_app; tr[4] = t_end; tr[5] = owner ? fl.z : 0; tr[6] = c.t; tr[7] = item;
     }
 }
 

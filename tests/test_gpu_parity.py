@@ -219,6 +219,31 @@ def test_graph_replay_is_bit_identical_to_eager():
         np.testing.assert_array_equal(a, b)
 
 
+def test_multirank_data_path_on_one_gpu(monkeypatch):
+    """The N > 1 step (dense gradients staged -> RCCL all-reduce on the side stream -> k_dense_apply, next to the
+    sparse update) with a one-rank communicator must reproduce the fused single-GPU step."""
+    kw = CASES['bprmax_mom_drop']
+    I, B, ns, T = 80, 12, 24, 60
+    plan = random_plan(I, B, T, seed=17)
+    outs = []
+    for staged in (0, 1):
+        if staged:
+            monkeypatch.setenv('G4R_FORCE_STAGED', '1')
+        _, m = make_pair(I, B, ns, store_rows=200, use_graph=0, **dict(kw))
+        if staged:
+            m.comm_init(_native.comm_unique_id(), 1, 0)
+            assert m.comm_min(T) == T
+        m.set_plan(plan)
+        m.train_steps(0, T)
+        if staged:
+            m.comm_sync_sparse()
+        outs.append((m.get_losses(0, T), m.get_param('Wy', (I, 16)), m.get_param('Wx', (16, 48), 0),
+                     m.get_param('Bh', (48,), 0), m.get_param('acc_Wh', (16, 16), 0)))
+        m.close()
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
 def test_epoch_with_real_schedule_and_compaction():
     """Sessions -> C++ plan -> device epoch (with H compaction at the tail) vs the oracle driven by the
     literal restatement of the reference loop."""
