@@ -257,7 +257,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
 #undef DA
     // LDS opt-in
     m->smem_score = ((size_t)(SC_BM + 32) * (SC_KC + 2) + 32) * sizeof(float);
-    m->smem_loss = (size_t)(d.ldSc + 8) * sizeof(float);
+    m->smem_loss = (size_t)(2 * d.ldSc + 18 * LOSS_NW) * sizeof(float);
     const int big = 156 * 1024;      // leaves room for the few bytes of static LDS some kernels use (__syncthreads_or)
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_p1, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_p2, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -535,7 +535,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
     hipLaunchKernelGGL(k_score_fwd, dim3(cdiv(d.ldSc, GT_BN), cdiv(B, SF_BM)), dim3(256), SMEM_SF, s, dmp, stp);
     end();
     begin(KN_LOSS);
-    hipLaunchKernelGGL(k_loss_rows, dim3(B), dim3(256), m->smem_loss, s, dmp, stp);
+    hipLaunchKernelGGL(k_loss_rows, dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
     end();
     begin(KN_SCORE_BWD);
     hipLaunchKernelGGL(k_score_bwd, dim3(m->nblkA + m->nblkB), dim3(256), std::max(SMEM_TN, SMEM_NN) + GT_BK * sizeof(int), s, dmp, stp, m->nblkA, m->ndtA, m->ndtB, m->nrtB);

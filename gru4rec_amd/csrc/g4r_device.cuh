@@ -118,15 +118,29 @@ struct DevModel {
     } while (0)
 
 // ---------------------------------------------------------------------------------------------
+// Wave-wide reductions with DPP row operations (no LDS round trips): xor-1 / xor-2 within quads, then the mirrored
+// half row and the mirrored row leave every lane with the sum of its 16-lane row; the four row sums are combined
+// through scalar registers.  All 64 lanes must be active.  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);      // row_half_mirror
+    v += dpp_mov<0x140>(v);      // row_mirror
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
 
 // block-wide reductions for a 256-thread (4-wave) block; `red` is 8 floats of LDS scratch

@@ -264,12 +264,35 @@ __global__ __launch_bounds__(256) void k_score_fwd(const DevModel* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Per-row final activation, loss and d cost / d s, in place in Sc.  One 256-thread workgroup per
-// batch row; the row (N <= ~40K floats) is staged in LDS; row statistics via wave64 shuffles.
+// Per-row final activation, loss and d cost / d s, in place in Sc.  One 512-thread workgroup per batch row; the row's
+// yhat and softmax numerators live in LDS (every thread only revisits the columns it wrote itself, so the passes need
+// no barriers besides the three block reductions); row statistics via DPP wave reductions.
 // Column j is active iff j < M (in-batch targets) or j >= B (sampled negatives); row i's positive is
 // column i.  Losses: gru4rec.py:225-230 (cross_entropy), :239-241 (bpr_max), :245-248 (top1_max),
 // softmax_neg :199-203.  The gradient goes through the softmax weights, as T.grad does.
-__global__ __launch_bounds__(256) void k_loss_rows(const DevModel* __restrict__ mp, StepState* st) {
+#define LOSS_T 512
+#define LOSS_NW (LOSS_T / 64)
+// NV simultaneous block sums / maxima; `red` = NV * LOSS_NW floats that no other reduction of the kernel touches
+template <int NV, bool MAX>
+__device__ __forceinline__ void block_reduce(float (&v)[NV], float* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] = MAX ? wave_max(v[q]) : wave_sum(v[q]);
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) red[q * LOSS_NW + w] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        float a = red[q * LOSS_NW];
+#pragma unroll
+        for (int u = 1; u < LOSS_NW; ++u) a = MAX ? fmaxf(a, red[q * LOSS_NW + u]) : a + red[q * LOSS_NW + u];
+        v[q] = a;
+    }
+}
+
+__global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict__ mp, StepState* st) {
     const DevModel& m = *mp;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -278,76 +301,72 @@ __global__ __launch_bounds__(256) void k_loss_rows(const DevModel* __restrict__ 
     const int fact = m.final_act, lossk = m.loss, ldSc = m.ldSc;    // snapshot: used inside the loops below
     const float fp0 = m.fa_p0, fp1 = m.fa_p1, invB = m.inv_B, bpreg = m.bpreg;
     if (i >= M) return;
-    float* sy = smem;              // [ldSc] yhat, later d/ds
-    float* red = smem + ldSc;    // [8]
+    float* sy = smem;                  // [ldSc] yhat
+    float* se = smem + ldSc;           // [ldSc] softmax numerators, later d L / d yhat
+    float* red = smem + 2 * ldSc;      // [6][3 * LOSS_NW] one region per reduction
     GAS float* row = m.Sc + (size_t)i * ldSc;
+    const bool fsm = (fact == G4R_ACT_SOFTMAX);
 #define ACTIVE(j) ((j) < M || (j) >= B)
-    // ---- final activation (gru4rec.py:496)
-    if (fact == G4R_ACT_SOFTMAX) {
-        float mx = -INFINITY;
-        for (int j = tid; j < N; j += 256)
-            if (ACTIVE(j)) { const float v = row[j]; sy[j] = v; mx = fmaxf(mx, v); }
-        mx = block_max_256(mx, red);
-        float sm = 0.f;
-        for (int j = tid; j < N; j += 256)
-            if (ACTIVE(j)) { const float e = fexp(sy[j] - mx); sy[j] = e; sm += e; }
-        sm = block_sum_256(sm, red);
-        const float inv_z = 1.f / sm;
-        for (int j = tid; j < N; j += 256)
-            if (ACTIVE(j)) sy[j] = sy[j] * inv_z;
+    // ---- final activation (gru4rec.py:496); mneg = max over the negatives of yhat (with the positive as a 0)
+    float mneg[1] = {0.f};
+    if (fsm) {
+        float mx[1] = {-INFINITY};
+        for (int j = tid; j < N; j += LOSS_T)
+            if (ACTIVE(j)) { const float v = row[j]; sy[j] = v; mx[0] = fmaxf(mx[0], v); }
+        block_reduce<1, true>(mx, red);
+        float sm[1] = {0.f};
+        for (int j = tid; j < N; j += LOSS_T)
+            if (ACTIVE(j)) { const float e = fexp(sy[j] - mx[0]); sy[j] = e; sm[0] += e; }
+        block_reduce<1, false>(sm, red + 3 * LOSS_NW);
+        const float inv_z = 1.f / sm[0];
+        for (int j = tid; j < N; j += LOSS_T)
+            if (ACTIVE(j)) { const float y = sy[j] * inv_z; sy[j] = y; if (j != i) mneg[0] = fmaxf(mneg[0], y); }
     } else {
-        for (int j = tid; j < N; j += 256)
-            if (ACTIVE(j)) sy[j] = act_fwd(fact, fp0, fp1, row[j]);
+        for (int j = tid; j < N; j += LOSS_T)
+            if (ACTIVE(j)) { const float y = act_fwd(fact, fp0, fp1, row[j]); sy[j] = y; if (j != i) mneg[0] = fmaxf(mneg[0], y); }
     }
-    __syncthreads();
+    block_reduce<1, true>(mneg, red + 6 * LOSS_NW);      // its barrier also publishes sy[i]
     const float yd = sy[i];
     float Lrow = 0.f;
-    // ---- loss and d L / d yhat (kept in registers per strided element, written back to sy)
     if (lossk == G4R_LOSS_XE) {
         Lrow = -logf(yd + G4R_EPS_LOSS);
-        __syncthreads();
-        if (fact == G4R_ACT_SOFTMAX) {
+        if (fsm) {
             // ds_k = yhat_k * (dy_k - sum_j dy_j yhat_j) with dy = -delta_ik / (yd + eps)
             const float coef = yd / (yd + G4R_EPS_LOSS);
-            for (int j = tid; j < N; j += 256)
-                if (ACTIVE(j)) sy[j] = coef * (sy[j] - (j == i ? 1.f : 0.f)) * invB;
+            for (int j = tid; j < ldSc; j += LOSS_T)
+                row[j] = (j < N && ACTIVE(j)) ? coef * (sy[j] - (j == i ? 1.f : 0.f)) * invB : 0.f;
         } else {
             const float dyd = -1.f / (yd + G4R_EPS_LOSS);
-            for (int j = tid; j < N; j += 256)
-                if (ACTIVE(j))
-                    sy[j] = (j == i) ? dyd * act_bwd_from_out(fact, fp0, fp1, yd) * invB : 0.f;
+            for (int j = tid; j < ldSc; j += LOSS_T)
+                row[j] = (j == i) ? dyd * act_bwd_from_out(fact, fp0, fp1, yd) * invB : 0.f;
         }
     } else {
         // softmax over the negatives, with the positive zeroed first (so the max includes a 0)
-        float mx = 0.f;
-        for (int j = tid; j < N; j += 256)
-            if (ACTIVE(j) && j != i) mx = fmaxf(mx, sy[j]);
-        mx = block_max_256(mx, red);
-        float sm = 0.f;
-        for (int j = tid; j < N; j += 256)
-            if (ACTIVE(j) && j != i) sm += fexp(sy[j] - mx);
-        sm = block_sum_256(sm, red);
-        const float inv_sm = 1.f / sm;
-        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const float mx = mneg[0];
+        float sm[1] = {0.f};
+        for (int j = tid; j < N; j += LOSS_T)
+            if (ACTIVE(j) && j != i) { const float e = fexp(sy[j] - mx); se[j] = e; sm[0] += e; }
+        block_reduce<1, false>(sm, red + 9 * LOSS_NW);
+        const float inv_sm = 1.f / sm[0];
+        float s[3] = {0.f, 0.f, 0.f};
         if (lossk == G4R_LOSS_BPR_MAX) {
-            for (int j = tid; j < N; j += 256)
+            for (int j = tid; j < N; j += LOSS_T)
                 if (ACTIVE(j) && j != i) {
-                    const float y = sy[j], p = fexp(y - mx) * inv_sm, sg = sigmoidf_(yd - y);
-                    s1 += sg * p;                 // A
-                    s2 += y * y * p;              // Q
-                    s3 += sg * (1.f - sg) * p;    // sum sigma' p
+                    const float y = sy[j], p = se[j] * inv_sm, sg = sigmoidf_(yd - y);
+                    s[0] += sg * p;                 // A
+                    s[1] += y * y * p;              // Q
+                    s[2] += sg * (1.f - sg) * p;    // sum sigma' p
                 }
         } else {
-            for (int j = tid; j < N; j += 256)
+            for (int j = tid; j < N; j += LOSS_T)
                 if (ACTIVE(j) && j != i) {
-                    const float y = sy[j], p = fexp(y - mx) * inv_sm, u = sigmoidf_(y - yd), q = sigmoidf_(y * y);
-                    s1 += p * (u + q);            // T
-                    s3 += p * u * (1.f - u);
+                    const float y = sy[j], p = se[j] * inv_sm, u = sigmoidf_(y - yd), q = sigmoidf_(y * y);
+                    s[0] += p * (u + q);            // T
+                    s[2] += p * u * (1.f - u);
                 }
         }
-        s1 = block_sum_256(s1, red);
-        s2 = block_sum_256(s2, red);
-        s3 = block_sum_256(s3, red);
+        block_reduce<3, false>(s, red + 12 * LOSS_NW);
+        const float s1 = s[0], s2 = s[1], s3 = s[2];
         float dyd;
         const float inv_A = 1.f / (s1 + G4R_EPS_LOSS);
         if (lossk == G4R_LOSS_BPR_MAX) {
@@ -357,16 +376,16 @@ __global__ __launch_bounds__(256) void k_loss_rows(const DevModel* __restrict__ 
             Lrow = s1;
             dyd = -s3;
         }
-        // d L / d yhat_j, written over yhat_j (the softmax final-act branch needs yhat again: keep a copy in row[])
-        const bool fsm = (fact == G4R_ACT_SOFTMAX);
-        float inner = 0.f;
-        for (int j = tid; j < N; j += 256)
-            if (ACTIVE(j)) {
+        // d L / d yhat_j -> d L / d s_j, straight to the row in memory (inactive and padding columns get 0)
+        float inner[1] = {0.f};
+        for (int j = tid; j < ldSc; j += LOSS_T) {
+            float out = 0.f;
+            if (j < N && ACTIVE(j)) {
                 const float y = sy[j];
                 float d;
                 if (j == i) d = dyd;
                 else {
-                    const float p = fexp(y - mx) * inv_sm;
+                    const float p = se[j] * inv_sm;
                     if (lossk == G4R_LOSS_BPR_MAX) {
                         const float sg = sigmoidf_(yd - y);
                         d = -p * (sg - sg * (1.f - sg) - s1) * inv_A + bpreg * p * (2.f * y + y * y - s2);
@@ -375,17 +394,17 @@ __global__ __launch_bounds__(256) void k_loss_rows(const DevModel* __restrict__ 
                         d = p * (u + q - s1) + p * (u * (1.f - u) + 2.f * y * q * (1.f - q));
                     }
                 }
-                if (fsm) { row[j] = y; inner += d * y; sy[j] = d; }
-                else sy[j] = d * act_bwd_from_out(fact, fp0, fp1, y) * invB;
+                if (fsm) { inner[0] += d * y; se[j] = d; }
+                else out = d * act_bwd_from_out(fact, fp0, fp1, y) * invB;
             }
+            if (!fsm) row[j] = out;
+        }
         if (fsm) {
-            inner = block_sum_256(inner, red);
-            for (int j = tid; j < N; j += 256)
-                if (ACTIVE(j)) { const float y = row[j]; sy[j] = y * (sy[j] - inner) * invB; }
+            block_reduce<1, false>(inner, red + 15 * LOSS_NW);
+            for (int j = tid; j < ldSc; j += LOSS_T)
+                row[j] = (j < N && ACTIVE(j)) ? sy[j] * (se[j] - inner[0]) * invB : 0.f;
         }
     }
-    __syncthreads();
-    for (int j = tid; j < ldSc; j += 256) row[j] = (j < N && ACTIVE(j)) ? sy[j] : 0.f;
     if (tid == 0) m.lossrow[i] = Lrow;
 #undef ACTIVE
 }
