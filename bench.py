@@ -241,7 +241,7 @@ def main():
         'events_per_s': events / dt, 'loss_first': float(losses[0]), 'loss_last': float(losses[-1]),
         'loss_finite': bool(np.isfinite(losses).all()),
     }
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and n_profile > 0:
         # per-kernel durations: HIP events on the library's own stream, eager launches over the next plan steps
         m.profile(True)
         m.train_steps(args.warmup + args.steps, n_profile)
@@ -250,7 +250,7 @@ def main():
         alg = algorithmic_cost(cfg)
         kern = {}
         for name, (ms, n) in kt.items():
-            us = 1000.0 * ms / n
+            us = 1000.0 * ms / max(n, 1)
             e = {'avg_us': us, 'launches_per_step': n / n_profile}
             a = alg.get(name)
             if a:
@@ -267,10 +267,16 @@ def main():
         # the roofline entry: the embedding gather/scatter kernel north_star names (HBM-bound)
         k = kern.get('k_sparse_update')
         if k:
+            traffic, tnote = None, ''
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic_%s.json' % args.config)
+            if os.path.exists(pmc):     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_summary.py)
+                traffic = json.load(open(pmc))['kernels'].get('k_sparse_update', {}).get('traffic_bytes')
+                tnote = '; traffic = 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/%s)' % os.path.basename(pmc)
             out['roofline'] = {'kernel': 'k_sparse_update', 'bound': 'hbm', 'achieved': k['achieved'], 'peak': 8000.0,
-                               'unit': 'GB/s', 'frac': k['achieved'] / 8000.0, 'traffic': None,
-                               'note': 'algorithmic bytes per launch = %d (gradient rows + param/accumulator r/w per occurrence); '
-                                       'the 15 MB table is Infinity-Cache resident at this config' % alg['k_sparse_update']['bytes']}
+                               'unit': 'GB/s', 'frac': k['achieved'] / 8000.0, 'traffic': traffic,
+                               'note': 'algorithmic bytes per launch = %d (gradient rows + param/accumulator r/w per occurrence, '
+                                       'SURVEY 8d); the 15 MB table is Infinity-Cache resident at this config%s' % (
+                                           alg['k_sparse_update']['bytes'], tnote)}
         dom = max(kern.items(), key=lambda kv: kv[1]['avg_us'] * kv[1]['launches_per_step'])
         out['dominant_kernel'] = dom[0]
         if not args.no_cpu_baseline:

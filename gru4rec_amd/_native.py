@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgru4rec_hip.so')
+LIB_PATH = os.environ.get('G4R_LIB') or os.path.join(_HERE, 'libgru4rec_hip.so')   # G4R_LIB: developer override
 
 G4R_MAX_LAYERS = 8
 LOSS_IDS = {'cross-entropy': 0, 'bpr-max': 1, 'top1-max': 2}

@@ -1,6 +1,7 @@
 // libgru4rec_hip.so -- host side of the C ABI declared in include/gru4rec_hip.h.
 // Owns device memory, the HIP stream, the captured step graph and the (optional) RCCL communicator.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -36,6 +37,8 @@ enum { KN_GRU_P1 = 0, KN_GRU_P2, KN_SCORE_FWD, KN_LOSS, KN_SCORE_BWD, KN_BWD_PRE
 static const char* KN_NAMES[KN_COUNT] = {"k_gru_p1", "k_gru_p2", "k_score_fwd", "k_loss_rows", "k_score_bwd", "k_gru_bwd_pre",
                                          "k_gru_bwd_a", "k_gru_bwd_b", "k_dense_grad", "rccl_allreduce", "k_dense_apply",
                                          "k_sparse_update"};
+
+struct EvRec { int kn; hipEvent_t a, b; };
 
 struct g4r_model {
     g4r_config cfg;
@@ -488,20 +491,19 @@ int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
 }
 
 // ------------------------------------------------------------------------------------------------ the step
-struct EvRec { int kn; hipEvent_t a, b; };
-
 static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
     DevModel& d = m->dm;
     const int L = d.n_layers, B = d.B;
     hipStream_t s = m->stream;
     GruFwdPredict nopa = {};
     size_t evi = 0;
+    hipEvent_t cur_a = nullptr, cur_b = nullptr;
     auto begin = [&](int kn) {
         if (!recs) return;
         while (m->evs.size() < evi + 2) { hipEvent_t e; (void)hipEventCreate(&e); m->evs.push_back(e); }
         EvRec r = {kn, m->evs[evi], m->evs[evi + 1]};
         evi += 2;
-        (void)hipEventRecord(r.a, s);
+        cur_a = r.a; cur_b = r.b;     // attached to the dispatch itself (hipExtLaunchKernelGGL): kernel-only duration
         recs->push_back(r);
     };
     static const bool trace = getenv("G4R_TRACE") != nullptr;
@@ -513,7 +515,6 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
         begin0(kn);
     };
     auto end = [&]() {
-        if (recs) (void)hipEventRecord(recs->back().b, s);
         if (trace) {
             hipError_t e = hipStreamSynchronize(s);
             fprintf(stderr, "[g4r] done   %s: %s\n", KN_NAMES[trace_kn], hipGetErrorString(e));
@@ -521,38 +522,43 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
         }
     };
 #define begin begin_t
+#define LK(kern, grid, block, smem, strm, ...)                                                             \
+    do {                                                                                                  \
+        if (recs) hipExtLaunchKernelGGL(kern, grid, block, smem, strm, cur_a, cur_b, 0, __VA_ARGS__);     \
+        else hipLaunchKernelGGL(kern, grid, block, smem, strm, __VA_ARGS__);                              \
+    } while (0)
     const DevModel* dmp = (const DevModel*)m->d_dm;
     StepState* stp = (StepState*)d.st;
     for (int l = 0; l < L; ++l) {
         begin(KN_GRU_P1);
-        hipLaunchKernelGGL(k_gru_p1, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_P1, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
+        LK(k_gru_p1, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_P1, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
         end();
         begin(KN_GRU_P2);
-        hipLaunchKernelGGL(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_NN, s, dmp, stp, l, 1, nopa);
+        LK(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_NN, s, dmp, stp, l, 1, nopa);
         end();
     }
     begin(KN_SCORE_FWD);
-    hipLaunchKernelGGL(k_score_fwd, dim3(cdiv(d.ldSc, GT_BN), cdiv(B, SF_BM)), dim3(256), SMEM_SF, s, dmp, stp);
+    LK(k_score_fwd, dim3(cdiv(d.ldSc, GT_BN), cdiv(B, SF_BM)), dim3(256), SMEM_SF, s, dmp, stp);
     end();
     begin(KN_LOSS);
-    hipLaunchKernelGGL(k_loss_rows, dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
+    LK(k_loss_rows, dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
     end();
     begin(KN_SCORE_BWD);
-    hipLaunchKernelGGL(k_score_bwd, dim3(m->nblkA + m->nblkB), dim3(256), std::max(SMEM_TN, SMEM_NN) + GT_BK * sizeof(int), s, dmp, stp, m->nblkA, m->ndtA, m->ndtB, m->nrtB);
+    LK(k_score_bwd, dim3(m->nblkA + m->nblkB), dim3(256), std::max(SMEM_TN, SMEM_NN) + GT_BK * sizeof(int), s, dmp, stp, m->nblkA, m->ndtA, m->ndtB, m->nrtB);
     end();
     for (int l = L - 1; l >= 0; --l) {
         begin(KN_BWD_PRE);
-        hipLaunchKernelGGL(k_gru_bwd_pre, dim3(cdiv((long long)B * d.D[l], 256)), dim3(256), 0, s, dmp, stp, l);
+        LK(k_gru_bwd_pre, dim3(cdiv((long long)B * d.D[l], 256)), dim3(256), 0, s, dmp, stp, l);
         end();
         begin(KN_BWD_A);
-        hipLaunchKernelGGL(k_gru_bwd_a, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_NT, s, dmp, stp, l);
+        LK(k_gru_bwd_a, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_NT, s, dmp, stp, l);
         end();
         begin(KN_BWD_B);
-        hipLaunchKernelGGL(k_gru_bwd_b, dim3(cdiv(d.IN[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_BB, s, dmp, stp, l);
+        LK(k_gru_bwd_b, dim3(cdiv(d.IN[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_BB, s, dmp, stp, l);
         end();
     }
     begin(KN_DENSE);
-    hipLaunchKernelGGL(k_dense_grad, dim3(m->ntiles), dim3(256), SMEM_TN + (size_t)B * sizeof(int), s, dmp, stp, (const DenseTile*)m->d_tiles);
+    LK(k_dense_grad, dim3(m->ntiles), dim3(256), SMEM_TN + (size_t)B * sizeof(int), s, dmp, stp, (const DenseTile*)m->d_tiles);
     end();
     // multi-rank: the dense-gradient all-reduce and the dense Adagrad run on their own stream next to the sparse
     // embedding update (which touches item rows only), and join before the next step reads the GRU weights
@@ -561,19 +567,20 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
         if (!m->comm_ready) return fail("nranks > 1 but g4r_comm_init was not called");
         hipStream_t cs = overlap ? m->comm_stream : s;
         if (overlap) { HIPCHK(hipEventRecord(m->ev_fork, s)); HIPCHK(hipStreamWaitEvent(cs, m->ev_fork, 0)); }
-        if (!overlap) begin(KN_ALLREDUCE);
+        if (!overlap) { begin(KN_ALLREDUCE); if (recs) (void)hipEventRecord(cur_a, cs); }
         NCCLCHK(ncclAllReduce(d.dense_g, d.dense_g, d.dense_count, ncclFloat, ncclSum, m->comm, cs));
-        if (!overlap) { end(); begin(KN_DENSE_APPLY); }
-        hipLaunchKernelGGL(k_dense_apply, dim3(cdiv(d.dense_count, 256)), dim3(256), 0, cs, (const DevModel*)m->d_dm);
+        if (!overlap) { if (recs) (void)hipEventRecord(cur_b, cs); end(); begin(KN_DENSE_APPLY); }
+        LK(k_dense_apply, dim3(cdiv(d.dense_count, 256)), dim3(256), 0, cs, (const DevModel*)m->d_dm);
         if (!overlap) end();
         if (overlap) HIPCHK(hipEventRecord(m->ev_join, cs));
     }
     begin(KN_SPARSE);
-    if (std::max(d.Dtop, d.Ein) <= 256) hipLaunchKernelGGL(k_sparse_update<1>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
-    else hipLaunchKernelGGL(k_sparse_update<2>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
+    if (std::max(d.Dtop, d.Ein) <= 256) LK(k_sparse_update<1>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
+    else LK(k_sparse_update<2>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
     end();
     if (overlap) HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0));
 #undef begin
+#undef LK
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -635,6 +642,8 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
         }
         for (; done < run; ++done) {
             if (m->profiling) {
+                // per-kernel durations: start/stop events attached to every dispatch (hipExtLaunchKernelGGL), i.e. the
+                // kernel's own begin/end timestamps -- the quantity rocprofv3 --kernel-trace reports; eager launches
                 recs.clear();
                 if (launch_step(m, &recs)) return -1;
                 HIPCHK(hipStreamSynchronize(m->stream));

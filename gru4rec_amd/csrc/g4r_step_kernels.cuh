@@ -51,8 +51,10 @@ struct GruFwdPredict {
 #define GT_BM 32
 #define GT_BN 32
 #define GT_BK 128
+#ifndef P1_BK
 #define P1_BK 256     // K = IN + D of GRU phase 1 in one chunk up to IN + D = 256
 #define BB_BK 320     // K = 3D of dy = dV Wx^T in one chunk up to D = 106
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // GRU phase 1: V[B, 3D] = [y | H] * [Wx ; 0|Wrz] + Bh over 32x32 tiles, K = IN + D.
@@ -270,7 +272,9 @@ __global__ __launch_bounds__(256) void k_score_fwd(const DevModel* __restrict__ 
 // Column j is active iff j < M (in-batch targets) or j >= B (sampled negatives); row i's positive is
 // column i.  Losses: gru4rec.py:225-230 (cross_entropy), :239-241 (bpr_max), :245-248 (top1_max),
 // softmax_neg :199-203.  The gradient goes through the softmax weights, as T.grad does.
+#ifndef LOSS_T
 #define LOSS_T 512
+#endif
 #define LOSS_NW (LOSS_T / 64)
 // NV simultaneous block sums / maxima; `red` = NV * LOSS_NW floats that no other reduction of the kernel touches
 template <int NV, bool MAX>
