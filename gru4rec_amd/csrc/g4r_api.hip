@@ -10,6 +10,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <chrono>
 
 #include "g4r_eval_kernels.cuh"
 
@@ -39,6 +40,9 @@ static const char* KN_NAMES[KN_COUNT] = {"k_gru_p1", "k_gru_p2", "k_score_fwd", 
                                          "k_sparse_update"};
 
 struct EvRec { int kn; hipEvent_t a, b; };
+static double g_hostprof[8];
+static long g_hostprof_n;
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct g4r_model {
     g4r_config cfg;
@@ -68,6 +72,7 @@ struct g4r_model {
     float* d_tmpH = nullptr;
     // graph
     hipGraphExec_t gexec = nullptr;
+    hipGraphExec_t gexec_head = nullptr;         // N > 1: one step's kernels up to the dense gradients (RCCL stays eager)
     int graph_steps = 0;
     // profiling
     bool profiling = false;
@@ -287,6 +292,7 @@ void g4r_destroy(g4r_model* m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->comm_stream) (void)hipStreamSynchronize(m->comm_stream);
     if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
+    if (m->gexec_head) (void)hipGraphExecDestroy(m->gexec_head);
     if (m->comm_ready) (void)ncclCommDestroy(m->comm);
     for (auto e : m->evs) (void)hipEventDestroy(e);
     for (void* p : m->allocs) (void)hipFree(p);
@@ -491,7 +497,8 @@ int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
 }
 
 // ------------------------------------------------------------------------------------------------ the step
-static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
+// part: 0 = the whole step; 1 = head (everything up to the dense gradients); 2 = tail (all-reduce, dense apply, sparse update)
+static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     DevModel& d = m->dm;
     const int L = d.n_layers, B = d.B;
     hipStream_t s = m->stream;
@@ -529,6 +536,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
     } while (0)
     const DevModel* dmp = (const DevModel*)m->d_dm;
     StepState* stp = (StepState*)d.st;
+    if (part != 2) {
     for (int l = 0; l < L; ++l) {
         begin(KN_GRU_P1);
         LK(k_gru_p1, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_P1, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
@@ -560,15 +568,24 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs) {
     begin(KN_DENSE);
     LK(k_dense_grad, dim3(m->ntiles), dim3(256), SMEM_TN + (size_t)B * sizeof(int), s, dmp, stp, (const DenseTile*)m->d_tiles);
     end();
-    // multi-rank: the dense-gradient all-reduce and the dense Adagrad run on their own stream next to the sparse
-    // embedding update (which touches item rows only), and join before the next step reads the GRU weights
-    const bool overlap = !d.apply_dense_inplace && !recs && !trace;
+    }
+    if (part == 1) { HIPCHK(hipGetLastError()); return 0; }
+    // multi-rank: dense-gradient all-reduce, dense Adagrad, then the sparse embedding update, in stream order.
+    // Optionally the first two run on their own stream next to the sparse update (which touches item rows only)
+    // and join before the next step reads the GRU weights
+    // (measured on one MI355X with a one-rank communicator: the two cross-stream event dependencies cost ~20 us per
+    // step, more than the ~11 us of sparse update they can hide, so the overlap is opt-in: G4R_OVERLAP=1)
+    static const bool want_overlap = getenv("G4R_OVERLAP") != nullptr;
+    const bool overlap = !d.apply_dense_inplace && !recs && !trace && want_overlap;
     if (!d.apply_dense_inplace) {
         if (!m->comm_ready) return fail("nranks > 1 but g4r_comm_init was not called");
         hipStream_t cs = overlap ? m->comm_stream : s;
+        double h1 = now_us();
         if (overlap) { HIPCHK(hipEventRecord(m->ev_fork, s)); HIPCHK(hipStreamWaitEvent(cs, m->ev_fork, 0)); }
+        g_hostprof[1] += now_us() - h1; h1 = now_us();
         if (!overlap) { begin(KN_ALLREDUCE); if (recs) (void)hipEventRecord(cur_a, cs); }
         NCCLCHK(ncclAllReduce(d.dense_g, d.dense_g, d.dense_count, ncclFloat, ncclSum, m->comm, cs));
+        g_hostprof[2] += now_us() - h1;
         if (!overlap) { if (recs) (void)hipEventRecord(cur_b, cs); end(); begin(KN_DENSE_APPLY); }
         LK(k_dense_apply, dim3(cdiv(d.dense_count, 256)), dim3(256), 0, cs, (const DevModel*)m->d_dm);
         if (!overlap) end();
@@ -613,6 +630,17 @@ static int ensure_graph(g4r_model* m) {
     return 0;
 }
 
+static int ensure_head_graph(g4r_model* m) {
+    if (m->gexec_head) return 0;
+    hipGraph_t graph;
+    HIPCHK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+    if (launch_step(m, nullptr, 1)) { hipGraph_t g2; (void)hipStreamEndCapture(m->stream, &g2); return -1; }
+    HIPCHK(hipStreamEndCapture(m->stream, &graph));
+    HIPCHK(hipGraphInstantiate(&m->gexec_head, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    return 0;
+}
+
 int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
     if (!m) return fail("null model");
     if (!m->d_in) return fail("no plan uploaded");
@@ -651,12 +679,21 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
                     float ms = 0.f;
                     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { m->kn_ms[r.kn] += ms; m->kn_n[r.kn]++; }
                 }
+            } else if (m->cfg.use_graph && !m->dm.apply_dense_inplace && !getenv("G4R_TRACE")) {
+                // N > 1: the step's 9 compute kernels replay from a graph; the RCCL all-reduce, the dense apply and the
+                // sparse update (two streams, fork/join events) are launched eagerly behind it
+                if (ensure_head_graph(m)) return -1;
+                const double h0 = now_us();
+                HIPCHK(hipGraphLaunch(m->gexec_head, m->stream));
+                g_hostprof[0] += now_us() - h0; g_hostprof_n++;
+                if (launch_step(m, nullptr, 2)) return -1;
             } else if (launch_step(m, nullptr)) return -1;
         }
         t += run;
         m->gstep += run;
     }
     HIPCHK(hipStreamSynchronize(m->stream));
+    if (getenv("G4R_HOSTPROF") && g_hostprof_n) fprintf(stderr, "[g4r] host us/step: graph launch %.1f, fork %.1f, rccl %.1f (n=%ld)\n", g_hostprof[0] / g_hostprof_n, g_hostprof[1] / g_hostprof_n, g_hostprof[2] / g_hostprof_n, g_hostprof_n);
     return 0;
 }
 
