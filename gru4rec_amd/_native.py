@@ -12,8 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('G4R_LIB') or os.path.join(_HERE, 'libgru4rec_hip.so')   # G4R_LIB: developer override
 
 G4R_MAX_LAYERS = 8
-LOSS_IDS = {'cross-entropy': 0, 'bpr-max': 1, 'top1-max': 2}
-ACT_IDS = {'linear': 0, 'relu': 1, 'tanh': 2, 'leaky': 3, 'elu': 4, 'selu': 5, 'softmax': 6}
+LOSS_IDS = {'cross-entropy': 0, 'bpr-max': 1, 'top1-max': 2, 'bpr': 3, 'top1': 4, 'xe_logit': 5}
+ACT_IDS = {'linear': 0, 'relu': 1, 'tanh': 2, 'leaky': 3, 'elu': 4, 'selu': 5, 'softmax': 6, 'softmax_logit': 7}
 RANK_MODES = {'standard': 0, 'conservative': 1, 'median': 2}
 EMBED_CONSTRAINED, EMBED_SEPARATE = 0, 1
 
@@ -30,7 +30,7 @@ class G4RConfig(C.Structure):
         ('dropout_p_hidden', C.c_float), ('dropout_p_embed', C.c_float),
         ('sample_store', C.c_int64), ('seed', C.c_uint64),
         ('device', C.c_int32), ('rank', C.c_int32), ('nranks', C.c_int32), ('use_graph', C.c_int32),
-        ('reserved', C.c_int32 * 7),
+        ('smoothing', C.c_float), ('reserved', C.c_int32 * 6),
     ]
 
 

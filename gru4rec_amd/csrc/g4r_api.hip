@@ -149,7 +149,9 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         return fail("embedding must be a multiple of 4 in [4, 512]");
     if (cfg->embed_mode != G4R_EMBED_CONSTRAINED && cfg->embed_mode != G4R_EMBED_SEPARATE)
         return fail("unsupported embedding mode");
-    if (cfg->loss < 0 || cfg->loss > G4R_LOSS_TOP1_MAX) return fail("unsupported loss");
+    if (cfg->loss < 0 || cfg->loss > G4R_LOSS_XE_LOGIT) return fail("unsupported loss");
+    if (cfg->smoothing != 0.f && cfg->loss != G4R_LOSS_XE && cfg->loss != G4R_LOSS_XE_LOGIT) return fail("smoothing needs a cross-entropy loss");
+    if (cfg->hidden_act == G4R_ACT_SOFTMAX_LOGIT) return fail("softmax_logit is not a hidden activation");
     if (cfg->hidden_act == G4R_ACT_SOFTMAX) return fail("softmax is not a hidden activation");
     int ndev = g4r_device_count();
     if (ndev <= 0) return fail("no HIP device visible: the gfx950 path has no CPU fallback");
@@ -176,6 +178,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     d.fa_p0 = cfg->final_act_p0; d.fa_p1 = cfg->final_act_p1; d.ha_p0 = cfg->hidden_act_p0; d.ha_p1 = cfg->hidden_act_p1;
     d.lr = cfg->learning_rate; d.mom = cfg->momentum; d.lmbd = cfg->lmbd; d.bpreg = cfg->bpreg; d.logq = cfg->logq;
     d.inv_B = 1.0f / (float)B;
+    d.smoothing = cfg->smoothing;
     d.drop_h = cfg->dropout_p_hidden; d.drop_e = cfg->dropout_p_embed;
     d.seed = cfg->seed;
     d.Dtop = cfg->layers[L - 1];
@@ -838,7 +841,7 @@ int g4r_predict_step(g4r_model* m, const int32_t* in_idx, int32_t mrows, const i
                            (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, pa);
     }
     m->ppar ^= 1;
-    const bool sm = (d.final_act == G4R_ACT_SOFTMAX);
+    const bool sm = (d.final_act == G4R_ACT_SOFTMAX || d.final_act == G4R_ACT_SOFTMAX_LOGIT);   // gru4rec.py:499-500
     hipLaunchKernelGGL(k_score_all<32>, dim3(cdiv(n_sel, 32), cdiv(mrows, SC_BM)), dim3(256), m->smem_score, m->stream, (const DevModel*)m->d_dm,
                        (const float*)m->phout[d.n_layers - 1], (int)mrows, item_idx ? (const int*)m->p_items : (const int*)nullptr,
                        (long long)n_sel, m->p_scores, (long long)ldo, sm ? 0 : 1);

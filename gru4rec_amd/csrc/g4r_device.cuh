@@ -67,7 +67,7 @@ struct DevModel {
     int n_items, n_layers, B, ns, N, R, ldSc;
     int loss, final_act, hidden_act, embed_mode;
     float fa_p0, fa_p1, ha_p0, ha_p1;
-    float lr, mom, lmbd, bpreg, logq, inv_B;
+    float lr, mom, lmbd, bpreg, logq, inv_B, smoothing, pad_f;
     float drop_h, drop_e;
     unsigned long long seed;
     int D[G4R_MAX_LAYERS], IN[G4R_MAX_LAYERS];

@@ -296,6 +296,10 @@ __device__ __forceinline__ void block_reduce(float (&v)[NV], float* red) {
     }
 }
 
+__device__ __forceinline__ float softplusf_(float x) {      // log(1 + e^x), stable
+    return fmaxf(x, 0.f) + log1pf(fexp(-fabsf(x)));
+}
+
 __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict__ mp, StepState* st) {
     const DevModel& m = *mp;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -303,28 +307,34 @@ __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict
     const StepCtx c = load_ctx(st);
     const int M = c.M, B = m.B, N = m.N, i = blockIdx.x;
     const int fact = m.final_act, lossk = m.loss, ldSc = m.ldSc;    // snapshot: used inside the loops below
-    const float fp0 = m.fa_p0, fp1 = m.fa_p1, invB = m.inv_B, bpreg = m.bpreg;
+    const float fp0 = m.fa_p0, fp1 = m.fa_p1, invB = m.inv_B, bpreg = m.bpreg, smooth = m.smoothing;
     if (i >= M) return;
     float* sy = smem;                  // [ldSc] yhat
     float* se = smem + ldSc;           // [ldSc] softmax numerators, later d L / d yhat
-    float* red = smem + 2 * ldSc;      // [6][3 * LOSS_NW] one region per reduction
+    float* red = smem + 2 * ldSc;      // [8][3 * LOSS_NW] one region per reduction
     GAS float* row = m.Sc + (size_t)i * ldSc;
-    const bool fsm = (fact == G4R_ACT_SOFTMAX);
+    const bool fsm = (fact == G4R_ACT_SOFTMAX), fsl = (fact == G4R_ACT_SOFTMAX_LOGIT);
+    const float n_out = (float)(M + (N - B));      // active columns (gru4rec.py:227,233,244: M + n_sample)
 #define ACTIVE(j) ((j) < M || (j) >= B)
     // ---- final activation (gru4rec.py:496); mneg = max over the negatives of yhat (with the positive as a 0)
     float mneg[1] = {0.f};
-    if (fsm) {
+    if (fsm || fsl) {
         float mx[1] = {-INFINITY};
         for (int j = tid; j < N; j += LOSS_T)
             if (ACTIVE(j)) { const float v = row[j]; sy[j] = v; mx[0] = fmaxf(mx[0], v); }
         block_reduce<1, true>(mx, red);
         float sm[1] = {0.f};
         for (int j = tid; j < N; j += LOSS_T)
-            if (ACTIVE(j)) { const float e = fexp(sy[j] - mx[0]); sy[j] = e; sm[0] += e; }
+            if (ACTIVE(j)) { const float e = fexp(sy[j] - mx[0]); if (fsm) sy[j] = e; sm[0] += e; }
         block_reduce<1, false>(sm, red + 3 * LOSS_NW);
-        const float inv_z = 1.f / sm[0];
+        const float inv_z = 1.f / sm[0], lse = logf(sm[0]);
         for (int j = tid; j < N; j += LOSS_T)
-            if (ACTIVE(j)) { const float y = sy[j] * inv_z; sy[j] = y; if (j != i) mneg[0] = fmaxf(mneg[0], y); }
+            if (ACTIVE(j)) {
+                // softmax :193-195 ; softmax_logit :196-198 = log(sum exp(x - max)) - (x - max)
+                const float y = fsm ? sy[j] * inv_z : lse - (sy[j] - mx[0]);
+                sy[j] = y;
+                if (j != i) mneg[0] = fmaxf(mneg[0], y);
+            }
     } else {
         for (int j = tid; j < N; j += LOSS_T)
             if (ACTIVE(j)) { const float y = act_fwd(fact, fp0, fp1, row[j]); sy[j] = y; if (j != i) mneg[0] = fmaxf(mneg[0], y); }
@@ -332,17 +342,67 @@ __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict
     block_reduce<1, true>(mneg, red + 6 * LOSS_NW);      // its barrier also publishes sy[i]
     const float yd = sy[i];
     float Lrow = 0.f;
-    if (lossk == G4R_LOSS_XE) {
+    // ---- loss and d L / d yhat_j -> se[j] (every thread its own columns)
+    if (lossk == G4R_LOSS_XE && fsm && smooth == 0.f) {
+        // fused softmax + cross-entropy: ds_k = yhat_k * (dy_k - sum_j dy_j yhat_j) with dy = -delta_ik / (yd + eps)
         Lrow = -logf(yd + G4R_EPS_LOSS);
-        if (fsm) {
-            // ds_k = yhat_k * (dy_k - sum_j dy_j yhat_j) with dy = -delta_ik / (yd + eps)
-            const float coef = yd / (yd + G4R_EPS_LOSS);
-            for (int j = tid; j < ldSc; j += LOSS_T)
-                row[j] = (j < N && ACTIVE(j)) ? coef * (sy[j] - (j == i ? 1.f : 0.f)) * invB : 0.f;
+        const float coef = yd / (yd + G4R_EPS_LOSS);
+        for (int j = tid; j < ldSc; j += LOSS_T)
+            row[j] = (j < N && ACTIVE(j)) ? coef * (sy[j] - (j == i ? 1.f : 0.f)) * invB : 0.f;
+        if (tid == 0) m.lossrow[i] = Lrow;
+        return;
+    }
+    if (lossk == G4R_LOSS_XE || lossk == G4R_LOSS_XE_LOGIT) {
+        // cross_entropy :225-230 on probabilities, cross_entropy_logits :231-236 on -log-probabilities, with label
+        // smoothing: (1 - n/(n-1) s) * l(yd) + s/(n-1) * sum_j l(y_j)
+        const bool lg = (lossk == G4R_LOSS_XE_LOGIT);
+        const float wd = 1.f - n_out / (n_out - 1.f) * smooth, wa = smooth / (n_out - 1.f);
+        float sa[1] = {0.f};
+        for (int j = tid; j < N; j += LOSS_T)
+            if (ACTIVE(j)) {
+                const float y = sy[j];
+                float d = 0.f;
+                if (smooth != 0.f) { sa[0] += lg ? y : -logf(y + G4R_EPS_LOSS); d = lg ? wa : -wa / (y + G4R_EPS_LOSS); }
+                if (j == i) d += lg ? wd : -wd / (y + G4R_EPS_LOSS);
+                se[j] = d;
+            }
+        if (smooth != 0.f) block_reduce<1, false>(sa, red + 9 * LOSS_NW);
+        Lrow = wd * (lg ? yd : -logf(yd + G4R_EPS_LOSS)) + wa * sa[0];
+    } else if (lossk == G4R_LOSS_BPR || lossk == G4R_LOSS_TOP1) {
+        float s[2] = {0.f, 0.f};
+        if (lossk == G4R_LOSS_BPR) {
+            // bpr :237-238: sum over ALL active columns of -log sigmoid(yd - y_j) (the diagonal adds log 2)
+            for (int j = tid; j < N; j += LOSS_T)
+                if (ACTIVE(j)) {
+                    const float y = sy[j];
+                    s[0] += softplusf_(y - yd);
+                    const float d = (j == i) ? 0.f : sigmoidf_(y - yd);
+                    s[1] += d;
+                    se[j] = d;
+                }
+            block_reduce<2, false>(s, red + 9 * LOSS_NW);
+            Lrow = s[0];
+            if (tid == (i % LOSS_T)) se[i] = -s[1];
         } else {
-            const float dyd = -1.f / (yd + G4R_EPS_LOSS);
-            for (int j = tid; j < ldSc; j += LOSS_T)
-                row[j] = (j == i) ? dyd * act_bwd_from_out(fact, fp0, fp1, yd) * invB : 0.f;
+            // top1 :242-244: mean_j (sigmoid(y_j - yd) + sigmoid(y_j^2)) - sigmoid(yd^2) / n  (the diagonal leaves 0.5 / n).
+            // As written in the reference the (M,) mean minus the (M, 1) diagonal term broadcasts to (M, M) before the
+            // sum, i.e. the cost is M times the per-row formula; reproduced here (wM).
+            const float inv_n = 1.f / n_out, wM = (float)M;
+            for (int j = tid; j < N; j += LOSS_T)
+                if (ACTIVE(j)) {
+                    const float y = sy[j];
+                    float d = 0.f;
+                    if (j != i) {
+                        const float u = sigmoidf_(y - yd), q = sigmoidf_(y * y);
+                        s[0] += u + q;
+                        s[1] += u * (1.f - u);
+                        d = wM * inv_n * (u * (1.f - u) + 2.f * y * q * (1.f - q));
+                    }
+                    se[j] = d;
+                }
+            block_reduce<2, false>(s, red + 9 * LOSS_NW);
+            Lrow = wM * inv_n * (s[0] + 0.5f);
+            if (tid == (i % LOSS_T)) se[i] = -wM * inv_n * s[1];
         }
     } else {
         // softmax over the negatives, with the positive zeroed first (so the max includes a 0)
@@ -380,11 +440,8 @@ __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict
             Lrow = s1;
             dyd = -s3;
         }
-        // d L / d yhat_j -> d L / d s_j, straight to the row in memory (inactive and padding columns get 0)
-        float inner[1] = {0.f};
-        for (int j = tid; j < ldSc; j += LOSS_T) {
-            float out = 0.f;
-            if (j < N && ACTIVE(j)) {
+        for (int j = tid; j < N; j += LOSS_T)
+            if (ACTIVE(j)) {
                 const float y = sy[j];
                 float d;
                 if (j == i) d = dyd;
@@ -398,16 +455,28 @@ __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict
                         d = p * (u + q - s1) + p * (u * (1.f - u) + 2.f * y * q * (1.f - q));
                     }
                 }
-                if (fsm) { inner[0] += d * y; se[j] = d; }
-                else out = d * act_bwd_from_out(fact, fp0, fp1, y) * invB;
+                se[j] = d;
             }
-            if (!fsm) row[j] = out;
+    }
+    // ---- d L / d yhat -> d cost / d s through the final activation, straight to the row in memory (inactive and
+    // padding columns get 0).  softmax: y (d - sum_j d_j y_j); softmax_logit: softmax_k sum_j d_j - d_k with
+    // softmax_k = exp(-yhat_k); element-wise: d f'(s)
+    float inner[1] = {0.f};
+    if (fsm || fsl) {
+        for (int j = tid; j < N; j += LOSS_T)
+            if (ACTIVE(j)) inner[0] += fsm ? se[j] * sy[j] : se[j];
+        block_reduce<1, false>(inner, red + 15 * LOSS_NW);
+    }
+    for (int j = tid; j < ldSc; j += LOSS_T) {
+        float out = 0.f;
+        if (j < N && ACTIVE(j)) {
+            const float y = sy[j], d = se[j];
+            if (fsm) out = y * (d - inner[0]);
+            else if (fsl) out = fexp(-y) * inner[0] - d;
+            else out = d * act_bwd_from_out(fact, fp0, fp1, y);
+            out *= invB;
         }
-        if (fsm) {
-            block_reduce<1, false>(inner, red + 15 * LOSS_NW);
-            for (int j = tid; j < ldSc; j += LOSS_T)
-                row[j] = (j < N && ACTIVE(j)) ? sy[j] * (se[j] - inner[0]) * invB : 0.f;
-        }
+        row[j] = out;
     }
     if (tid == 0) m.lossrow[i] = Lrow;
 #undef ACTIVE

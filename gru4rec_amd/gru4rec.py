@@ -27,8 +27,8 @@ def _parse_act(name, allow_softmax):
         if name == 'softmax' and not allow_softmax:
             raise NotImplementedError
         return _native.ACT_IDS[name], 0.0, 0.0
-    if name == 'softmax_logit' and allow_softmax:
-        raise NotImplementedError('final_act=softmax_logit (xe_logit loss) is not available in the MI355X path yet')
+    if name == 'softmax_logit' and allow_softmax:      # final activation only (gru4rec.py:149)
+        return _native.ACT_IDS[name], 0.0, 0.0
     for prefix, npar in (('leaky-', 1), ('elu-', 1), ('selu-', 2)):
         if name.startswith(prefix):
             p = [float(x) for x in name.split('-')[1:]]
@@ -89,18 +89,12 @@ class GRU4Rec:
 
     # ------------------------------------------------------------------ validation of names
     def set_loss_function(self, loss):
-        if loss in ('cross-entropy', 'bpr-max', 'top1-max'):
+        if loss in _native.LOSS_IDS:         # gru4rec.py:136-143
             self._loss_id = _native.LOSS_IDS[loss]
-        elif loss in ('bpr', 'top1', 'xe_logit'):
-            # valid reference names (gru4rec.py:136-143) outside this hot path; rejected when fit() starts
-            self._loss_id = None
         else:
             raise NotImplementedError
 
     def set_final_activation(self, final_act):
-        if final_act == 'softmax_logit':
-            self._final = None
-            return
         self._final = _parse_act(final_act, True)
 
     def set_hidden_activation(self, hidden_act):
@@ -179,14 +173,12 @@ class GRU4Rec:
 
     # ------------------------------------------------------------------ native model management
     def _check_supported(self):
-        if self._loss_id is None:
-            raise NotImplementedError('loss {} is outside the MI355X hot path (cross-entropy, bpr-max, top1-max)'.format(self.loss))
-        if self._final is None:
-            raise NotImplementedError('final_act softmax_logit is outside the MI355X hot path')
         if self.adapt != 'adagrad':
             raise NotImplementedError('adapt={} is outside the MI355X hot path (adagrad only)'.format(self.adapt))
-        if self.smoothing or self.grad_cap:
-            raise NotImplementedError('smoothing / grad_cap are outside the MI355X hot path')
+        if self.grad_cap:
+            raise NotImplementedError('grad_cap is outside the MI355X hot path')
+        if self.smoothing and self.loss not in ('cross-entropy', 'xe_logit'):
+            raise NotImplementedError('smoothing is only defined for cross-entropy / xe_logit (gru4rec.py:226-235)')
         if not self.constrained_embedding and not self.embedding:
             raise NotImplementedError('one-hot input (embedding=0, constrained_embedding=False) is not in the MI355X path yet; '
                                       'use constrained_embedding=True or embedding=<size>')
@@ -202,7 +194,7 @@ class GRU4Rec:
             hidden_act=self._hidden[0], hidden_act_p0=self._hidden[1], hidden_act_p1=self._hidden[2],
             embed_mode=_native.EMBED_CONSTRAINED if self.constrained_embedding else _native.EMBED_SEPARATE,
             embedding=int(self.embedding or 0), learning_rate=self.learning_rate, momentum=self.momentum,
-            lmbd=self.lmbd, bpreg=self.bpreg, logq=self.logq, sample_alpha=self.sample_alpha,
+            lmbd=self.lmbd, bpreg=self.bpreg, logq=self.logq, sample_alpha=self.sample_alpha, smoothing=float(self.smoothing),
             dropout_p_hidden=self.dropout_p_hidden, dropout_p_embed=self.dropout_p_embed,
             sample_store=int(sample_store), seed=int(self.seed) + 7919 * rank, device=int(self.device),
             rank=rank, nranks=nranks, use_graph=1 if self.use_graph else 0)

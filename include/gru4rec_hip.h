@@ -27,10 +27,12 @@ extern "C" {
 #define G4R_MAX_LAYERS 8
 
 /* gru4rec.py:136-143 (set_loss_function) */
-enum { G4R_LOSS_XE = 0, G4R_LOSS_BPR_MAX = 1, G4R_LOSS_TOP1_MAX = 2 };
+enum { G4R_LOSS_XE = 0, G4R_LOSS_BPR_MAX = 1, G4R_LOSS_TOP1_MAX = 2, G4R_LOSS_BPR = 3, G4R_LOSS_TOP1 = 4,
+       G4R_LOSS_XE_LOGIT = 5 };
 /* gru4rec.py:144-161 (set_final_activation / set_hidden_activation) */
 enum { G4R_ACT_LINEAR = 0, G4R_ACT_RELU = 1, G4R_ACT_TANH = 2, G4R_ACT_LEAKY = 3, G4R_ACT_ELU = 4,
-       G4R_ACT_SELU = 5, G4R_ACT_SOFTMAX = 6 };
+       G4R_ACT_SELU = 5, G4R_ACT_SOFTMAX = 6, G4R_ACT_SOFTMAX_LOGIT = 7 /* final activation only; plain softmax when
+       predicting, gru4rec.py:490-491,499-500 */ };
 /* gru4rec.py:438-470: where the GRU input comes from */
 enum { G4R_EMBED_CONSTRAINED = 0 /* Wy shared, :438-448 */, G4R_EMBED_SEPARATE = 1 /* E, :449-456 */ };
 /* evaluation.py:62-65 */
@@ -57,7 +59,8 @@ typedef struct g4r_config {
     int32_t device;              /* HIP device ordinal */
     int32_t rank, nranks;        /* data-parallel rank layout (1 process per GPU) */
     int32_t use_graph;           /* capture steady-state steps into a hipGraph */
-    int32_t reserved[7];
+    float   smoothing;           /* label smoothing of cross-entropy / xe_logit, gru4rec.py:226-235 */
+    int32_t reserved[6];
 } g4r_config;
 
 typedef struct g4r_model g4r_model;

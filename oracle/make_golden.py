@@ -45,6 +45,16 @@ SCENARIOS = {
                                   n_epochs=1, batch_size=6, dropout_p_embed=0.0, dropout_p_hidden=0.0,
                                   learning_rate=0.1, momentum=0.0, n_sample=0, embedding=8,
                                   constrained_embedding=False),
+    'bpr_linear': dict(loss='bpr', final_act='linear', hidden_act='tanh', layers=[12], n_epochs=2, batch_size=8,
+                       dropout_p_embed=0.0, dropout_p_hidden=0.0, learning_rate=0.1, momentum=0.0, n_sample=16,
+                       sample_alpha=0.5, constrained_embedding=True),
+    'top1_tanh': dict(loss='top1', final_act='tanh', hidden_act='tanh', layers=[12], n_epochs=2, batch_size=8,
+                      dropout_p_embed=0.0, dropout_p_hidden=0.2, learning_rate=0.1, momentum=0.1, n_sample=16,
+                      sample_alpha=0.75, constrained_embedding=True),
+    'xelogit_smoothing': dict(loss='xe_logit', final_act='softmax_logit', hidden_act='tanh', layers=[12], n_epochs=2,
+                              batch_size=8, dropout_p_embed=0.0, dropout_p_hidden=0.0, learning_rate=0.2,
+                              momentum=0.0, n_sample=16, sample_alpha=0.5, smoothing=0.1, logq=1.0,
+                              constrained_embedding=True),
 }
 SAMPLE_STORE_ROWS = 9        # generate_length: small, so that the store is refilled several times
 

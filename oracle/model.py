@@ -90,6 +90,11 @@ def softmax_rows(s, colmask):
 def final_act_fwd(kind, p0, p1, s, colmask):
     if kind == 'softmax':
         return softmax_rows(s, colmask)
+    if kind == 'softmax_logit':      # gru4rec.py:196-198: log(sum exp(X - max)) - (X - max)
+        neg = np.where(colmask[None, :], s, -np.inf)
+        x = s - neg.max(axis=1, keepdims=True)
+        e = np.where(colmask[None, :], np.exp(x), 0).astype(s.dtype)
+        return (np.log(e.sum(axis=1, keepdims=True)) - x).astype(s.dtype)
     return act_fwd(kind, p0, p1, s)
 
 
@@ -98,10 +103,17 @@ def final_act_bwd(kind, p0, p1, s, yhat, dyhat, colmask):
         d = np.where(colmask[None, :], dyhat, 0).astype(s.dtype)
         inner = (d * yhat).sum(axis=1, keepdims=True)
         return yhat * (d - inner)
+    if kind == 'softmax_logit':      # yhat_j = lse - x_j  =>  dx_k = softmax_k * sum_j d_j - d_k, softmax_k = exp(-yhat_k)
+        d = np.where(colmask[None, :], dyhat, 0).astype(s.dtype)
+        return (np.exp(-yhat) * d.sum(axis=1, keepdims=True) - d).astype(s.dtype)
     return dyhat * act_bwd(kind, p0, p1, s, yhat)
 
 
-def loss_fwd_bwd(loss, yhat, M, diag_cols, colmask, bpreg):
+def softplus(x):
+    return np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x)))
+
+
+def loss_fwd_bwd(loss, yhat, M, diag_cols, colmask, bpreg, smoothing=0.0):
     """Return (sum of per-row losses, d/d yhat).  Rows 0..M-1; row i's positive is column diag_cols[i].
 
     softmax_neg restates gru4rec.py:199-203: the positive is masked out *after* being zeroed, the row
@@ -114,11 +126,35 @@ def loss_fwd_bwd(loss, yhat, M, diag_cols, colmask, bpreg):
     hm[rows, diag_cols] = 0
     hm = hm * colmask[None, :].astype(yhat.dtype)
     ydiag = yhat[rows, diag_cols][:, None]
-    if loss == 'cross-entropy':
-        L = -np.log(ydiag[:, 0] + dt(EPS_LOSS))
-        d = np.zeros_like(yhat)
-        d[rows, diag_cols] = -dt(1) / (ydiag[:, 0] + dt(EPS_LOSS))
-        return L.sum(dtype=yhat.dtype), d
+    cm = colmask[None, :].astype(yhat.dtype)
+    n_out = dt(colmask.sum())
+    if loss in ('cross-entropy', 'xe_logit'):
+        # cross_entropy :225-230 / cross_entropy_logits :231-236, label smoothing included
+        lg = loss == 'xe_logit'
+        wd = dt(1) - n_out / (n_out - dt(1)) * dt(smoothing) if smoothing else dt(1)
+        wa = dt(smoothing) / (n_out - dt(1)) if smoothing else dt(0)
+        l_all = yhat if lg else -np.log(yhat + dt(EPS_LOSS))
+        dl_all = np.ones_like(yhat) if lg else -dt(1) / (yhat + dt(EPS_LOSS))
+        L = wd * l_all[rows, diag_cols] + wa * (l_all * cm).sum(axis=1)
+        d = wa * dl_all * cm
+        d[rows, diag_cols] += wd * dl_all[rows, diag_cols]
+        return L.sum(dtype=yhat.dtype), d.astype(yhat.dtype)
+    if loss == 'bpr':
+        # bpr :237-238: -log sigmoid(yd - y_j) summed over ALL columns (the diagonal contributes log 2, no gradient)
+        L = (softplus(yhat - ydiag) * cm).sum(axis=1)
+        d = sigmoid(yhat - ydiag) * hm
+        d[rows, diag_cols] = -d.sum(axis=1)
+        return L.sum(dtype=yhat.dtype), d.astype(yhat.dtype)
+    if loss == 'top1':
+        # top1 :242-244: mean_j(sigmoid(y_j - yd) + sigmoid(y_j^2)) - sigmoid(yd^2) / n.  As written in the reference the
+        # mean is a vector (M,) and the subtracted term a column (M, 1) (gpu_diag(..., keepdims=True)), so the
+        # difference broadcasts to (M, M) before T.sum: the reference's cost is M times the per-row formula.  Kept.
+        u = sigmoid(yhat - ydiag)
+        q = sigmoid(yhat * yhat)
+        L = (((u + q) * hm).sum(axis=1) + dt(0.5)) / n_out
+        d = (u * (dt(1) - u) + dt(2) * yhat * q * (dt(1) - q)) * hm / n_out
+        d[rows, diag_cols] = -((u * (dt(1) - u)) * hm).sum(axis=1) / n_out
+        return dt(M) * L.sum(dtype=yhat.dtype), (dt(M) * d).astype(yhat.dtype)
     if loss in ('bpr-max', 'top1-max'):
         X = yhat * hm
         Xm = np.where(colmask[None, :], X, -np.inf)
@@ -156,7 +192,7 @@ class OracleGRU4Rec:
                  hidden_act='tanh', n_sample=2048, sample_alpha=0.75, learning_rate=0.1, momentum=0.0,
                  lmbd=0.0, bpreg=1.0, logq=0.0, dropout_p_hidden=0.0, dropout_p_embed=0.0,
                  constrained_embedding=False, embedding=0, sigma=0.0, init_as_normal=False,
-                 dtype=np.float32, seed=12345):
+                 dtype=np.float32, seed=12345, smoothing=0.0):
         self.n_items = n_items
         self.layers = list(layers)
         self.batch_size = batch_size
@@ -169,6 +205,7 @@ class OracleGRU4Rec:
         self.momentum = momentum
         self.lmbd = lmbd
         self.bpreg = bpreg
+        self.smoothing = smoothing
         self.logq = logq
         self.dropout_p_hidden = dropout_p_hidden
         self.dropout_p_embed = dropout_p_embed
@@ -346,7 +383,7 @@ class OracleGRU4Rec:
         colmask = np.ones(N, dtype=bool)
         yhat = final_act_fwd(*self.final_act, s, colmask).astype(self.dtype)
         diag = np.arange(M)
-        Lsum, dyhat = loss_fwd_bwd(self.loss, yhat, M, diag, colmask, self.bpreg)
+        Lsum, dyhat = loss_fwd_bwd(self.loss, yhat, M, diag, colmask, self.bpreg, self.smoothing)
         cost = dt(Lsum) / dt(B)
         # ---- backward (T.grad, gru4rec.py:383-384)
         ds = (final_act_bwd(*self.final_act, s, yhat, dyhat, colmask) / dt(B)).astype(self.dtype)

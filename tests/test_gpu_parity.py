@@ -59,6 +59,7 @@ def make_pair(I, B, ns, store_rows, seed=3, **kw):
         hidden_act=_native.ACT_IDS[ha[0]], hidden_act_p0=ha[1], hidden_act_p1=ha[2],
         embed_mode=0 if o.constrained_embedding else 1, embedding=int(o.embedding or 0),
         learning_rate=o.learning_rate, momentum=o.momentum, lmbd=o.lmbd, bpreg=o.bpreg, logq=o.logq,
+        smoothing=float(o.smoothing),
         sample_alpha=o.sample_alpha, dropout_p_hidden=o.dropout_p_hidden, dropout_p_embed=o.dropout_p_embed,
         sample_store=store_rows * ns if ns else 0, seed=seed, device=0, rank=0, nranks=1,
         use_graph=use_graph)
@@ -136,6 +137,13 @@ CASES = {
     'bprmax_relu_sep2': dict(loss='bpr-max', final_act='relu', hidden_act='relu', constrained_embedding=False,
                              embedding=8, layers=(8, 8), lmbd=0.01),
     'bprmax_softmax': dict(loss='bpr-max', final_act='softmax', constrained_embedding=True, layers=(12,)),
+    'bpr_linear': dict(loss='bpr', final_act='linear', constrained_embedding=True, layers=(12,)),
+    'top1_tanh_mom': dict(loss='top1', final_act='tanh', constrained_embedding=True, layers=(12,), momentum=0.1),
+    'xelogit_smooth': dict(loss='xe_logit', final_act='softmax_logit', constrained_embedding=True, layers=(12,),
+                           smoothing=0.1, logq=1.0),
+    'xe_smooth_sep': dict(loss='cross-entropy', final_act='softmax', constrained_embedding=False, embedding=8,
+                          layers=(12,), smoothing=0.2),
+    'xelogit_elu': dict(loss='xe_logit', final_act='elu-1.0', constrained_embedding=True, layers=(12,)),
 }
 
 
@@ -318,7 +326,7 @@ def test_wide_layer_and_big_batch():
     assert not errs, errs
 
 
-@pytest.mark.parametrize('name', ['bprmax_elu', 'xe_softmax_logq', 'top1max_2layer', 'xe_sep_embed'])
+@pytest.mark.parametrize('name', ['bprmax_elu', 'xe_softmax_logq', 'top1max_2layer', 'xe_sep_embed', 'xelogit_smooth'])
 def test_predict_and_ranks(name):
     kw = CASES[name]
     I, B = 300, 24

@@ -47,6 +47,9 @@ def torch_forward_cost(o, P, in_idx, Yp, M, masks):
     if kind == 'softmax':
         e = torch.exp(s - s.max(dim=1, keepdim=True).values)
         yhat = e / e.sum(dim=1, keepdim=True)
+    elif kind == 'softmax_logit':      # gru4rec.py:196-198
+        x = s - s.max(dim=1, keepdim=True).values
+        yhat = torch.log(torch.exp(x).sum(dim=1, keepdim=True)) - x
     elif kind == 'elu':
         yhat = torch.where(s >= 0, s, p0 * (torch.exp(s) - 1))
     elif kind == 'tanh':
@@ -57,8 +60,21 @@ def torch_forward_cost(o, P, in_idx, Yp, M, masks):
         yhat = s
     N = s.shape[1]
     diag = torch.diagonal(yhat)[:, None]
-    if o.loss == 'cross-entropy':
-        cost = (-torch.log(diag[:, 0] + EPS_LOSS)).sum()
+    n_out = M + o.n_sample
+    sm = o.smoothing
+    if o.loss == 'cross-entropy':      # gru4rec.py:225-230
+        cost = (-torch.log(diag[:, 0] + EPS_LOSS)).sum() if not sm else \
+            ((1.0 - (n_out / (n_out - 1)) * sm) * (-torch.log(diag[:, 0] + EPS_LOSS))
+             + (sm / (n_out - 1)) * (-torch.log(yhat + EPS_LOSS)).sum(dim=1)).sum()
+    elif o.loss == 'xe_logit':         # :231-236
+        cost = diag[:, 0].sum() if not sm else \
+            ((1.0 - (n_out / (n_out - 1)) * sm) * diag[:, 0] + (sm / (n_out - 1)) * yhat.sum(dim=1)).sum()
+    elif o.loss == 'bpr':              # :237-238
+        cost = (-torch.log(torch.sigmoid(diag - yhat))).sum()
+    elif o.loss == 'top1':             # :242-244
+        # exactly as written: a (M,) vector minus a (M, 1) column broadcasts to (M, M) before the sum
+        cost = ((torch.sigmoid(-diag + yhat) + torch.sigmoid(yhat ** 2)).mean(dim=1)
+                - torch.sigmoid(diag ** 2) / n_out).sum()
     else:
         hm = 1.0 - torch.eye(M, N, dtype=s.dtype)
         X = yhat * hm
@@ -81,6 +97,11 @@ CASES = [
     dict(loss='cross-entropy', final_act='softmax', constrained_embedding=False, embedding=10, layers=(12,)),
     dict(loss='bpr-max', final_act='relu', hidden_act='relu', constrained_embedding=False, embedding=6,
          layers=(8, 8)),
+    dict(loss='bpr', final_act='linear', constrained_embedding=True, layers=(12,)),
+    dict(loss='top1', final_act='tanh', constrained_embedding=True, layers=(12,)),
+    dict(loss='xe_logit', final_act='softmax_logit', constrained_embedding=True, layers=(12,), smoothing=0.1),
+    dict(loss='xe_logit', final_act='softmax_logit', constrained_embedding=False, embedding=8, layers=(12,)),
+    dict(loss='cross-entropy', final_act='softmax', constrained_embedding=True, layers=(12,), smoothing=0.2, logq=1.0),
 ]
 
 
