@@ -15,7 +15,7 @@ G4R_MAX_LAYERS = 8
 LOSS_IDS = {'cross-entropy': 0, 'bpr-max': 1, 'top1-max': 2, 'bpr': 3, 'top1': 4, 'xe_logit': 5}
 ACT_IDS = {'linear': 0, 'relu': 1, 'tanh': 2, 'leaky': 3, 'elu': 4, 'selu': 5, 'softmax': 6, 'softmax_logit': 7}
 RANK_MODES = {'standard': 0, 'conservative': 1, 'median': 2}
-EMBED_CONSTRAINED, EMBED_SEPARATE = 0, 1
+EMBED_CONSTRAINED, EMBED_SEPARATE, EMBED_ONEHOT = 0, 1, 2
 
 
 class G4RConfig(C.Structure):

@@ -147,8 +147,10 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
             return fail("layer sizes must be multiples of 4 in [4, 512]");
     if (cfg->embed_mode == G4R_EMBED_SEPARATE && (cfg->embedding % 4 != 0 || cfg->embedding < 4 || cfg->embedding > 512))
         return fail("embedding must be a multiple of 4 in [4, 512]");
-    if (cfg->embed_mode != G4R_EMBED_CONSTRAINED && cfg->embed_mode != G4R_EMBED_SEPARATE)
+    if (cfg->embed_mode != G4R_EMBED_CONSTRAINED && cfg->embed_mode != G4R_EMBED_SEPARATE && cfg->embed_mode != G4R_EMBED_ONEHOT)
         return fail("unsupported embedding mode");
+    if (cfg->embed_mode == G4R_EMBED_ONEHOT && 3 * cfg->layers[0] > 512)
+        return fail("one-hot input: 3 * layers[0] must be <= 512 (row width of the Wx[0] table)");
     if (cfg->loss < 0 || cfg->loss > G4R_LOSS_XE_LOGIT) return fail("unsupported loss");
     if (cfg->smoothing != 0.f && cfg->loss != G4R_LOSS_XE && cfg->loss != G4R_LOSS_XE_LOGIT) return fail("smoothing needs a cross-entropy loss");
     if (cfg->hidden_act == G4R_ACT_SOFTMAX_LOGIT) return fail("softmax_logit is not a hidden activation");
@@ -182,11 +184,12 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     d.drop_h = cfg->dropout_p_hidden; d.drop_e = cfg->dropout_p_embed;
     d.seed = cfg->seed;
     d.Dtop = cfg->layers[L - 1];
-    d.Ein = (cfg->embed_mode == G4R_EMBED_CONSTRAINED) ? d.Dtop : cfg->embedding;
+    // width of the layer-0 input rows: shared Wy rows, E rows, or (one-hot input) rows of Wx[0] = [cand|r|z] pre-activations
+    d.Ein = (cfg->embed_mode == G4R_EMBED_CONSTRAINED) ? d.Dtop : (cfg->embed_mode == G4R_EMBED_ONEHOT ? 3 * cfg->layers[0] : cfg->embedding);
     int off = 0;
     for (int l = 0; l < L; ++l) {
         d.D[l] = cfg->layers[l];
-        d.IN[l] = (l == 0) ? d.Ein : cfg->layers[l - 1];
+        d.IN[l] = (l == 0) ? (cfg->embed_mode == G4R_EMBED_ONEHOT ? 0 : d.Ein) : cfg->layers[l - 1];
         d.offWx[l] = off; off += d.IN[l] * 3 * d.D[l];
         d.offWh[l] = off; off += d.D[l] * d.D[l];
         d.offWrz[l] = off; off += d.D[l] * 2 * d.D[l];
@@ -201,7 +204,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     DA(d.dense_p, off); DA(d.dense_acc, off); DA(d.dense_vel, off); DA(d.dense_g, off);
     DA(d.Wy, I * d.Dtop); DA(d.accWy, I * d.Dtop); DA(d.By, I); DA(d.accBy, I);
     if (cfg->momentum > 0.f) { DA(d.velWy, I * d.Dtop); DA(d.velBy, I); }
-    if (cfg->embed_mode == G4R_EMBED_SEPARATE) {
+    if (cfg->embed_mode != G4R_EMBED_CONSTRAINED) {     // E table, or Wx[0] as a row table (one-hot input)
         DA(d.E, I * d.Ein); DA(d.accE, I * d.Ein);
         if (cfg->momentum > 0.f) DA(d.velE, I * d.Ein);
     }
@@ -220,7 +223,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     DA(d.dAx, (size_t)B * d.Ein); DA(d.dAy, (size_t)d.ldSc * d.Dtop); DA(d.dABy, d.ldSc);
     DA(d.lossrow, B);
     DA(d.occ_idx, d.R + 64); DA(d.col_item, d.ldSc);
-    DA(d.occ_fl, (size_t)(cfg->embed_mode == G4R_EMBED_SEPARATE ? 2 : 1) * I * 4);
+    DA(d.occ_fl, (size_t)(cfg->embed_mode != G4R_EMBED_CONSTRAINED ? 2 : 1) * I * 4);
     DA(d.st, 1);
     // scoring backward geometry: role A tiles (n x d, one spare d column for dSBy), role B tiles (b x d x k-chunk)
     {
@@ -314,10 +317,12 @@ static int locate(g4r_model* m, const char* name, int layer, float** p, int64_t*
     bool want_acc = false, want_vel = false;
     if (s.rfind("acc_", 0) == 0) { want_acc = true; s = s.substr(4); }
     else if (s.rfind("vel_", 0) == 0) { want_vel = true; s = s.substr(4); }
-    if (want_vel && m->cfg.momentum <= 0.f && (s == "Wy" || s == "By" || s == "E")) return fail("no velocity state without momentum");
+    if (want_vel && m->cfg.momentum <= 0.f && (s == "Wy" || s == "By" || s == "E" || (d.embed_mode == G4R_EMBED_ONEHOT && s == "Wx" && layer == 0)))
+        return fail("no velocity state without momentum");
     const int64_t I = d.n_items;
     if (s == "Wy") { *p = want_acc ? d.accWy : (want_vel ? d.velWy : d.Wy); *n = I * d.Dtop; return 0; }
     if (s == "By") { *p = want_acc ? d.accBy : (want_vel ? d.velBy : d.By); *n = I; return 0; }
+    if (d.embed_mode == G4R_EMBED_ONEHOT && s == "Wx" && layer == 0) s = "E";    // Wx[0] is the (I, 3D) row table
     if (s == "E") {
         if (!d.E) return fail("model has no separate embedding");
         *p = want_acc ? d.accE : (want_vel ? d.velE : d.E); *n = I * d.Ein; return 0;
@@ -565,7 +570,8 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         LK(k_gru_bwd_a, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_NT, s, dmp, stp, l);
         end();
         begin(KN_BWD_B);
-        LK(k_gru_bwd_b, dim3(cdiv(d.IN[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_BB, s, dmp, stp, l);
+        if (l == 0 && d.embed_mode == G4R_EMBED_ONEHOT) LK(k_onehot_step, dim3(cdiv((long long)B * d.Ein, 4 * 256)), dim3(256), 0, s, dmp, stp);
+        else LK(k_gru_bwd_b, dim3(cdiv(d.IN[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_BB, s, dmp, stp, l);
         end();
     }
     begin(KN_DENSE);

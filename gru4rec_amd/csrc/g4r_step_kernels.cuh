@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void k_gru_p1(const DevModel* __restrict__ mp,
     if (m0 >= M) return;
     __syncthreads();
     const GAS float* table = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.Wy : m.E;
+    const bool onehot = (l == 0 && m.embed_mode == G4R_EMBED_ONEHOT);    // V = Wx[0][X] + Bh + (0 | H Wrz), gru4rec.py:458-460
     const GAS float* Wx = m.dense_p + m.offWx[l];
     const GAS float* Wrz = m.dense_p + m.offWrz[l];
     const GAS float* Bh = m.dense_p + m.offBh[l];
@@ -125,11 +126,12 @@ __global__ __launch_bounds__(256) void k_gru_p1(const DevModel* __restrict__ mp,
     };
     auto pre = [&](int row, int n) -> float4 {      // bias and (for the r block) the hidden value
         const bool ok = row < M && n < D3;
-        return make_float4(ldf_if(Bh, n, ok), ldf_if(Hcur, (size_t)row * D + (n - D), ok && n >= D && n < 2 * D), 0.f, 0.f);
+        const float oh = onehot ? ldf_if(table, (size_t)max(sRow[row - m0], 0) * D3 + n, ok) : 0.f;
+        return make_float4(ldf_if(Bh, n, ok), ldf_if(Hcur, (size_t)row * D + (n - D), ok && n >= D && n < 2 * D), oh, 0.f);
     };
     auto epi = [&](int row, int n, float v, float4 p) {
         if (row >= M || n >= D3) return;
-        v += p.x;
+        v += p.x + p.z;
         if (n < D) { Vc[(size_t)row * D + n] = v; return; }
         if (n < 2 * D) {
             const size_t o = (size_t)row * D + (n - D);
@@ -676,6 +678,26 @@ __global__ __launch_bounds__(256) void k_gru_bwd_b(const DevModel* __restrict__ 
 // One 16x16 output tile of a dense GRU gradient, resolved on the host: out[r0.., c0..] (leading dim ldo, at
 // float offset `base` of the flat dense buffers) = X^T[., batch] * dV[batch, coff + .] ; X0/X1 = operand for
 // even/odd global step (the hidden state ping-pongs) ; X == nullptr selects the bias row (column sums of dV).
+// One-hot input (gru4rec.py:457-470): the layer-0 "input rows" are rows of Wx[0] itself, so their gradient is dV of
+// layer 0 as it stands (no dy GEMM, no embedding dropout).  This turns it into the per-occurrence Adagrad step and
+// new accumulator rows for k_sparse_update, like the epilogue of k_gru_bwd_b does for E / Wy rows.
+__global__ __launch_bounds__(256) void k_onehot_step(const DevModel* __restrict__ mp, StepState* st) {
+    const DevModel& m = *mp;
+    const StepCtx c = load_ctx(st);
+    const int W = m.Ein, nc4 = W >> 2;
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int row = (int)(q / nc4), c4 = (int)(q % nc4);
+    if (row >= c.M) return;
+    const int item = m.occ_idx[row];
+    const float lr = m.lr;
+    const float4 g = ld4(m.dV[0] + (size_t)row * W + 4 * c4);
+    const float4 a = ld4(m.accE + (size_t)item * W + 4 * c4);
+    const float4 an = make_float4(a.x + g.x * g.x, a.y + g.y * g.y, a.z + g.z * g.z, a.w + g.w * g.w);
+    st4(m.dAx + (size_t)row * W + 4 * c4, an);
+    st4(m.dSx + (size_t)row * W + 4 * c4, make_float4(lr * g.x * frsq(an.x + G4R_EPS_ADAGRAD), lr * g.y * frsq(an.y + G4R_EPS_ADAGRAD),
+                                                         lr * g.z * frsq(an.z + G4R_EPS_ADAGRAD), lr * g.w * frsq(an.w + G4R_EPS_ADAGRAD)));
+}
+
 struct DenseTile {
     GP(const float) X0; GP(const float) X1; GP(const float) dV;
     long long base;

@@ -179,9 +179,9 @@ class GRU4Rec:
             raise NotImplementedError('grad_cap is outside the MI355X hot path')
         if self.smoothing and self.loss not in ('cross-entropy', 'xe_logit'):
             raise NotImplementedError('smoothing is only defined for cross-entropy / xe_logit (gru4rec.py:226-235)')
-        if not self.constrained_embedding and not self.embedding:
-            raise NotImplementedError('one-hot input (embedding=0, constrained_embedding=False) is not in the MI355X path yet; '
-                                      'use constrained_embedding=True or embedding=<size>')
+        if not self.constrained_embedding and not self.embedding and 3 * self.layers[0] > 512:
+            raise NotImplementedError('one-hot input (embedding=0, constrained_embedding=False) needs 3 * layers[0] <= 512 '
+                                      'in the MI355X path; use constrained_embedding=True or embedding=<size> for wider layers')
 
     def _create_model(self, sample_store, batch_size=None):
         self._check_supported()
@@ -192,7 +192,8 @@ class GRU4Rec:
             n_sample=int(self.n_sample), loss=self._loss_id,
             final_act=self._final[0], final_act_p0=self._final[1], final_act_p1=self._final[2],
             hidden_act=self._hidden[0], hidden_act_p0=self._hidden[1], hidden_act_p1=self._hidden[2],
-            embed_mode=_native.EMBED_CONSTRAINED if self.constrained_embedding else _native.EMBED_SEPARATE,
+            embed_mode=_native.EMBED_CONSTRAINED if self.constrained_embedding else (
+                _native.EMBED_SEPARATE if self.embedding else _native.EMBED_ONEHOT),
             embedding=int(self.embedding or 0), learning_rate=self.learning_rate, momentum=self.momentum,
             lmbd=self.lmbd, bpreg=self.bpreg, logq=self.logq, sample_alpha=self.sample_alpha, smoothing=float(self.smoothing),
             dropout_p_hidden=self.dropout_p_hidden, dropout_p_embed=self.dropout_p_embed,

@@ -34,7 +34,8 @@ enum { G4R_ACT_LINEAR = 0, G4R_ACT_RELU = 1, G4R_ACT_TANH = 2, G4R_ACT_LEAKY = 3
        G4R_ACT_SELU = 5, G4R_ACT_SOFTMAX = 6, G4R_ACT_SOFTMAX_LOGIT = 7 /* final activation only; plain softmax when
        predicting, gru4rec.py:490-491,499-500 */ };
 /* gru4rec.py:438-470: where the GRU input comes from */
-enum { G4R_EMBED_CONSTRAINED = 0 /* Wy shared, :438-448 */, G4R_EMBED_SEPARATE = 1 /* E, :449-456 */ };
+enum { G4R_EMBED_CONSTRAINED = 0 /* Wy shared, :438-448 */, G4R_EMBED_SEPARATE = 1 /* E, :449-456 */,
+       G4R_EMBED_ONEHOT = 2 /* no embedding, layer 0 reads rows of Wx[0] (I x 3D), :457-470; the constructor default */ };
 /* evaluation.py:62-65 */
 enum { G4R_RANK_STANDARD = 0, G4R_RANK_CONSERVATIVE = 1, G4R_RANK_MEDIAN = 2 };
 

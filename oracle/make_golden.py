@@ -45,6 +45,9 @@ SCENARIOS = {
                                   n_epochs=1, batch_size=6, dropout_p_embed=0.0, dropout_p_hidden=0.0,
                                   learning_rate=0.1, momentum=0.0, n_sample=0, embedding=8,
                                   constrained_embedding=False),
+    'onehot_default': dict(loss='bpr-max', final_act='elu-0.5', hidden_act='tanh', layers=[12], n_epochs=2, batch_size=8,
+                           dropout_p_embed=0.0, dropout_p_hidden=0.2, learning_rate=0.1, momentum=0.1, n_sample=16,
+                           sample_alpha=0.75, bpreg=1.0, constrained_embedding=False, embedding=0),
     'bpr_linear': dict(loss='bpr', final_act='linear', hidden_act='tanh', layers=[12], n_epochs=2, batch_size=8,
                        dropout_p_embed=0.0, dropout_p_hidden=0.0, learning_rate=0.1, momentum=0.0, n_sample=16,
                        sample_alpha=0.5, constrained_embedding=True),

@@ -217,8 +217,8 @@ class OracleGRU4Rec:
         self.seed = seed
         self.global_step = 0
         self.ST = None
-        if not constrained_embedding and not embedding:
-            raise NotImplementedError('one-hot input (no embedding) mode is not restated yet')
+        # no embedding at all (the constructor default): layer 0 reads rows of Wx[0] (I x 3D), gru4rec.py:457-470
+        self.onehot = (not constrained_embedding) and (not embedding)
         self._init_weights()
 
     # -- gru4rec.py:252-260
@@ -235,9 +235,11 @@ class OracleGRU4Rec:
         self.E = None
         if self.constrained_embedding:
             n_features = L[-1]
-        else:
+        elif self.embedding:
             self.E = self._init_matrix((self.n_items, self.embedding))
             n_features = self.embedding
+        else:
+            n_features = self.n_items        # gru4rec.py:278
         self.Wx, self.Wh, self.Wrz, self.Bh, self.H = [], [], [], [], []
         for i in range(len(L)):
             n_in = L[i - 1] if i > 0 else n_features
@@ -316,9 +318,10 @@ class OracleGRU4Rec:
         return self.ST[k % self.generate_length].astype(np.int64)
 
     # ------------------------------------------------------------------ forward pieces
-    def _gru_fwd(self, i, y, H):
+    def _gru_fwd(self, i, y, H, rows=None):
         D = self.layers[i]
-        V = y @ self.Wx[i] + self.Bh[i]
+        # rows: one-hot input, the "product" with Wx[0] is a row gather (gru4rec.py:458-459)
+        V = (self.Wx[i][rows] if rows is not None else y @ self.Wx[i]) + self.Bh[i]
         G = H @ self.Wrz[i]
         rz = sigmoid(V[:, D:] + G)
         r, z = rz[:, :D], rz[:, D:]
@@ -351,6 +354,9 @@ class OracleGRU4Rec:
             Xc = np.concatenate([in_idx, Yp])
             S = self.Wy[Xc]
             Sx, Sy = S[:M], S[M:]
+        elif self.onehot:
+            Sx = self.Wx[0][in_idx]          # gru4rec.py:458 (the rows already are x * Wx[0]; no embedding dropout)
+            Sy = self.Wy[Yp]
         else:
             Sx = self.E[in_idx]
             Sy = self.Wy[Yp]
@@ -358,18 +364,18 @@ class OracleGRU4Rec:
         # ---- dropout masks
         if masks is None:
             masks = {'embed': None, 'hidden': [None] * len(L)}
-            if self.dropout_p_embed > 0:
+            if self.dropout_p_embed > 0 and not self.onehot:
                 masks['embed'] = philox.dropout_mask(M, Sx.shape[1], 1 - self.dropout_p_embed, self.seed, step,
                                                      philox.STREAM_DROP_EMBED).astype(self.dtype)
             if self.dropout_p_hidden > 0:
                 for i in range(len(L)):
                     masks['hidden'][i] = philox.dropout_mask(M, L[i], 1 - self.dropout_p_hidden, self.seed, step,
                                                              philox.STREAM_DROP_HIDDEN + i).astype(self.dtype)
-        y = Sx if masks['embed'] is None else Sx * masks['embed']
+        y = Sx if (masks['embed'] is None or self.onehot) else Sx * masks['embed']
         # ---- GRU layers (gru4rec.py:471-479)
         caches = []
         for i in range(len(L)):
-            cch = self._gru_fwd(i, y, self.H[i][:M])
+            cch = self._gru_fwd(i, y, self.H[i][:M], rows=in_idx if (self.onehot and i == 0) else None)
             hd = cch['h'] if masks['hidden'][i] is None else cch['h'] * masks['hidden'][i]
             cch['hd'] = hd
             caches.append(cch)
@@ -407,12 +413,14 @@ class OracleGRU4Rec:
             dzp = dz * z * (1 - z)
             dWrz = H.T @ np.hstack([drp, dzp])
             dV = np.hstack([da, drp, dzp]).astype(self.dtype)
-            dWx = cch['y'].T @ dV
             dBh = dV.sum(axis=0)
-            dy = dV @ self.Wx[i].T
-            dense_grads.append((i, dWx.astype(self.dtype), dWh.astype(self.dtype), dWrz.astype(self.dtype),
-                                dBh.astype(self.dtype)))
-        dSx = dy if masks['embed'] is None else dy * masks['embed']
+            if self.onehot and i == 0:
+                dWx, dy = None, dV            # the gathered rows of Wx[0] receive dV itself (sparse update below)
+            else:
+                dWx = (cch['y'].T @ dV).astype(self.dtype)
+                dy = dV @ self.Wx[i].T
+            dense_grads.append((i, dWx, dWh.astype(self.dtype), dWrz.astype(self.dtype), dBh.astype(self.dtype)))
+        dSx = dy if (masks['embed'] is None or self.onehot) else dy * masks['embed']
         dbg = None
         if return_debug:
             dbg = dict(Sx=Sx, Sy=Sy, s=s, yhat=yhat, ds=ds, dSy=dSy, dSBy=dSBy, dtop=dtop, dSx=dSx,
@@ -428,14 +436,15 @@ class OracleGRU4Rec:
             Hfull[:M] = hn
             newH.append(Hfull)
         for (i, dWx, dWh, dWrz, dBh) in dense_grads:
-            self._dense_update('Wx', i, dWx)
+            if dWx is not None:
+                self._dense_update('Wx', i, dWx)
             self._dense_update('Wh', i, dWh)
             self._dense_update('Wrz', i, dWrz)
             self._dense_update('Bh', i, dBh)
         if self.constrained_embedding:
             self._sparse_update('Wy', Xc, np.vstack([dSx, dSy]).astype(self.dtype))
         else:
-            self._sparse_update('E', in_idx, dSx.astype(self.dtype))
+            self._sparse_update('Wx0' if self.onehot else 'E', in_idx, dSx.astype(self.dtype))
             self._sparse_update('Wy', Yp, dSy.astype(self.dtype))
         self._sparse_update('By', Yp, dSBy.astype(self.dtype))
         self.H = newH
@@ -467,8 +476,10 @@ class OracleGRU4Rec:
         of a duplicated index wins (NumPy/CPU `set_subtensor` semantics; on the GPU the reference's winner is
         unspecified); parameter increments of duplicates accumulate in occurrence order (`inc_subtensor`)."""
         dt = self.dtype.type
-        P = getattr(self, name)
-        acc = self.acc[name]
+        if name == 'Wx0':       # one-hot input: Wx[0] is the sparse-updated (I, 3D) table (gru4rec.py:467-469,578)
+            P, acc, vel = self.Wx[0], self.acc['Wx'][0], self.vel['Wx'][0]
+        else:
+            P, acc, vel = getattr(self, name), self.acc[name], self.vel[name]
         acc_s = acc[idx]
         acc_new = acc_s + g * g
         gs = g / np.sqrt(acc_new + dt(EPS_ADAGRAD))
@@ -479,7 +490,6 @@ class OracleGRU4Rec:
             delta = lr * gs
         acc[idx] = acc_new                                  # last write wins
         if self.momentum > 0:
-            vel = self.vel[name]
             v2 = dt(self.momentum) * vel[idx] - delta
             vel[idx] = v2                                   # last write wins
             np.add.at(P, idx, v2.astype(self.dtype))        # accumulates, occurrence order
@@ -490,10 +500,10 @@ class OracleGRU4Rec:
     def predict_step(self, H_list, in_idx, item_idx=None):
         """Forward only (`predict=True`): no dropout, no logQ, no reset switch.  Returns (scores[M, n], new H)."""
         in_idx = np.asarray(in_idx, dtype=np.int64)
-        y = self.Wy[in_idx] if self.constrained_embedding else self.E[in_idx]
+        y = self.Wy[in_idx] if self.constrained_embedding else (None if self.onehot else self.E[in_idx])
         newH = []
         for i in range(len(self.layers)):
-            cch = self._gru_fwd(i, y, H_list[i])
+            cch = self._gru_fwd(i, y, H_list[i], rows=in_idx if (self.onehot and i == 0) else None)
             y = cch['h']
             newH.append(y)
         if item_idx is None:

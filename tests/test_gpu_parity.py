@@ -57,7 +57,7 @@ def make_pair(I, B, ns, store_rows, seed=3, **kw):
         n_items=I, layers=list(o.layers), batch_size=B, n_sample=ns, loss=_native.LOSS_IDS[o.loss],
         final_act=_native.ACT_IDS[fa[0]], final_act_p0=fa[1], final_act_p1=fa[2],
         hidden_act=_native.ACT_IDS[ha[0]], hidden_act_p0=ha[1], hidden_act_p1=ha[2],
-        embed_mode=0 if o.constrained_embedding else 1, embedding=int(o.embedding or 0),
+        embed_mode=0 if o.constrained_embedding else (1 if o.embedding else 2), embedding=int(o.embedding or 0),
         learning_rate=o.learning_rate, momentum=o.momentum, lmbd=o.lmbd, bpreg=o.bpreg, logq=o.logq,
         smoothing=float(o.smoothing),
         sample_alpha=o.sample_alpha, dropout_p_hidden=o.dropout_p_hidden, dropout_p_embed=o.dropout_p_embed,
@@ -144,6 +144,10 @@ CASES = {
     'xe_smooth_sep': dict(loss='cross-entropy', final_act='softmax', constrained_embedding=False, embedding=8,
                           layers=(12,), smoothing=0.2),
     'xelogit_elu': dict(loss='xe_logit', final_act='elu-1.0', constrained_embedding=True, layers=(12,)),
+    # one-hot input (the reference's constructor default: no embedding, layer 0 reads rows of Wx[0])
+    'onehot_bprmax': dict(loss='bpr-max', final_act='elu-0.5', layers=(12,), momentum=0.2),
+    'onehot_xe_2layer': dict(loss='cross-entropy', final_act='softmax', layers=(8, 12), dropout_p_hidden=0.2, dropout_p_embed=0.3,
+                             lmbd=0.01),
 }
 
 
@@ -183,7 +187,7 @@ def test_first_step_intermediates(name):
     ks = int(m.get_debug('ksplit', (1,))[0])
     dhp = m.get_debug('dhpart', (ks, B, o.layers[-1])).sum(axis=0)
     close('dh_top', dhp[:M], dbg['dtop'], atol=1e-6, rtol=1e-3, errs=errs)
-    n_in = o.layers[-1] if o.constrained_embedding else o.embedding
+    n_in = o.layers[-1] if o.constrained_embedding else (o.embedding or 3 * o.layers[0])
     close('dSx(step)', m.get_debug('dSx', (B, n_in))[:M], step_of(dbg['dSx']), atol=2e-6, rtol=2e-3, errs=errs)
     close('cost', m.get_losses(0, 1), [cost], atol=2e-6, rtol=2e-4, errs=errs)
     compare_params(o, m, errs, 'p1', Mrows=M)
@@ -326,7 +330,7 @@ def test_wide_layer_and_big_batch():
     assert not errs, errs
 
 
-@pytest.mark.parametrize('name', ['bprmax_elu', 'xe_softmax_logq', 'top1max_2layer', 'xe_sep_embed', 'xelogit_smooth'])
+@pytest.mark.parametrize('name', ['bprmax_elu', 'xe_softmax_logq', 'top1max_2layer', 'xe_sep_embed', 'xelogit_smooth', 'onehot_bprmax'])
 def test_predict_and_ranks(name):
     kw = CASES[name]
     I, B = 300, 24

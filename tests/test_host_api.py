@@ -62,8 +62,10 @@ def test_reference_paramfiles_load(tmp_path):
 def test_out_of_scope_options_fail_loudly_at_fit():
     data = synth.make_sessions(50, n_items=30, seed=1)
     for kw in (dict(adapt='adam', constrained_embedding=True), dict(grad_cap=1.0, constrained_embedding=True),
-               dict(smoothing=0.1, loss='bpr-max', constrained_embedding=True), dict()):   # last: one-hot input mode
-        g = GRU4Rec(layers=[8], batch_size=4, **kw)
+               dict(smoothing=0.1, loss='bpr-max', constrained_embedding=True),
+               dict(layers=[256])):   # last: one-hot input wider than the 512-float row limit
+        kw.setdefault('layers', [8])
+        g = GRU4Rec(batch_size=4, **kw)
         g.n_items = 30
         with pytest.raises(NotImplementedError):
             g._check_supported()

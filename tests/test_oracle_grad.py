@@ -19,10 +19,11 @@ def torch_forward_cost(o, P, in_idx, Yp, M, masks):
     else:
         Sx = P['Sx']
         Sy = P['Sy']
-    y = Sx if masks['embed'] is None else Sx * torch.tensor(masks['embed'])
+    y = Sx if (masks['embed'] is None or o.onehot) else Sx * torch.tensor(masks['embed'])
     for i, D in enumerate(o.layers):
         H = torch.tensor(o.H[i][:M])
-        V = y @ P['Wx%d' % i] + P['Bh%d' % i]
+        # one-hot input: Sx are the gathered rows of Wx[0] (gru4rec.py:458-459)
+        V = (Sx if (o.onehot and i == 0) else y @ P['Wx%d' % i]) + P['Bh%d' % i]
         rz = torch.sigmoid(V[:, D:] + H @ P['Wrz%d' % i])
         a = (H * rz[:, :D]) @ P['Wh%d' % i] + V[:, :D]
         kind, p0, p1 = o.hidden_act
@@ -98,6 +99,8 @@ CASES = [
     dict(loss='bpr-max', final_act='relu', hidden_act='relu', constrained_embedding=False, embedding=6,
          layers=(8, 8)),
     dict(loss='bpr', final_act='linear', constrained_embedding=True, layers=(12,)),
+    dict(loss='bpr-max', final_act='elu-0.5', layers=(12,)),                          # one-hot input (constructor default)
+    dict(loss='cross-entropy', final_act='softmax', layers=(8, 12), dropout_p_hidden=0.2),   # one-hot, 2 layers
     dict(loss='top1', final_act='tanh', constrained_embedding=True, layers=(12,)),
     dict(loss='xe_logit', final_act='softmax_logit', constrained_embedding=True, layers=(12,), smoothing=0.1),
     dict(loss='xe_logit', final_act='softmax_logit', constrained_embedding=False, embedding=8, layers=(12,)),
@@ -124,7 +127,7 @@ def test_backward_matches_autograd(case, M):
     # masks fixed so that both sides see the same dropout
     from oracle import philox
     masks = {'embed': None, 'hidden': [None] * len(o.layers)}
-    n_in = o.layers[-1] if o.constrained_embedding else o.embedding
+    n_in = o.layers[-1] if o.constrained_embedding else (o.embedding or 3 * o.layers[0])
     if o.dropout_p_embed > 0:
         masks['embed'] = philox.dropout_mask(M, n_in, 1 - o.dropout_p_embed, 7, 0, 1).astype(np.float64)
     if o.dropout_p_hidden > 0:
@@ -134,11 +137,13 @@ def test_backward_matches_autograd(case, M):
     if o.constrained_embedding:
         P['S'] = torch.tensor(o.Wy[np.concatenate([in_idx, Yp])], requires_grad=True)
     else:
-        P['Sx'] = torch.tensor(o.E[in_idx], requires_grad=True)
+        P['Sx'] = torch.tensor((o.Wx[0] if o.onehot else o.E)[in_idx], requires_grad=True)
         P['Sy'] = torch.tensor(o.Wy[Yp], requires_grad=True)
     P['SBy'] = torch.tensor(o.By[Yp], requires_grad=True)
     for i in range(len(o.layers)):
         for n in ('Wx', 'Wh', 'Wrz', 'Bh'):
+            if n == 'Wx' and i == 0 and o.onehot:
+                continue
             P['%s%d' % (n, i)] = torch.tensor(getattr(o, n)[i], requires_grad=True)
     cost_t = torch_forward_cost(o, P, in_idx, Yp, M, masks)
     cost_t.backward()
@@ -153,7 +158,8 @@ def test_backward_matches_autograd(case, M):
         np.testing.assert_allclose(dbg['dSy'], P['Sy'].grad.numpy(), rtol=1e-9, atol=1e-13)
     np.testing.assert_allclose(dbg['dSBy'], P['SBy'].grad.numpy(), rtol=1e-9, atol=1e-13)
     for (i, dWx, dWh, dWrz, dBh) in dbg['dense_grads']:
-        np.testing.assert_allclose(dWx, P['Wx%d' % i].grad.numpy(), rtol=1e-9, atol=1e-13)
+        if dWx is not None:
+            np.testing.assert_allclose(dWx, P['Wx%d' % i].grad.numpy(), rtol=1e-9, atol=1e-13)
         np.testing.assert_allclose(dWh, P['Wh%d' % i].grad.numpy(), rtol=1e-9, atol=1e-13)
         np.testing.assert_allclose(dWrz, P['Wrz%d' % i].grad.numpy(), rtol=1e-9, atol=1e-13)
         np.testing.assert_allclose(dBh, P['Bh%d' % i].grad.numpy(), rtol=1e-9, atol=1e-13)
