@@ -9,6 +9,7 @@ lets the device run whole epochs without a host round trip (libgru4rec_hip.so th
 There is deliberately no CPU fallback.
 """
 import pickle
+import sys
 import time
 from collections import OrderedDict  # noqa: F401  (kept: parameter files use it)
 
@@ -36,6 +37,18 @@ def _parse_act(name, allow_softmax):
                 raise NotImplementedError
             return _native.ACT_IDS[prefix[:-1]], p[0], (p[1] if npar == 2 else 0.0)
     raise NotImplementedError
+
+
+def _markers(*names):
+    """Methods that only carry a name (a bound method pickles as getattr(obj, __name__))."""
+    out = []
+    for name in names:
+        def f(self, *a, **k):
+            raise NotImplementedError('symbolic Theano expression in the reference; computed by the HIP kernels here')
+        f.__name__ = name
+        f.__qualname__ = 'GRU4Rec.' + name
+        out.append(f)
+    return out
 
 
 class GRU4Rec:
@@ -88,17 +101,63 @@ class GRU4Rec:
         self.loss_history = []
 
     # ------------------------------------------------------------------ validation of names
+    # The reference keeps its loss / activation as bound methods (`self.loss_function = self.bpr_max`, gru4rec.py:136-161)
+    # and pickles them with the model (:742-756).  The same attribute names are kept here so that checkpoints travel both
+    # ways (a pickle written by either implementation names `gru4rec.GRU4Rec` and these methods); the methods themselves
+    # are markers: the arithmetic lives in the HIP kernels (k_loss_rows, act_fwd).
+    linear, tanh, softmax, softmax_logit, softmax_neg, relu, sigmoid = _markers(
+        'linear', 'tanh', 'softmax', 'softmax_logit', 'softmax_neg', 'relu', 'sigmoid')
+    cross_entropy, cross_entropy_logits, bpr, bpr_max, top1, top1_max = _markers(
+        'cross_entropy', 'cross_entropy_logits', 'bpr', 'bpr_max', 'top1', 'top1_max')
+
+    class Selu:
+        def __init__(self, lmbd, alpha):
+            self.lmbd, self.alpha = lmbd, alpha
+
+        def execute(self, X):
+            raise NotImplementedError
+
+    class Elu:
+        def __init__(self, alpha):
+            self.alpha = alpha
+
+        def execute(self, X):
+            raise NotImplementedError
+
+    class LeakyReLU:
+        def __init__(self, leak):
+            self.leak = leak
+
+        def execute(self, X):
+            raise NotImplementedError
+
+    _LOSS_METHODS = {'cross-entropy': 'cross_entropy', 'bpr': 'bpr', 'bpr-max': 'bpr_max', 'top1': 'top1',
+                     'top1-max': 'top1_max', 'xe_logit': 'cross_entropy_logits'}
+
+    def _act_callable(self, name):
+        if name in ('linear', 'relu', 'tanh', 'softmax', 'softmax_logit'):
+            return getattr(self, name)
+        p = [float(x) for x in name.split('-')[1:]]
+        if name.startswith('leaky-'):
+            return self.LeakyReLU(p[0]).execute
+        if name.startswith('elu-'):
+            return self.Elu(p[0]).execute
+        return self.Selu(*p).execute
+
     def set_loss_function(self, loss):
         if loss in _native.LOSS_IDS:         # gru4rec.py:136-143
             self._loss_id = _native.LOSS_IDS[loss]
+            self.loss_function = getattr(self, self._LOSS_METHODS[loss])
         else:
             raise NotImplementedError
 
     def set_final_activation(self, final_act):
         self._final = _parse_act(final_act, True)
+        self.final_activation = self._act_callable(final_act)
 
     def set_hidden_activation(self, hidden_act):
         self._hidden = _parse_act(hidden_act, False)
+        self.hidden_activation = self._act_callable(hidden_act)
 
     def set_params(self, **kvargs):
         """String -> typed coercion against the current attribute type, as gru4rec.py:162-187."""
@@ -382,15 +441,27 @@ class GRU4Rec:
                                   'exposes the same computation through gru4rec_amd.evaluation.evaluate_gpu')
 
     # ------------------------------------------------------------------ (de)serialisation (gru4rec.py:742-781)
+    _EXTRAS = dict(seed=12345, device=0, use_graph=True, steps_per_call=16384)     # attributes the reference does not have
+
     def __getstate__(self):
         st = dict(self.__dict__)
-        for k in ('_model', '_plan', '_plan_key', '_data_items', '_offsets', '_base_order', '_dist'):
+        for k in ('_model', '_plan', '_plan_key', '_data_items', '_offsets', '_base_order', '_dist', '_loss_id', '_final', '_hidden'):
             st.pop(k, None)
         st['predict'] = None
         return st
 
     def __setstate__(self, st):
+        """Accepts pickles of this class and of the reference's (whose state lacks the MI355X extras)."""
         self.__dict__.update(st)
+        for k, v in self._EXTRAS.items():
+            self.__dict__.setdefault(k, v)
+        self.__dict__.setdefault('loss_history', [])
+        self.__dict__.setdefault('error_during_train', False)
+        self.set_loss_function(self.loss)
+        self.set_final_activation(self.final_act)
+        self.set_hidden_activation(self.hidden_act)
+        if hasattr(self, 'By') and self.By is not None:
+            self.By = np.asarray(self.By, dtype=np.float32).reshape(-1, 1)
         self._model = None
         self._dist = None
         self.predict = None
@@ -405,7 +476,45 @@ class GRU4Rec:
 
     @classmethod
     def loadmodel(cls, fname):
-        gru = pd.read_pickle(fname)
+        """gru4rec.py:768-781.  Reads checkpoints written by this class and by the reference's `savemodel` (both name the
+        class `gru4rec.GRU4Rec`; the reference's arrays are plain NumPy in the pickle, :744-756)."""
+        class _Opaque:
+            """Stand-in for Theano / pygpu objects inside a reference pickle (sample store, RNG state, compiled
+            functions left on the object after fit): they are rebuilt by fit() / predict here, never read."""
+            def __init__(self, *a, **k):
+                pass
+
+            def __setstate__(self, st):
+                pass
+
+        class _Unpickler(pickle.Unpickler):
+            def find_class(self, module, name):
+                if module.split('.')[0] in ('theano', 'pygpu'):
+                    return _Opaque
+                if module in ('gru4rec', 'gru4rec_amd.gru4rec'):
+                    obj = sys.modules[cls.__module__] if cls.__module__ in sys.modules else None
+                    target = cls
+                    parts = name.split('.')
+                    if parts[0] == 'GRU4Rec':
+                        for part in parts[1:]:
+                            target = getattr(target, part)
+                        return target
+                    if obj is not None and hasattr(obj, name):
+                        return getattr(obj, name)
+                return super().find_class(module, name)
+        with open(fname, 'rb') as f:
+            gru = _Unpickler(f).load()
+        for k in [k for k, v in gru.__dict__.items() if isinstance(v, _Opaque)]:
+            del gru.__dict__[k]
         gru._model = None
         gru.predict = None
         return gru
+
+
+# Checkpoints name the class `gru4rec.GRU4Rec`, exactly like the reference's (gru4rec.py:755), so they load on either side;
+# `gru4rec.py` at the repository root re-exports this class under that module name.
+GRU4Rec.__module__ = 'gru4rec'
+GRU4Rec.__qualname__ = 'GRU4Rec'
+for _c in (GRU4Rec.Selu, GRU4Rec.Elu, GRU4Rec.LeakyReLU):
+    _c.__module__ = 'gru4rec'
+sys.modules.setdefault('gru4rec', sys.modules[__name__])     # so pickle can resolve the name without the root shim

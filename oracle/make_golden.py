@@ -100,13 +100,10 @@ def install_rng_hook(params, state):
 
 
 def run_scenario(name, params):
-    import importlib
+    from oracle import ref_loader
     theano._rng_nodes.clear()
     theano.CALL_LOG.clear()
-    import gru4rec as ref_gru4rec
-    importlib.reload(ref_gru4rec)
-    import evaluation as ref_eval
-    importlib.reload(ref_eval)
+    _, ref_gru4rec, ref_eval = ref_loader.load()      # the reference's own modules, by explicit path
     data = make_data(7)
     train = data[data.SessionId <= 55].copy()
     test = data[data.SessionId > 55].copy()

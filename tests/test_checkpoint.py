@@ -1,0 +1,82 @@
+"""Checkpoint interchange with the reference (gru4rec.py:742-781).
+
+tests/golden/checkpoint/ref_checkpoint.pickle was written by the REFERENCE's own `savemodel` (oracle/make_checkpoint_fixture.py runs
+the reference source on the Theano stand-in); ref_checkpoint_pred.npz holds what its `predict_next_batch` returned."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from gru4rec_amd.gru4rec import GRU4Rec
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'checkpoint')
+PICKLE = os.path.join(GOLD, 'ref_checkpoint.pickle')
+PRED = os.path.join(GOLD, 'ref_checkpoint_pred.npz')
+
+
+def test_reference_pickle_loads_into_the_product_class():
+    g = GRU4Rec.loadmodel(PICKLE)
+    want = np.load(PRED, allow_pickle=False)
+    assert isinstance(g, GRU4Rec)
+    assert (g.loss, g.final_act, g.layers, g.embedding, g.constrained_embedding) == ('bpr-max', 'elu-0.5', [12], 8, False)
+    np.testing.assert_array_equal(g.Wy, want['Wy'])
+    np.testing.assert_array_equal(g.E, want['E'])
+    np.testing.assert_array_equal(g.Wx[0], want['Wx0'])
+    assert g.By.shape == (g.n_items, 1) and g.Wy.dtype == np.float32
+    assert list(g.itemidmap.index.astype(str)) == list(want['itemids'])
+    # the MI355X-side attributes the reference does not know get their defaults
+    assert g.use_graph is True and g._model is None and g._loss_id is not None
+
+
+def test_product_pickle_names_the_reference_class(tmp_path):
+    """What the reference's loadmodel needs: module `gru4rec`, class `GRU4Rec`, NumPy arrays under the reference's
+    attribute names, loss / activations as bound methods with the reference's method names."""
+    g = GRU4Rec.loadmodel(PICKLE)
+    f = str(tmp_path / 'm.pickle')
+    g.savemodel(f)
+    raw = open(f, 'rb').read()
+    assert b'gru4rec_amd' not in raw and b'\x8c\x07gru4rec\x94\x8c\x07GRU4Rec' in raw
+    h = GRU4Rec.loadmodel(f)
+    st = h.__dict__
+    for name in ('layers', 'loss', 'final_act', 'hidden_act', 'Wx', 'Wh', 'Wrz', 'Bh', 'H', 'Wy', 'By', 'E', 'itemidmap',
+                 'n_items', 'loss_function', 'final_activation', 'hidden_activation', 'error_during_train'):
+        assert name in st, name
+    assert h.loss_function.__name__ == 'bpr_max' and h.hidden_activation.__name__ == 'tanh'
+    assert type(h.final_activation.__self__).__name__ == 'Elu' and h.final_activation.__self__.alpha == 0.5
+    assert '_model' not in pickle.loads(raw).__getstate__()
+    np.testing.assert_array_equal(h.Wy, g.Wy)
+
+
+def test_reference_reads_product_pickle_live(tmp_path):
+    """Only where /root/reference exists: the reference's own loadmodel + predict_next_batch on a product-written pickle."""
+    from oracle import ref_loader
+    if not ref_loader.available():
+        pytest.skip('/root/reference not present')
+    import sys
+    g = GRU4Rec.loadmodel(PICKLE)
+    f = str(tmp_path / 'm.pickle')
+    g.savemodel(f)
+    saved = sys.modules.get('gru4rec')
+    try:
+        _, ref, _ = ref_loader.load()
+        back = ref.GRU4Rec.loadmodel(f)
+        want = np.load(PRED, allow_pickle=False)
+        ids = np.array(list(back.itemidmap.index))
+        p1 = back.predict_next_batch(np.array([1, 2, 3, 4]), ids[[0, 3, 5, 7]], None, batch=4)
+        np.testing.assert_array_equal(p1.values.astype(np.float32), want['pred1'])
+    finally:
+        ref_loader.unload()
+        if saved is not None:
+            sys.modules['gru4rec'] = saved
+
+
+@pytest.mark.gpu
+def test_reference_checkpoint_predicts_on_the_gpu():
+    g = GRU4Rec.loadmodel(PICKLE)
+    want = np.load(PRED, allow_pickle=False)
+    ids = np.array(list(g.itemidmap.index))
+    p1 = g.predict_next_batch(np.array([1, 2, 3, 4]), ids[[0, 3, 5, 7]], None, batch=4)
+    p2 = g.predict_next_batch(np.array([1, 2, 9, 4]), ids[[2, 3, 1, 6]], None, batch=4)
+    np.testing.assert_allclose(p1.values, want['pred1'], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(p2.values, want['pred2'], rtol=2e-4, atol=2e-5)
