@@ -10,7 +10,6 @@
 #include <cstring>
 #include <string>
 #include <vector>
-#include <chrono>
 
 #include "g4r_eval_kernels.cuh"
 
@@ -40,9 +39,6 @@ static const char* KN_NAMES[KN_COUNT] = {"k_gru_p1", "k_gru_p2", "k_score_fwd", 
                                          "k_sparse_update"};
 
 struct EvRec { int kn; hipEvent_t a, b; };
-static double g_hostprof[8];
-static long g_hostprof_n;
-static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct g4r_model {
     g4r_config cfg;
@@ -217,7 +213,6 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         DA(d.dV[l], bd * 3); DA(d.dyl[l], bd); DA(d.Vc[l], bd);
     }
     DA(m->d_tmpH, (size_t)B * maxD);
-    DA(d.yin0, (size_t)B * d.Ein);
     DA(d.Sc, (size_t)B * d.ldSc);
     DA(d.dSx, (size_t)B * d.Ein); DA(d.dSy, (size_t)d.ldSc * d.Dtop); DA(d.dSBy, d.ldSc);
     DA(d.dAx, (size_t)B * d.Ein); DA(d.dAy, (size_t)d.ldSc * d.Dtop); DA(d.dABy, d.ldSc);
@@ -285,7 +280,6 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_score_all<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel"); }
-    if (getenv("G4R_DBG_MODE")) d.dbg_mode = atoi(getenv("G4R_DBG_MODE"));
     if (getenv("G4R_CLK")) { if (dalloc(m, &d.dbgclk, 64 + 8 * (size_t)d.R)) { g4r_destroy(m); return -1; } }
     if (dalloc(m, &m->d_dm, 1) || sync_dm(m)) { g4r_destroy(m); return -1; }
     *out = m;
@@ -547,35 +541,35 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     if (part != 2) {
     for (int l = 0; l < L; ++l) {
         begin(KN_GRU_P1);
-        LK(k_gru_p1, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_P1, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
+        LK(k_gru_p1, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
         end();
         begin(KN_GRU_P2);
-        LK(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_NN, s, dmp, stp, l, 1, nopa);
+        LK(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH), SMEM_NN, s, dmp, stp, l, 1, nopa);
         end();
     }
     begin(KN_SCORE_FWD);
-    LK(k_score_fwd, dim3(cdiv(d.ldSc, GT_BN), cdiv(B, SF_BM)), dim3(256), SMEM_SF, s, dmp, stp);
+    LK(k_score_fwd, dim3(cdiv(d.ldSc, GT_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF, s, dmp, stp);
     end();
     begin(KN_LOSS);
     LK(k_loss_rows, dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
     end();
     begin(KN_SCORE_BWD);
-    LK(k_score_bwd, dim3(m->nblkA + m->nblkB), dim3(256), std::max(SMEM_TN, SMEM_NN) + GT_BK * sizeof(int), s, dmp, stp, m->nblkA, m->ndtA, m->ndtB, m->nrtB);
+    LK(k_score_bwd, dim3(m->nblkA + m->nblkB), dim3(GT_NTH), std::max(SMEM_TN, SMEM_NN) + GT_BK * sizeof(int), s, dmp, stp, m->nblkA, m->ndtA, m->ndtB, m->nrtB);
     end();
     for (int l = L - 1; l >= 0; --l) {
         begin(KN_BWD_PRE);
         LK(k_gru_bwd_pre, dim3(cdiv((long long)B * d.D[l], 256)), dim3(256), 0, s, dmp, stp, l);
         end();
         begin(KN_BWD_A);
-        LK(k_gru_bwd_a, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_NT, s, dmp, stp, l);
+        LK(k_gru_bwd_a, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH), SMEM_NT, s, dmp, stp, l);
         end();
         begin(KN_BWD_B);
         if (l == 0 && d.embed_mode == G4R_EMBED_ONEHOT) LK(k_onehot_step, dim3(cdiv((long long)B * d.Ein, 4 * 256)), dim3(256), 0, s, dmp, stp);
-        else LK(k_gru_bwd_b, dim3(cdiv(d.IN[l], GT_BN), cdiv(B, GT_BM)), dim3(256), SMEM_BB, s, dmp, stp, l);
+        else LK(k_gru_bwd_b, dim3(cdiv(d.IN[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_BB, s, dmp, stp, l);
         end();
     }
     begin(KN_DENSE);
-    LK(k_dense_grad, dim3(m->ntiles), dim3(256), SMEM_TN + (size_t)B * sizeof(int), s, dmp, stp, (const DenseTile*)m->d_tiles);
+    LK(k_dense_grad, dim3(m->ntiles), dim3(GT_NTH_FEW), SMEM_TN + (size_t)B * sizeof(int), s, dmp, stp, (const DenseTile*)m->d_tiles);
     end();
     }
     if (part == 1) { HIPCHK(hipGetLastError()); return 0; }
@@ -589,12 +583,9 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     if (!d.apply_dense_inplace) {
         if (!m->comm_ready) return fail("nranks > 1 but g4r_comm_init was not called");
         hipStream_t cs = overlap ? m->comm_stream : s;
-        double h1 = now_us();
         if (overlap) { HIPCHK(hipEventRecord(m->ev_fork, s)); HIPCHK(hipStreamWaitEvent(cs, m->ev_fork, 0)); }
-        g_hostprof[1] += now_us() - h1; h1 = now_us();
         if (!overlap) { begin(KN_ALLREDUCE); if (recs) (void)hipEventRecord(cur_a, cs); }
         NCCLCHK(ncclAllReduce(d.dense_g, d.dense_g, d.dense_count, ncclFloat, ncclSum, m->comm, cs));
-        g_hostprof[2] += now_us() - h1;
         if (!overlap) { if (recs) (void)hipEventRecord(cur_b, cs); end(); begin(KN_DENSE_APPLY); }
         LK(k_dense_apply, dim3(cdiv(d.dense_count, 256)), dim3(256), 0, cs, (const DevModel*)m->d_dm);
         if (!overlap) end();
@@ -692,9 +683,7 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
                 // N > 1: the step's 9 compute kernels replay from a graph; the RCCL all-reduce, the dense apply and the
                 // sparse update (two streams, fork/join events) are launched eagerly behind it
                 if (ensure_head_graph(m)) return -1;
-                const double h0 = now_us();
                 HIPCHK(hipGraphLaunch(m->gexec_head, m->stream));
-                g_hostprof[0] += now_us() - h0; g_hostprof_n++;
                 if (launch_step(m, nullptr, 2)) return -1;
             } else if (launch_step(m, nullptr)) return -1;
         }
@@ -702,7 +691,6 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
         m->gstep += run;
     }
     HIPCHK(hipStreamSynchronize(m->stream));
-    if (getenv("G4R_HOSTPROF") && g_hostprof_n) fprintf(stderr, "[g4r] host us/step: graph launch %.1f, fork %.1f, rccl %.1f (n=%ld)\n", g_hostprof[0] / g_hostprof_n, g_hostprof[1] / g_hostprof_n, g_hostprof[2] / g_hostprof_n, g_hostprof_n);
     return 0;
 }
 
@@ -841,9 +829,9 @@ int g4r_predict_step(g4r_model* m, const int32_t* in_idx, int32_t mrows, const i
         pa.hout = (GP(float))m->phout[l];
         pa.Vc = (GP(float))m->pVc[l]; pa.z = (GP(float))m->pz[l]; pa.Hr = (GP(float))m->pHr[l];
         pa.M = mrows;
-        hipLaunchKernelGGL(k_gru_p1, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(256), SMEM_P1, m->stream,
+        hipLaunchKernelGGL(k_gru_p1, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1, m->stream,
                            (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, 0, pa);
-        hipLaunchKernelGGL(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(256), SMEM_NN, m->stream,
+        hipLaunchKernelGGL(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(GT_NTH), SMEM_NN, m->stream,
                            (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, pa);
     }
     m->ppar ^= 1;
@@ -952,7 +940,6 @@ int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
     else if (s == "dSBy") { p = d.dSBy; n = d.ldSc; }
     else if (s == "dhpart") { p = d.dhpart; n = (int64_t)d.ksplit * d.B * d.Dtop; }
     else if (s == "lossrow") { p = d.lossrow; n = d.B; }
-    else if (s == "yin") { p = d.yin0; n = (int64_t)d.B * d.Ein; }
     else if (s == "hd") { p = d.hd[l]; n = bd; }
     else if (s == "r") { p = d.r[l]; n = bd; }
     else if (s == "z") { p = d.z[l]; n = bd; }

@@ -86,7 +86,6 @@ struct DevModel {
     GP(float) r[G4R_MAX_LAYERS]; GP(float) z[G4R_MAX_LAYERS]; GP(float) c[G4R_MAX_LAYERS];
     GP(float) hd[G4R_MAX_LAYERS]; GP(float) Hr[G4R_MAX_LAYERS];
     GP(float) dV[G4R_MAX_LAYERS]; GP(float) dyl[G4R_MAX_LAYERS]; GP(float) Vc[G4R_MAX_LAYERS];
-    GP(float) yin0;
     // ---- scoring / loss
     GP(float) Sc; GP(float) dSx; GP(float) dSy; GP(float) dSBy; GP(float) dhpart; GP(float) lossrow; GP(float) loss_steps;
     // per-occurrence Adagrad pieces written by the gradient producers: dS* hold lr * g / sqrt(acc_pre + g^2 + eps)
@@ -106,7 +105,6 @@ struct DevModel {
     int gl;
     GP(const float) lq_tgt; GP(const float) lq_smp;
     GP(StepState) st;
-    int dbg_mode, dbg_pad;  // G4R_DBG_MODE experiments (0 in production)
     GP(long long) dbgclk;   // optional [kernel][16] phase timestamps (100 MHz wall clock), block 0 only
 };
 
@@ -167,34 +165,6 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// acc[ti] (16 rows x 16 cols each) += A(16 x K, LDS, row stride lda) * W(K x cols, global/L2).
-// The wave owns up to MAXT column tiles; boff[ti] is this lane's column offset into W (already multiplied
-// by the column stride; < 0 = column out of range) and tmask has bit ti set for tiles that take part.
-// W element (k, col) lives at W[k * sk + boff].  The K loop runs in batches of U k-steps whose operand
-// loads are all issued before the first MFMA of the batch: U*MAXT independent L2 loads in flight per
-// lane instead of one dependent load per MFMA (the step working set is L2 resident, latency is the bound).
-template <int MAXT, int U>
-__device__ __forceinline__ void tile_gemm_rows(f32x4 (&acc)[MAXT], unsigned tmask, const long long (&boff)[MAXT],
-                                               const float* sA, int lda, int K, const GAS float* __restrict__ W,
-                                               long long sk, int li, int lg) {
-    for (int k0 = 0; k0 < K; k0 += 4 * U) {
-        float a[U], b[U][MAXT];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int kk = k0 + 4 * u + lg;
-            const bool ok = (k0 + 4 * u) < K;
-            a[u] = ok ? sA[li * lda + kk] : 0.f;
-#pragma unroll
-            for (int ti = 0; ti < MAXT; ++ti)
-                b[u][ti] = (ok && ((tmask >> ti) & 1u) && boff[ti] >= 0) ? W[(long long)kk * sk + boff[ti]] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int ti = 0; ti < MAXT; ++ti)
-                if ((tmask >> ti) & 1u) acc[ti] = mfma16(a[u], b[u][ti], acc[ti]);
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 struct Philox4 { unsigned x, y, z, w; };

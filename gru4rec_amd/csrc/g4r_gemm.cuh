@@ -31,26 +31,26 @@ struct TileCfg {
 
 // Staging is split in two halves so that the global loads of a chunk are issued long before they are needed:
 // stage_issue puts all loads of the chunk in flight (registers), stage_commit writes them to LDS.
-template <int ROWS, int COLS>
-struct StageRegs { static constexpr int NQ = (ROWS * (COLS / 4) + 255) / 256; float4 v[NQ]; };
+template <int ROWS, int COLS, int NTH = 256>
+struct StageRegs { static constexpr int NQ = (ROWS * (COLS / 4) + NTH - 1) / NTH; float4 v[NQ]; };
 
-template <int ROWS, int COLS, class Load>
-__device__ __forceinline__ void stage_issue(StageRegs<ROWS, COLS>& r, int kk, Load load, int tid) {
+template <int ROWS, int COLS, int NTH, class Load>
+__device__ __forceinline__ void stage_issue(StageRegs<ROWS, COLS, NTH>& r, int kk, Load load, int tid) {
     constexpr int C4 = COLS / 4, TOTAL = ROWS * C4;
 #pragma unroll
-    for (int q = 0; q < StageRegs<ROWS, COLS>::NQ; ++q) {
+    for (int q = 0; q < StageRegs<ROWS, COLS, NTH>::NQ; ++q) {
         // no branch around the load (a conditional definition of v[q] would force an s_waitcnt vmcnt(0) per load):
         // threads beyond the tile re-load its last element and simply do not store it
-        const int e = min(tid + 256 * q, TOTAL - 1);
+        const int e = min(tid + NTH * q, TOTAL - 1);
         r.v[q] = load(kk, e / C4, 4 * (e % C4));
     }
 }
-template <int ROWS, int COLS, int LD>
-__device__ __forceinline__ void stage_commit(float* s, const StageRegs<ROWS, COLS>& r, int tid) {
+template <int ROWS, int COLS, int LD, int NTH>
+__device__ __forceinline__ void stage_commit(float* s, const StageRegs<ROWS, COLS, NTH>& r, int tid) {
     constexpr int C4 = COLS / 4, TOTAL = ROWS * C4;
 #pragma unroll
-    for (int q = 0; q < StageRegs<ROWS, COLS>::NQ; ++q) {
-        const int e = tid + 256 * q;
+    for (int q = 0; q < StageRegs<ROWS, COLS, NTH>::NQ; ++q) {
+        const int e = tid + NTH * q;
         if (e < TOTAL) {
             float* d = s + (e / C4) * LD + 4 * (e % C4);
             if constexpr (LD % 4 == 0) {
@@ -68,17 +68,24 @@ __device__ __forceinline__ void stage_commit(float* s, const StageRegs<ROWS, COL
 // BEFORE the K loop, so those loads fly together with the operand staging instead of costing a round trip at the end.
 struct NoPre { __device__ __forceinline__ float4 operator()(int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); } };
 
-template <int BM, int BN, int BK, bool AKM, bool BNK, class ALoad, class BLoad, class Pre, class Epi>
-__device__ __forceinline__ void gemm_tile(int m0, int n0, int K, ALoad aload, BLoad bload, Pre pre, Epi epi, float* smem) {
+// NTH = 256: 4 waves, one (BM/16 x BN/16)/4 share of the 16x16 sub-tiles each.  NTH = 512: two such wave groups that
+// split every K chunk between them (so 2 waves per SIMD overlap their load-issue and MFMA latencies: the GEMMs of the
+// step only occupy a few dozen CUs, one workgroup each) and add their accumulators through LDS at the end; the
+// epilogue and its `pre` loads run on group 0.
+template <int BM, int BN, int BK, bool AKM, bool BNK, int NTH = 256, class ALoad, class BLoad, class Pre, class Epi>
+__device__ __forceinline__ void gemm_tile(int m0, int n0, int K, ALoad aload, BLoad bload, Pre pre, Epi epi, float* smem,
+                                          GAS long long* clk = nullptr) {      // clk: optional phase timestamps (debug)
     using C = TileCfg<BM, BN, BK, AKM, BNK>;
+    static_assert(NTH == 256 || NTH == 512, "4 or 8 waves");
     float* sA = smem;
     float* sB = smem + C::A_ROWS * C::LDA;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wid = (tid >> 6) & 3, li = lane & 15, lg = lane >> 4;
+    const int grp = (NTH == 512) ? (tid >> 8) : 0;
     constexpr int NT = BN / 16;
     f32x4 acc[C::NSUB];
     float4 pf[C::NSUB][4];
-    StageRegs<C::A_ROWS, C::A_COLS> ra;
-    StageRegs<C::B_ROWS, C::B_COLS> rb;
+    StageRegs<C::A_ROWS, C::A_COLS, NTH> ra;
+    StageRegs<C::B_ROWS, C::B_COLS, NTH> rb;
     // chunk 0 operands first, then the epilogue operands: the (older) operand loads can be waited for with a
     // counted vmcnt while the epilogue loads are still in flight
     stage_issue(ra, 0, aload, tid);
@@ -88,11 +95,13 @@ __device__ __forceinline__ void gemm_tile(int m0, int n0, int K, ALoad aload, BL
         acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int s = wid * C::NSUB + q, ms = s / NT, ns = s % NT;
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) pf[q][rg] = pre(m0 + ms * 16 + 4 * lg + rg, n0 + ns * 16 + li);
+        for (int rg = 0; rg < 4; ++rg) pf[q][rg] = pre(m0 + ms * 16 + 4 * lg + rg, n0 + ns * 16 + li);   // (both groups: branch-free)
     }
+    if (clk && tid == 0) clk[0] = wall_clock64();      // loads issued
     stage_commit<C::A_ROWS, C::A_COLS, C::LDA>(sA, ra, tid);
     stage_commit<C::B_ROWS, C::B_COLS, C::LDB>(sB, rb, tid);
     __syncthreads();
+    if (clk && tid == 0) clk[1] = wall_clock64();      // first chunk in LDS
     for (int kk = 0; kk < K; kk += BK) {
         const bool more = kk + BK < K;
         if (more) {         // next chunk's loads fly during this chunk's MFMAs
@@ -100,8 +109,11 @@ __device__ __forceinline__ void gemm_tile(int m0, int n0, int K, ALoad aload, BL
             stage_issue(rb, kk + BK, bload, tid);
         }
         const int kend = min(BK, K - kk);
+        // this wave group's share of the chunk's k-steps
+        int kb = 0, ke = kend;
+        if (NTH == 512) { const int khalf = ((kend + 7) >> 3) << 2; if (grp) kb = khalf; else ke = khalf; }
 #pragma unroll 4
-        for (int k = 0; k < kend; k += 4) {
+        for (int k = kb; k < ke; k += 4) {
 #pragma unroll
             for (int q = 0; q < C::NSUB; ++q) {
                 const int s = wid * C::NSUB + q, ms = s / NT, ns = s % NT;
@@ -117,6 +129,22 @@ __device__ __forceinline__ void gemm_tile(int m0, int n0, int K, ALoad aload, BL
             __syncthreads();
         }
     }
+    if (clk && tid == 0) clk[2] = wall_clock64();      // MFMA loop done
+    if (NTH == 512) {       // group 1 hands its partial accumulators to group 0 through LDS (operand tiles are dead)
+        __syncthreads();
+        f32x4* sR = reinterpret_cast<f32x4*>(smem);
+        if (grp) {
+#pragma unroll
+            for (int q = 0; q < C::NSUB; ++q) sR[(wid * C::NSUB + q) * 64 + lane] = acc[q];
+        }
+        __syncthreads();
+        if (grp) return;
+#pragma unroll
+        for (int q = 0; q < C::NSUB; ++q) {
+            const f32x4 o = sR[(wid * C::NSUB + q) * 64 + lane];
+            acc[q][0] += o[0]; acc[q][1] += o[1]; acc[q][2] += o[2]; acc[q][3] += o[3];
+        }
+    }
 #pragma unroll
     for (int q = 0; q < C::NSUB; ++q) {
         const int s = wid * C::NSUB + q, ms = s / NT, ns = s % NT;
@@ -124,4 +152,5 @@ __device__ __forceinline__ void gemm_tile(int m0, int n0, int K, ALoad aload, BL
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) epi(m0 + ms * 16 + 4 * lg + rg, n, acc[q][rg], pf[q][rg]);
     }
+    if (clk && tid == 0) clk[3] = wall_clock64();      // epilogue issued
 }

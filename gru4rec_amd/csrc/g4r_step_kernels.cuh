@@ -48,6 +48,12 @@ struct GruFwdPredict {
     int M;
 };
 
+// Threads per GEMM workgroup.  Kernels whose grid is a few dozen tiles (one workgroup per CU, most CUs idle) run 8 waves:
+// two wave groups split each K chunk (g4r_gemm.cuh) so that two waves per SIMD overlap their issue / MFMA latencies
+// (measured: k_gru_p1 11.2 -> 8.9 us, k_gru_bwd_b 7.8 -> 6.6, k_dense_grad 5.5 -> 5.1).  The scoring kernels already
+// have more workgroups than CUs and are faster with 4 waves.
+#define GT_NTH_FEW 512
+#define GT_NTH 256
 #define GT_BM 32
 #define GT_BN 32
 #define GT_BK 128
@@ -60,7 +66,7 @@ struct GruFwdPredict {
 // GRU phase 1: V[B, 3D] = [y | H] * [Wx ; 0|Wrz] + Bh over 32x32 tiles, K = IN + D.
 // Epilogue per column block: [0,D) -> Vc (candidate pre-activation part), [D,2D) -> r = sigmoid, Hr = H*r,
 // [2D,3D) -> z = sigmoid.  For layer 0 the A provider gathers Wy[X] / E[X] rows and applies embedding dropout.
-__global__ __launch_bounds__(256) void k_gru_p1(const DevModel* __restrict__ mp, StepState* st, int l, int train, int first, GruFwdPredict pa) {
+__global__ __launch_bounds__(GT_NTH_FEW) void k_gru_p1(const DevModel* __restrict__ mp, StepState* st, int l, int train, int first, GruFwdPredict pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const int tid = threadIdx.x;
@@ -80,6 +86,8 @@ __global__ __launch_bounds__(256) void k_gru_p1(const DevModel* __restrict__ mp,
         M = pa.M; Hcur = pa.Hcur; gidx = pa.in_idx; ysrc = pa.ysrc; Vc = pa.Vc; zb = pa.z; Hrb = pa.Hr;
     }
     const int m0 = blockIdx.y * GT_BM, n0 = blockIdx.x * GT_BN;
+    GAS long long* clk = (m.dbgclk && blockIdx.x == 1 && blockIdx.y == 1) ? m.dbgclk + 0 : nullptr;      // kernel 0 of tools/clk.py
+    if (clk && tid == 0) clk[4] = wall_clock64();     // context known
     // gather indices of the tile's rows go to LDS first: the row loads must not chain behind index loads
     int* sRow = reinterpret_cast<int*>(smem + TileCfg<GT_BM, GT_BN, P1_BK, false, false>::SMEM_FLOATS);
     if (tid < GT_BM) {
@@ -142,11 +150,12 @@ __global__ __launch_bounds__(256) void k_gru_p1(const DevModel* __restrict__ mp,
         }
         zb[(size_t)row * D + (n - 2 * D)] = sigmoidf_(v);
     };
-    gemm_tile<GT_BM, GT_BN, P1_BK, false, false>(m0, n0, K, aload, bload, pre, epi, smem);
+    if (clk && tid == 0) clk[5] = wall_clock64();     // row indices in LDS
+    gemm_tile<GT_BM, GT_BN, P1_BK, false, false, GT_NTH_FEW>(m0, n0, K, aload, bload, pre, epi, smem, clk);
 }
 
 // GRU phase 2: c = act(Hr * Wh + Vc) ; h = (1 - z) H + z c ; hidden dropout ; reset switch (gru4rec.py:474-479)
-__global__ __launch_bounds__(256) void k_gru_p2(const DevModel* __restrict__ mp, StepState* st, int l, int train, GruFwdPredict pa) {
+__global__ __launch_bounds__(GT_NTH) void k_gru_p2(const DevModel* __restrict__ mp, StepState* st, int l, int train, GruFwdPredict pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const int D = m.D[l];
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(256) void k_gru_p2(const DevModel* __restrict__ mp,
             Hnext[o] = h;
         }
     };
-    gemm_tile<GT_BM, GT_BN, GT_BK, false, false>(m0, n0, D, aload, bload, pre, epi, smem);
+    gemm_tile<GT_BM, GT_BN, GT_BK, false, false, GT_NTH>(m0, n0, D, aload, bload, pre, epi, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(256) void k_gru_p2(const DevModel* __restrict__ mp,
 // 64 x 32 tiles; the B provider gathers the TN output-embedding rows of the tile's columns (in-batch targets,
 // then the step's row of the negative-sample store).  Publishes the column -> item map for the later kernels.
 #define SF_BM 64
-__global__ __launch_bounds__(256) void k_score_fwd(const DevModel* __restrict__ mp, StepState* st) {
+__global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict__ mp, StepState* st) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     using C = TileCfg<SF_BM, GT_BN, GT_BK, false, true>;
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(256) void k_score_fwd(const DevModel* __restrict__ 
         if (row >= M || n >= N) return;
         Sc[(size_t)row * ldSc + n] = v + p.x;
     };
-    gemm_tile<SF_BM, GT_BN, GT_BK, false, true>(m0, n0, D, aload, bload, pre, epi, smem);
+    gemm_tile<SF_BM, GT_BN, GT_BK, false, true, GT_NTH>(m0, n0, D, aload, bload, pre, epi, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -490,7 +499,7 @@ __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict
 //          column d == D of the last d-tile carries a ones column of h, so it accumulates dSBy = colsum(ds).
 //   role B: split-K slabs of dh = ds * Sy: tile (32 rows b, 32 cols d) x one 128-wide chunk of score columns,
 //          B provider = gathered Wy rows of the chunk's columns.  Slabs are summed (fixed order) by k_gru_bwd_pre.
-__global__ __launch_bounds__(256) void k_score_bwd(const DevModel* __restrict__ mp, StepState* st, int nblkA, int ndtA, int ndtB, int nrtB) {
+__global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict__ mp, StepState* st, int nblkA, int ndtA, int ndtB, int nrtB) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const StepCtx c = load_ctx(st);
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(256) void k_score_bwd(const DevModel* __restrict__ 
             if (d < D) { dSy[(size_t)n * D + d] = step; dAy[(size_t)n * D + d] = an; }
             else { dSBy[n] = step; dABy[n] = an; }
         };
-        gemm_tile<GT_BM, GT_BN, GT_BK, true, false>(n0, d0, M, aload, bload, pre, epi, smem);
+        gemm_tile<GT_BM, GT_BN, GT_BK, true, false, GT_NTH>(n0, d0, M, aload, bload, pre, epi, smem);
         return;
     }
     const int w = blockIdx.x - nblkA;
@@ -557,7 +566,7 @@ __global__ __launch_bounds__(256) void k_score_bwd(const DevModel* __restrict__ 
     auto epi = [&](int b, int d, float v, float4) {
         if (b < M && d < D) dhpart[((size_t)kc * B + b) * D + d] = v;
     };
-    gemm_tile<GT_BM, GT_BN, GT_BK, false, false>(m0, d0, min(GT_BK, ld - kbeg), aload, bload, NoPre(), epi, smem);
+    gemm_tile<GT_BM, GT_BN, GT_BK, false, false, GT_NTH>(m0, d0, min(GT_BK, ld - kbeg), aload, bload, NoPre(), epi, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -596,7 +605,7 @@ __global__ __launch_bounds__(256) void k_gru_bwd_pre(const DevModel* __restrict_
 }
 
 // dr' = (da Wh^T) * H * r (1 - r)  -> dV[:, D:2D]      (B provider reads Wh rows: B[k][n] = Wh[n][k])
-__global__ __launch_bounds__(256) void k_gru_bwd_a(const DevModel* __restrict__ mp, StepState* st, int l) {
+__global__ __launch_bounds__(GT_NTH) void k_gru_bwd_a(const DevModel* __restrict__ mp, StepState* st, int l) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const StepCtx c = load_ctx(st);
@@ -624,11 +633,11 @@ __global__ __launch_bounds__(256) void k_gru_bwd_a(const DevModel* __restrict__ 
         if (row >= M || n >= D) return;
         dV[(size_t)row * D3 + D + n] = v * p.y * p.x * (1.f - p.x);
     };
-    gemm_tile<GT_BM, GT_BN, GT_BK, false, true>(m0, n0, D, aload, bload, pre, epi, smem);
+    gemm_tile<GT_BM, GT_BN, GT_BK, false, true, GT_NTH>(m0, n0, D, aload, bload, pre, epi, smem);
 }
 
 // dy = dV Wx^T -> embedding-row gradient dSx (layer 0, through the embedding-dropout mask) or the lower layer's dh
-__global__ __launch_bounds__(256) void k_gru_bwd_b(const DevModel* __restrict__ mp, StepState* st, int l) {
+__global__ __launch_bounds__(GT_NTH_FEW) void k_gru_bwd_b(const DevModel* __restrict__ mp, StepState* st, int l) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const StepCtx c = load_ctx(st);
@@ -667,7 +676,8 @@ __global__ __launch_bounds__(256) void k_gru_bwd_b(const DevModel* __restrict__ 
             dylo[(size_t)row * IN + n] = v;
         }
     };
-    gemm_tile<GT_BM, GT_BN, BB_BK, false, true>(m0, n0, D3, aload, bload, pre, epi, smem);
+    GAS long long* clk = (m.dbgclk && blockIdx.x == 1 && blockIdx.y == 1) ? m.dbgclk + 16 : nullptr;     // kernel 1 of tools/clk.py
+    gemm_tile<GT_BM, GT_BN, BB_BK, false, true, GT_NTH_FEW>(m0, n0, D3, aload, bload, pre, epi, smem, clk);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -723,7 +733,7 @@ __device__ __forceinline__ void dense_adagrad(const DevModel& m, size_t off, flo
 //   dWx = yin^T dV ; dWh = (H r)^T dV[:, :D] ; dWrz = H^T dV[:, D:] ; dBh = colsum(dV)
 // with the dense Adagrad(+momentum) update (gru4rec.py:330-334,390-406) fused into the epilogue when no all-reduce
 // is needed (single GPU); otherwise the gradient goes to dense_g for RCCL.
-__global__ __launch_bounds__(256) void k_dense_grad(const DevModel* __restrict__ mp, StepState* st, const DenseTile* __restrict__ tiles_) {
+__global__ __launch_bounds__(GT_NTH_FEW) void k_dense_grad(const DevModel* __restrict__ mp, StepState* st, const DenseTile* __restrict__ tiles_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const GAS DenseTile* tiles = (const GAS DenseTile*)tiles_;   // same mangled signature on both passes
@@ -737,7 +747,7 @@ __global__ __launch_bounds__(256) void k_dense_grad(const DevModel* __restrict__
     int* sIdx = reinterpret_cast<int*>(smem + TileCfg<GT_BM, GT_BN, GT_BK, true, false>::SMEM_FLOATS);   // [B]
     const GAS float* table = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.Wy : m.E;
     if (tl.gather) {
-        for (int b = tid; b < M; b += 256) sIdx[b] = m.in_idx[c.t * m.B + b];
+        for (int b = tid; b < M; b += (int)blockDim.x) sIdx[b] = m.in_idx[c.t * m.B + b];
         __syncthreads();
     }
     const float drop_e = m.drop_e, lr = m.lr, momc = m.mom, lmbd = m.lmbd;
@@ -782,7 +792,7 @@ __global__ __launch_bounds__(256) void k_dense_grad(const DevModel* __restrict__
             dp[off] = p.y * (1.0f - lr * lmbd) - lr * gs;
         }
     };
-    gemm_tile<GT_BM, GT_BN, GT_BK, true, false>(tl.r0, tl.c0, M, aload, bload, pre, epi, smem);
+    gemm_tile<GT_BM, GT_BN, GT_BK, true, false, GT_NTH_FEW>(tl.r0, tl.c0, M, aload, bload, pre, epi, smem);
 }
 
 // after the RCCL all-reduce: element-wise dense Adagrad on the averaged gradient
@@ -849,7 +859,6 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevMod
         }
         return;
     }
-    if (m.dbg_mode == 1) return;
     const long long t_start = m.dbgclk ? wall_clock64() : 0;
     // LDS: occurrence list padded with -2 to a multiple of 256 (+256) | hot-item slots | per-wave match lists |
     // per-wave partial sums
