@@ -37,12 +37,22 @@ struct StageRegs { static constexpr int NQ = (ROWS * (COLS / 4) + NTH - 1) / NTH
 template <int ROWS, int COLS, int NTH, class Load>
 __device__ __forceinline__ void stage_issue(StageRegs<ROWS, COLS, NTH>& r, int kk, Load load, int tid) {
     constexpr int C4 = COLS / 4, TOTAL = ROWS * C4;
+    if constexpr (NTH % C4 == 0) {
+        // a thread keeps its column for all of its loads and only steps through rows: everything the provider derives
+        // from the column (which source, bounds, dropout column) is computed once
+        constexpr int RSTEP = NTH / C4;
+        const int c = 4 * (tid % C4), r0 = tid / C4;
 #pragma unroll
-    for (int q = 0; q < StageRegs<ROWS, COLS, NTH>::NQ; ++q) {
-        // no branch around the load (a conditional definition of v[q] would force an s_waitcnt vmcnt(0) per load):
-        // threads beyond the tile re-load its last element and simply do not store it
-        const int e = min(tid + NTH * q, TOTAL - 1);
-        r.v[q] = load(kk, e / C4, 4 * (e % C4));
+        for (int q = 0; q < StageRegs<ROWS, COLS, NTH>::NQ; ++q)
+            r.v[q] = load(kk, min(r0 + q * RSTEP, ROWS - 1), c);      // rows past the tile re-load the last row, not stored
+    } else {
+#pragma unroll
+        for (int q = 0; q < StageRegs<ROWS, COLS, NTH>::NQ; ++q) {
+            // no branch around the load (a conditional definition of v[q] would force an s_waitcnt vmcnt(0) per load):
+            // threads beyond the tile re-load its last element and simply do not store it
+            const int e = min(tid + NTH * q, TOTAL - 1);
+            r.v[q] = load(kk, e / C4, 4 * (e % C4));
+        }
     }
 }
 template <int ROWS, int COLS, int LD, int NTH>
@@ -50,9 +60,12 @@ __device__ __forceinline__ void stage_commit(float* s, const StageRegs<ROWS, COL
     constexpr int C4 = COLS / 4, TOTAL = ROWS * C4;
 #pragma unroll
     for (int q = 0; q < StageRegs<ROWS, COLS, NTH>::NQ; ++q) {
-        const int e = tid + NTH * q;
-        if (e < TOTAL) {
-            float* d = s + (e / C4) * LD + 4 * (e % C4);
+        int row, col;
+        bool ok;
+        if constexpr (NTH % C4 == 0) { row = tid / C4 + q * (NTH / C4); col = 4 * (tid % C4); ok = row < ROWS; }
+        else { const int e = tid + NTH * q; row = e / C4; col = 4 * (e % C4); ok = e < TOTAL; }
+        if (ok) {
+            float* d = s + row * LD + col;
             if constexpr (LD % 4 == 0) {
                 *reinterpret_cast<float4*>(d) = r.v[q];
             } else {
