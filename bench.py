@@ -33,6 +33,10 @@ CONFIGS = {
     'cfg3': dict(n_items=3000000, layers=[512], batch_size=240, n_sample=2048, loss='cross-entropy', final_act='softmax',
                  bpreg=0.0, learning_rate=0.065, momentum=0.0, sample_alpha=0.5, logq=1.0, dropout_p_embed=0.45,
                  dropout_p_hidden=0.0, constrained_embedding=True),
+    # BASELINE.json configs[3] (per-GPU shape of the 8-GPU synthetic 10M-item catalogue)
+    'cfg4': dict(n_items=10000000, layers=[256], batch_size=512, n_sample=8192, loss='bpr-max', final_act='elu-0.5',
+                 bpreg=1.0, learning_rate=0.1, momentum=0.0, sample_alpha=0.75, logq=0.0, dropout_p_embed=0.0,
+                 dropout_p_hidden=0.0, constrained_embedding=True),
     # BASELINE.json configs[4]
     'cfg5': dict(n_items=37483, layers=[100, 100], batch_size=128, n_sample=2048, loss='top1-max', final_act='elu-0.5',
                  bpreg=1.0, learning_rate=0.1, momentum=0.0, sample_alpha=0.75, logq=0.0, dropout_p_embed=0.2,
@@ -226,7 +230,8 @@ def main():
     losses = m.get_losses(args.warmup, args.steps)
     events = int(plan['M'][args.warmup:args.warmup + args.steps].sum()) * world
     out = {
-        'metric': 'mini-batches/sec (gru4rec.py:661), RSC15-shaped batch=128 n_sample=2048 BPR-max',
+        'metric': 'mini-batches/sec (gru4rec.py:661), RSC15-shaped batch=128 n_sample=2048 BPR-max' if args.config == 'cfg2'
+        else 'mini-batches/sec (gru4rec.py:661), %s: batch=%d n_sample=%d %s' % (args.config, cfg['batch_size'], cfg['n_sample'], cfg['loss']),
         'value': args.steps * world / dt, 'unit': 'mini-batches/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': (args.steps * world / dt) / A30_PUBLISHED_MBS if args.config == 'cfg2' else None,
