@@ -25,6 +25,10 @@ sys.path.insert(0, ROOT)
 A30_PUBLISHED_MBS = 1240.0   # BPR-max, layers=[100], batch 128, n_sample 2048 on an A30 (Theano)
 
 CONFIGS = {
+    # BASELINE.json configs[0] (the reference's CPU-runnable plumbing case; in-batch negatives only)
+    'cfg1': dict(n_items=37483, layers=[100], batch_size=32, n_sample=0, loss='cross-entropy', final_act='softmax',
+                 bpreg=0.0, learning_rate=0.1, momentum=0.0, sample_alpha=0.75, logq=0.0, dropout_p_embed=0.0,
+                 dropout_p_hidden=0.0, constrained_embedding=True),
     # BASELINE.json configs[1]
     'cfg2': dict(n_items=37483, layers=[100], batch_size=128, n_sample=2048, loss='bpr-max', final_act='elu-0.5',
                  bpreg=1.0, learning_rate=0.1, momentum=0.0, sample_alpha=0.75, logq=0.0, dropout_p_embed=0.0,
