@@ -581,24 +581,25 @@ __global__ __launch_bounds__(256) void k_gru_bwd_pre(const DevModel* __restrict_
     if (e >= M * D) return;
     const int row = e / D, d = e - row * D;
     const size_t o = (size_t)row * D + d;
+    // everything this thread needs is requested in one round trip: the gate values first, then the split-K slabs of
+    // dh (up to 24 at a time, clamped slab index + 0/1 weight instead of a data-dependent trip count)
+    const float hv = m.H[l][c.g & 1][o], zz = m.z[l][o], cc = m.c[l][o];
+    const int ks = m.ksplit;
     float dh = 0.f;
     if (l == m.n_layers - 1) {
         const GAS float* pp = m.dhpart + o;
         const size_t ps = (size_t)B * D;
-        int kc = 0;
-        for (; kc + 8 <= m.ksplit; kc += 8) {     // 8 independent loads in flight, fixed summation order
-            float v[8];
+        for (int k0 = 0; k0 < ks; k0 += 24) {
+            float v[24];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = pp[(size_t)(kc + q) * ps];
+            for (int q = 0; q < 24; ++q) v[q] = pp[(size_t)min(k0 + q, ks - 1) * ps];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) dh += v[q];
+            for (int q = 0; q < 24; ++q) dh += (k0 + q < ks) ? v[q] : 0.f;      // fixed summation order
         }
-        for (; kc < m.ksplit; ++kc) dh += pp[(size_t)kc * ps];
     } else {
         dh = m.dyl[l][o];
     }
     if (m.drop_h > 0.f) dh *= drop_mult(m.seed, (unsigned)c.g, G4R_STREAM_DROP_HIDDEN + l, row, d, 1.0f - m.drop_h);
-    const float hv = m.H[l][c.g & 1][o], zz = m.z[l][o], cc = m.c[l][o];
     const float dz = dh * (cc - hv), dc = dh * zz;
     m.dV[l][(size_t)row * D3 + d] = dc * act_bwd_from_out(m.hidden_act, m.ha_p0, m.ha_p1, cc);
     m.dV[l][(size_t)row * D3 + 2 * D + d] = dz * zz * (1.f - zz);
