@@ -67,6 +67,9 @@ def algorithmic_cost(cfg):
         'k_gru_bwd_a': dict(bound='mfma', flops=2.0 * B * D * D, bytes=B * D * 4 * 4 + D * D * 4),
         'k_gru_bwd_b': dict(bound='mfma', flops=2.0 * B * 3 * D * D, bytes=B * D * 4 * 4 + 3 * D * D * 4),
         'k_dense_grad': dict(bound='mfma', flops=2.0 * B * 6 * D * D, bytes=B * D * 4 * 6 + 3 * 6 * D * D * 4),
+        # single GPU: dense-gradient tiles + sparse row update share one launch; its HBM-side work is the sparse
+        # gather/scatter plus the dense parameters / accumulators read and written once
+        'k_update': dict(bound='hbm', bytes=(5 + mom) * R * D * 4 + 5 * N * 4 + R * 4 + 4 * 6 * D * D * 4 + B * D * 4 * 6),
     }
 
 
@@ -274,18 +277,19 @@ def main():
         out['kernels'] = kern
         out['kernel_time_sum_us_per_step'] = sum(1000.0 * ms / n_profile for ms, n in kt.values())
         # the roofline entry: the embedding gather/scatter kernel north_star names (HBM-bound)
-        k = kern.get('k_sparse_update')
+        rk = 'k_update' if 'k_update' in kern else 'k_sparse_update'
+        k = kern.get(rk)
         if k:
             traffic, tnote = None, ''
             pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic_%s.json' % args.config)
             if os.path.exists(pmc):     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_summary.py)
-                traffic = json.load(open(pmc))['kernels'].get('k_sparse_update', {}).get('traffic_bytes')
+                traffic = json.load(open(pmc))['kernels'].get(rk, {}).get('traffic_bytes')
                 tnote = '; traffic = 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/%s)' % os.path.basename(pmc)
-            out['roofline'] = {'kernel': 'k_sparse_update', 'bound': 'hbm', 'achieved': k['achieved'], 'peak': 8000.0,
+            out['roofline'] = {'kernel': rk, 'bound': 'hbm', 'achieved': k['achieved'], 'peak': 8000.0,
                                'unit': 'GB/s', 'frac': k['achieved'] / 8000.0, 'traffic': traffic,
-                               'note': 'algorithmic bytes per launch = %d (gradient rows + param/accumulator r/w per occurrence, '
-                                       'SURVEY 8d); the 15 MB table is Infinity-Cache resident at this config%s' % (
-                                           alg['k_sparse_update']['bytes'], tnote)}
+                               'note': 'algorithmic bytes per launch = %d (sparse update: gradient rows + param/accumulator r/w per '
+                                       'occurrence, SURVEY 8d; + dense params/accumulators r/w when the dense tiles share the launch); '
+                                       'the 15 MB table is Infinity-Cache resident at cfg2%s' % (alg[rk]['bytes'], tnote)}
         dom = max(kern.items(), key=lambda kv: kv[1]['avg_us'] * kv[1]['launches_per_step'])
         out['dominant_kernel'] = dom[0]
         if not args.no_cpu_baseline:

@@ -33,10 +33,10 @@ static int fail(const std::string& s) { g_err = s; return -1; }
     } while (0)
 
 enum { KN_GRU_P1 = 0, KN_GRU_P2, KN_SCORE_FWD, KN_LOSS, KN_SCORE_BWD, KN_BWD_PRE, KN_BWD_A, KN_BWD_B, KN_DENSE, KN_ALLREDUCE,
-       KN_DENSE_APPLY, KN_SPARSE, KN_COUNT };
+       KN_DENSE_APPLY, KN_SPARSE, KN_UPDATE, KN_COUNT };
 static const char* KN_NAMES[KN_COUNT] = {"k_gru_p1", "k_gru_p2", "k_score_fwd", "k_loss_rows", "k_score_bwd", "k_gru_bwd_pre",
                                          "k_gru_bwd_a", "k_gru_bwd_b", "k_dense_grad", "rccl_allreduce", "k_dense_apply",
-                                         "k_sparse_update"};
+                                         "k_sparse_update", "k_update"};
 
 struct EvRec { int kn; hipEvent_t a, b; };
 
@@ -213,6 +213,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         DA(d.dV[l], bd * 3); DA(d.dyl[l], bd); DA(d.Vc[l], bd);
     }
     DA(m->d_tmpH, (size_t)B * maxD);
+    DA(d.yin0, (size_t)B * std::max(d.IN[0], 4));
     DA(d.Sc, (size_t)B * d.ldSc);
     DA(d.dSx, (size_t)B * d.Ein); DA(d.dSy, (size_t)d.ldSc * d.Dtop); DA(d.dSBy, d.ldSc);
     DA(d.dAx, (size_t)B * d.Ein); DA(d.dAy, (size_t)d.ldSc * d.Dtop); DA(d.dABy, d.ldSc);
@@ -277,6 +278,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_dense_grad, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_all<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel"); }
@@ -568,8 +571,19 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         else LK(k_gru_bwd_b, dim3(cdiv(d.IN[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_BB, s, dmp, stp, l);
         end();
     }
+    static const bool no_merge = getenv("G4R_NO_MERGE") != nullptr;
+    if (part == 0 && d.apply_dense_inplace && !no_merge) {
+        // single GPU: dense-gradient tiles (+ fused dense Adagrad) and the sparse row update in ONE launch (k_update)
+        const size_t smem = std::max(SMEM_TN, m->smem_sparse);
+        begin(KN_UPDATE);
+        if (std::max(d.Dtop, d.Ein) <= 256) LK(k_update<1>, dim3(m->ntiles + m->nblk_occ + 1), dim3(SP_WAVES * 64), smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);
+        else LK(k_update<2>, dim3(m->ntiles + m->nblk_occ + 1), dim3(SP_WAVES * 64), smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);
+        end();
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     begin(KN_DENSE);
-    LK(k_dense_grad, dim3(m->ntiles), dim3(GT_NTH_FEW), SMEM_TN + (size_t)B * sizeof(int), s, dmp, stp, (const DenseTile*)m->d_tiles);
+    LK(k_dense_grad, dim3(m->ntiles), dim3(GT_NTH_FEW), SMEM_TN, s, dmp, stp, (const DenseTile*)m->d_tiles);
     end();
     }
     if (part == 1) { HIPCHK(hipGetLastError()); return 0; }

@@ -92,6 +92,7 @@ struct DevModel {
     // (the scaled step), dA* hold acc_pre + g^2 (the accumulator value the LAST occurrence leaves behind)
     GP(float) dAx; GP(float) dAy; GP(float) dABy;
     int ksplit, kch;
+    GP(float) yin0;    // [B][IN0] layer-0 input rows as the GRU saw them (gathered, embedding dropout applied)
     GP(int) occ_idx;   // [R] item of each gathered-row occurrence (X | Y | samples), -1 = inactive
     GP(int) col_item;  // [ldSc] item of each score column, -1 = inactive
     // [tables][n_items][4]: (last occurrence + 1, R - first occurrence, count, 0) of every item touched this step, written

@@ -80,14 +80,16 @@ __device__ __forceinline__ void stage_commit(float* s, const StageRegs<ROWS, COL
 // pre(m, n) -> float4 fetches whatever the epilogue needs besides the accumulator (bias, gates, optimizer state)
 // BEFORE the K loop, so those loads fly together with the operand staging instead of costing a round trip at the end.
 struct NoPre { __device__ __forceinline__ float4 operator()(int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); } };
+// optional hook called by all threads once a K chunk [kk, kk + kend) of the operand tiles sits in LDS (sA, row stride LDA)
+struct NoHook { __device__ __forceinline__ void operator()(const float*, int, int) const {} };
 
 // NTH = 256: 4 waves, one (BM/16 x BN/16)/4 share of the 16x16 sub-tiles each.  NTH = 512: two such wave groups that
 // split every K chunk between them (so 2 waves per SIMD overlap their load-issue and MFMA latencies: the GEMMs of the
 // step only occupy a few dozen CUs, one workgroup each) and add their accumulators through LDS at the end; the
 // epilogue and its `pre` loads run on group 0.
-template <int BM, int BN, int BK, bool AKM, bool BNK, int NTH = 256, class ALoad, class BLoad, class Pre, class Epi>
+template <int BM, int BN, int BK, bool AKM, bool BNK, int NTH = 256, class ALoad, class BLoad, class Pre, class Epi, class Hook = NoHook>
 __device__ __forceinline__ void gemm_tile(int m0, int n0, int K, ALoad aload, BLoad bload, Pre pre, Epi epi, float* smem,
-                                          GAS long long* clk = nullptr) {      // clk: optional phase timestamps (debug)
+                                          GAS long long* clk = nullptr, Hook hook = Hook()) {      // clk: optional phase timestamps (debug)
     using C = TileCfg<BM, BN, BK, AKM, BNK>;
     static_assert(NTH == 256 || NTH == 512, "4 or 8 waves");
     float* sA = smem;
@@ -122,6 +124,7 @@ __device__ __forceinline__ void gemm_tile(int m0, int n0, int K, ALoad aload, BL
             stage_issue(rb, kk + BK, bload, tid);
         }
         const int kend = min(BK, K - kk);
+        hook(sA, kk, kend);
         // this wave group's share of the chunk's k-steps
         int kb = 0, ke = kend;
         if (NTH == 512) { const int khalf = ((kend + 7) >> 3) << 2; if (grp) kb = khalf; else ke = khalf; }

@@ -151,7 +151,20 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_p1(const DevModel* __restric
         zb[(size_t)row * D + (n - 2 * D)] = sigmoidf_(v);
     };
     if (clk && tid == 0) clk[5] = wall_clock64();     // row indices in LDS
-    gemm_tile<GT_BM, GT_BN, P1_BK, false, false, GT_NTH_FEW>(m0, n0, K, aload, bload, pre, epi, smem, clk);
+    // the first column tile of every row block also publishes its gathered (and dropout-masked) layer-0 input rows: the
+    // dense-gradient tiles read them back (dWx = yin^T dV) while the sparse update is already rewriting the table rows
+    GAS float* yin0 = m.yin0;
+    const bool pub = train && l == 0 && blockIdx.x == 0 && IN > 0;
+    auto hook = [&](const float* sA, int kk, int kend) {
+        if (!pub) return;
+        constexpr int LDA = TileCfg<GT_BM, GT_BN, P1_BK, false, false>::LDA;
+        const int kmax = min(kend, IN - kk);          // columns of this chunk that belong to y
+        for (int e = tid; e < GT_BM * kmax; e += GT_NTH_FEW) {
+            const int r = e / kmax, k = e - r * kmax;
+            if (m0 + r < M) yin0[(size_t)(m0 + r) * IN + kk + k] = sA[r * LDA + k];
+        }
+    };
+    gemm_tile<GT_BM, GT_BN, P1_BK, false, false, GT_NTH_FEW>(m0, n0, K, aload, bload, pre, epi, smem, clk, hook);
 }
 
 // GRU phase 2: c = act(Hr * Wh + Vc) ; h = (1 - z) H + z c ; hidden dropout ; reset switch (gru4rec.py:474-479)
@@ -733,40 +746,23 @@ __device__ __forceinline__ void dense_adagrad(const DevModel& m, size_t off, flo
 // One workgroup per 32x32 output tile of a dense GRU gradient (contraction over the batch):
 //   dWx = yin^T dV ; dWh = (H r)^T dV[:, :D] ; dWrz = H^T dV[:, D:] ; dBh = colsum(dV)
 // with the dense Adagrad(+momentum) update (gru4rec.py:330-334,390-406) fused into the epilogue when no all-reduce
-// is needed (single GPU); otherwise the gradient goes to dense_g for RCCL.
-__global__ __launch_bounds__(GT_NTH_FEW) void k_dense_grad(const DevModel* __restrict__ mp, StepState* st, const DenseTile* __restrict__ tiles_) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const DevModel& m = *mp;
+// is needed (single GPU); otherwise the gradient goes to dense_g for RCCL.  Layer-0 input rows come from yin0
+// (published by k_gru_p1), never from the embedding table, so this may run next to the sparse update.
+__device__ __forceinline__ void dense_grad_tile(const DevModel& m, StepState* st, const DenseTile* tiles_, int tile, float* smem) {
     const GAS DenseTile* tiles = (const GAS DenseTile*)tiles_;   // same mangled signature on both passes
     const StepCtx c = load_ctx(st);
-    const DenseTile tl = tiles[blockIdx.x];    // fully resolved on the host: no per-layer lookups here
-    const GAS float* X = (c.g & 1) ? tl.X1 : tl.X0;
+    const DenseTile tl = tiles[tile];    // fully resolved on the host: no per-layer lookups here
+    const GAS float* X = tl.gather ? (const GAS float*)m.yin0 : ((c.g & 1) ? tl.X1 : tl.X0);
     const GAS float* dV = tl.dV;
-    const int M = c.M, tid = threadIdx.x;
-    const bool ones = (X == nullptr) && !tl.gather;          // bias row: column sums of dV
-    // layer-0 input rows are re-gathered (and re-masked) here instead of being written out by the forward kernel
-    int* sIdx = reinterpret_cast<int*>(smem + TileCfg<GT_BM, GT_BN, GT_BK, true, false>::SMEM_FLOATS);   // [B]
-    const GAS float* table = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.Wy : m.E;
-    if (tl.gather) {
-        for (int b = tid; b < M; b += (int)blockDim.x) sIdx[b] = m.in_idx[c.t * m.B + b];
-        __syncthreads();
-    }
-    const float drop_e = m.drop_e, lr = m.lr, momc = m.mom, lmbd = m.lmbd;
-    const unsigned long long seed = m.seed;
+    const int M = c.M;
+    const bool ones = (X == nullptr);          // bias row: column sums of dV
+    const float lr = m.lr, momc = m.mom, lmbd = m.lmbd;
     const int inplace = m.apply_dense_inplace;
     GAS float *dp = m.dense_p, *dacc = m.dense_acc, *dvel = m.dense_vel, *dg = m.dense_g;
     auto aload = [&](int kk, int r, int cc) -> float4 {      // staging tile [k = b][m = output row]
         const int b = kk + r, rr = tl.r0 + cc;
         const bool ok = b < M && rr < tl.nrows;
         if (ones) return make_float4((ok && rr == 0) ? 1.f : 0.f, 0.f, 0.f, 0.f);
-        if (tl.gather) {
-            float4 v = ld4_if(table, (size_t)sIdx[ok ? b : 0] * tl.ldx + rr, ok);
-            if (drop_e > 0.f && ok) {
-                const float4 mk = drop_mult4(seed, (unsigned)c.g, G4R_STREAM_DROP_EMBED, b, rr >> 2, 1.0f - drop_e);
-                v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
-            }
-            return v;
-        }
         return ld4_if(X, (size_t)b * tl.ldx + rr, ok);
     };
     auto bload = [&](int kk, int r, int cc) -> float4 {
@@ -794,6 +790,10 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_dense_grad(const DevModel* __res
         }
     };
     gemm_tile<GT_BM, GT_BN, GT_BK, true, false, GT_NTH_FEW>(tl.r0, tl.c0, M, aload, bload, pre, epi, smem);
+}
+__global__ __launch_bounds__(GT_NTH_FEW) void k_dense_grad(const DevModel* __restrict__ mp, StepState* st, const DenseTile* __restrict__ tiles_) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    dense_grad_tile(*mp, st, tiles_, blockIdx.x, smem);
 }
 
 // after the RCCL all-reduce: element-wise dense Adagrad on the averaged gradient
@@ -826,8 +826,7 @@ __global__ __launch_bounds__(256) void k_dense_apply(const DevModel* __restrict_
 
 // MAXCH = float4 chunks per lane (1: row width <= 256, 2: <= 512).
 template <int MAXCH>
-__global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevModel* __restrict__ mp, StepState* st, int nblk_occ) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__ mp, StepState* st, int nblk_occ, int blk, float* smem) {
     const DevModel& m = *mp;
     constexpr int UB = SP_UB / MAXCH;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -842,7 +841,7 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevMod
     const int wE = m.Ein, wY = m.Dtop;
     const GAS int* g_occ = m.occ_idx;
     const GAS float *g_dSx = m.dSx, *g_dSy = m.dSy, *g_dAx = m.dAx, *g_dAy = m.dAy, *g_dSBy = m.dSBy, *g_dABy = m.dABy;
-    if ((int)blockIdx.x == nblk_occ) {
+    if (blk == nblk_occ) {
         // ---- bookkeeping block: cost = sum_i L_i / batch_size (gru4rec.py:577), NaN flag (:626), advance state
         if (wid == 0) {
             float s = 0.f;
@@ -872,7 +871,7 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevMod
     int* myList = sList + 64 * wid;
     GAS int* g_fl = m.occ_fl;
     const int nI = m.n_items;
-    const int k = blockIdx.x * SP_WAVES + wid;
+    const int k = blk * SP_WAVES + wid;
     int item = g_occ[min(k, R - 1)];
     if (k >= R) item = -1;
     // occurrence range sharing a table with k: constrained -> all of X|Y|samples ; separate -> X alone, Y|samples alone
@@ -973,7 +972,7 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevMod
             if (h >= 0) {
                 it = sHot[h];
                 if (it < 0) continue;             // workgroup-uniform
-                const int hk = blockIdx.x * SP_WAVES + h, hlo = sHot[SP_WAVES + h];
+                const int hk = blk * SP_WAVES + h, hlo = sHot[SP_WAVES + h];
                 const int slice = (((hk - hlo + SP_WAVES - 1) / SP_WAVES) + 63) & ~63;
                 a = hlo + wid * slice; b = min(hk, a + slice);
                 tW = (hk < B && !constrained) ? wE : wY; tnc4 = tW >> 2;
@@ -1087,6 +1086,24 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevMod
         GAS long long* tr = m.dbgclk + 64 + 8 * k;
         tr[0] = t_start; tr[1] = t_own; tr[2] = t_col; tr[3] = t_app; tr[4] = t_end; tr[5] = owner ? fl.z : 0; tr[6] = c.t; tr[7] = item;
     }
+}
+
+template <int MAXCH>
+__global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevModel* __restrict__ mp, StepState* st, int nblk_occ) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    sparse_update_block<MAXCH>(mp, st, nblk_occ, (int)blockIdx.x, smem);
+}
+
+// Single GPU: the dense-gradient tiles (+ fused dense Adagrad) and the sparse row update are independent of each other
+// (the tiles read layer-0 input rows from yin0, not from the table), so they share ONE launch: blocks [0, ntiles) are
+// dense tiles, the rest sparse-update blocks.  One dispatch (~4.5 us) less per step.
+static_assert(GT_NTH_FEW == SP_WAVES * 64, "both roles use the same workgroup size");
+template <int MAXCH>
+__global__ __launch_bounds__(SP_WAVES * 64, 4) void k_update(const DevModel* __restrict__ mp, StepState* st, const DenseTile* __restrict__ tiles_,
+                                                             int ntiles, int nblk_occ) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < ntiles) dense_grad_tile(*mp, st, tiles_, (int)blockIdx.x, smem);
+    else sparse_update_block<MAXCH>(mp, st, nblk_occ, (int)blockIdx.x - ntiles, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
