@@ -117,8 +117,9 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_p1(const DevModel* __restric
     auto aload = [&](int kk, int r, int c) -> float4 {
         const int row = m0 + r, k = kk + c;
         const bool ok = row < M && k < K, isy = k < IN;
-        const GAS float* src = isy ? ((l == 0) ? table + (size_t)max(sRow[r], 0) * IN : ysrc + (size_t)row * IN)
-                                   : Hcur + (size_t)row * D;
+        const int rowc = min(row, M - 1);      // rows past the batch must not even form an out-of-range address
+        const GAS float* src = isy ? ((l == 0) ? table + (size_t)max(sRow[r], 0) * IN : ysrc + (size_t)rowc * IN)
+                                   : Hcur + (size_t)rowc * D;
         float4 v = ld4_if(src, isy ? k : k - IN, ok);
         if (train && l == 0 && drop_e > 0.f && ok && isy) {
             const float4 mk = drop_mult4(seed, (unsigned)g, G4R_STREAM_DROP_EMBED, row, k >> 2, retain_e);
