@@ -1,40 +1,46 @@
-"""Host-side data helpers with the interface of the reference's datatools.py (sort_if_needed :12-34,
-compute_offset :36-39).  Pure pandas/NumPy; feeds the epoch-plan builder."""
+"""Host-side table helpers used by `GRU4Rec.fit` before the epoch plan is built.  Same entry points and console
+messages as the reference's datatools.py (`sort_if_needed`, `compute_offset`); pandas / NumPy only."""
 import time
 
 import numpy as np
 
 
+def _first_unordered_key(table, keys, first_key_any_order):
+    """None when `table` is lexicographically non-decreasing in `keys` (the first key may instead merely be grouped),
+    otherwise the key at which the order breaks."""
+    n = len(table)
+    if n < 2:
+        return None
+    tie = np.ones(n - 1, dtype=bool)          # rows whose preceding keys are all equal to the previous row's
+    for depth, key in enumerate(keys):
+        col = table[key].values
+        step_up, same = col[1:] > col[:-1], col[1:] == col[:-1]
+        if depth == 0 and first_key_any_order:
+            # grouped but not necessarily ascending: as many value changes as distinct values minus one
+            if int((~same).sum()) + 1 != table[key].nunique():
+                return key
+        elif np.any(tie & ~step_up & ~same):
+            return key
+        tie &= same
+    return None
+
+
 def sort_if_needed(data, columns, any_order_first_dim=False):
-    """Sort `data` in place by `columns` unless it already is (same messages as the reference)."""
-    ok = True
-    prev_neq = None
-    col = columns[0]
-    for pos, col in enumerate(columns):
-        v = data[col].values
-        neq = v[1:] != v[:-1]
-        if pos == 0:
-            if any_order_first_dim:
-                ok = ok and (data[col].nunique() == int(neq.sum()) + 1)
-            else:
-                ok = ok and bool(np.all(v[1:] >= v[:-1]))
-        else:
-            ok = ok and bool(np.all(prev_neq | (v[1:] >= v[:-1])))
-        prev_neq = neq
-        if not ok:
-            break
-    if ok:
+    """Sorts `data` in place by `columns` unless it already is in that order."""
+    broken_at = _first_unordered_key(data, columns, any_order_first_dim)
+    if broken_at is None:
         print('The dataframe is already sorted by {}'.format(', '.join(columns)))
         return
-    print('The dataframe is not sorted by {}, sorting now'.format(col))
-    t0 = time.time()
+    print('The dataframe is not sorted by {}, sorting now'.format(broken_at))
+    began = time.time()
     data.sort_values(columns, inplace=True)
-    print('Data is sorted in {:.2f}'.format(time.time() - t0))
+    print('Data is sorted in {:.2f}'.format(time.time() - began))
 
 
 def compute_offset(data, column):
-    """int32[n_groups + 1] start offsets of the (sorted) groups of `column`."""
-    sizes = data.groupby(column).size().values
-    offset = np.zeros(len(sizes) + 1, dtype=np.int32)
-    offset[1:] = np.cumsum(sizes)
-    return offset
+    """Start offset of every run of equal `column` values in the (sorted) table, plus the total length: int32[n_groups + 1]."""
+    values = data[column].values
+    if len(values) == 0:
+        return np.zeros(1, dtype=np.int32)
+    starts = np.flatnonzero(np.concatenate(([True], values[1:] != values[:-1])))
+    return np.concatenate((starts, [len(values)])).astype(np.int32)

@@ -1,125 +1,145 @@
 #!/usr/bin/env python
-"""CLI with the arguments, messages and exit codes of the reference's run.py (run.py:10-133), driving the
-MI355X implementation.  `-g/--gru4rec_model` (run.py:21,39) keeps working as the plugin hook: any module that
-exposes a `GRU4Rec` class; the default is gru4rec_amd.gru4rec.  `paropt.py` of the reference works unchanged
-against this script (it scrapes the `PRIMARY METRIC:` line).
+"""Command line front end of the MI355X GRU4Rec path.
+
+It accepts the same flags, prints the same progress lines and uses the same exit codes as the reference's `run.py`, so
+shell scripts and `paropt.py` (which scrapes the `PRIMARY METRIC:` line) keep working; the work itself goes through the
+plugin class selected with `-g` (any module exposing `GRU4Rec`; default: the HIP implementation).
 """
 import argparse
 import importlib
 import importlib.util
 import os
-import shutil
 import sys
 import time
 from collections import OrderedDict
 
+KEY_COLUMNS = (          # (what it is, CLI attribute, default column, model parameter that overrides it)
+    ('session IDs', 'session_key', 'SessionId'),
+    ('item IDs', 'item_key', 'ItemId'),
+    ('time', 'time_key', 'Time'),
+)
 
-class _WideHelp(argparse.HelpFormatter):
-    def __init__(self, *a, **k):
-        super().__init__(*a, **k)
-        self._width = shutil.get_terminal_size().columns
+# flag table: (short, long, argparse keywords)
+OPTIONS = [
+    ('-ps', '--parameter_string', dict(metavar='PARAM_STRING', help='hyper-parameters inline: name=value pairs separated by commas; list values use "/" (layers=100/100)')),
+    ('-pf', '--parameter_file', dict(metavar='PARAM_PATH', help='python file that defines an OrderedDict called gru4rec_params')),
+    ('-l', '--load_model', dict(action='store_true', help='PATH is a saved model: skip training')),
+    ('-s', '--save_model', dict(metavar='MODEL_PATH', help='where to pickle the trained model (not saved by default)')),
+    ('-t', '--test', dict(metavar='TEST_PATH', nargs='+', help='one or more test sets to evaluate on')),
+    ('-m', '--measure', dict(metavar='AT', type=int, nargs='+', default=[20], help='cut-offs N for Recall@N / MRR@N (default 20)')),
+    ('-e', '--eval_type', dict(metavar='EVAL_TYPE', choices=['standard', 'conservative', 'median', 'tiebreaking'], default='standard',
+                               help='tie handling when ranking the target item (default standard)')),
+    ('-ss', '--sample_store_size', dict(metavar='SS', type=int, default=10000000, help='number of pre-drawn negative samples kept on the device (default 10000000)')),
+    (None, '--sample_store_on_cpu', dict(action='store_true', help='accepted for compatibility; the sample store of this implementation always lives in HBM')),
+    ('-g', '--gru4rec_model', dict(metavar='GRFILE', default='gru4rec_amd.gru4rec', help='module that provides the GRU4Rec class (default gru4rec_amd.gru4rec)')),
+    ('-ik', '--item_key', dict(metavar='IK', default='ItemId', help='item id column (default ItemId)')),
+    ('-sk', '--session_key', dict(metavar='SK', default='SessionId', help='session id column (default SessionId)')),
+    ('-tk', '--time_key', dict(metavar='TK', default='Time', help='timestamp column (default Time)')),
+    ('-pm', '--primary_metric', dict(metavar='METRIC', choices=['recall', 'mrr'], default='recall', help='metric reported on the PRIMARY METRIC line (default recall)')),
+    ('-lpm', '--log_primary_metric', dict(action='store_true', help='print the PRIMARY METRIC line after every evaluation')),
+]
 
 
 def build_parser():
-    p = argparse.ArgumentParser(formatter_class=_WideHelp, description='Train or load a GRU4Rec model & measure recall and MRR on the specified test set(s).')
-    p.add_argument('path', metavar='PATH', type=str, help='Path to the training data (TAB separated file (.tsv or .txt) or pickled pandas.DataFrame object (.pickle)) (if the --load_model parameter is NOT provided) or to the serialized model (if the --load_model parameter is provided).')
-    p.add_argument('-ps', '--parameter_string', metavar='PARAM_STRING', type=str, help='Training parameters as `name1=value1,name2=value2...`; lists use / (e.g. layers=200/200).')
-    p.add_argument('-pf', '--parameter_file', metavar='PARAM_PATH', type=str, help='Config file containing a single OrderedDict named `gru4rec_params`.')
-    p.add_argument('-l', '--load_model', action='store_true', help='Load an already trained model instead of training a model.')
-    p.add_argument('-s', '--save_model', metavar='MODEL_PATH', type=str, help='Save the trained model to the MODEL_PATH. (Default: don\'t save model)')
-    p.add_argument('-t', '--test', metavar='TEST_PATH', type=str, nargs='+', help='Path to the test data set(s) located at TEST_PATH.')
-    p.add_argument('-m', '--measure', metavar='AT', type=int, nargs='+', default=[20], help='Measure recall & MRR at the defined recommendation list length(s). (Default: 20)')
-    p.add_argument('-e', '--eval_type', metavar='EVAL_TYPE', choices=['standard', 'conservative', 'median', 'tiebreaking'], default='standard', help='How ties between prediction scores are handled. (Default: standard)')
-    p.add_argument('-ss', '--sample_store_size', metavar='SS', type=int, default=10000000, help='Size of the negative sample buffer. (Default: 10000000)')
-    p.add_argument('--sample_store_on_cpu', action='store_true', help='Kept for CLI compatibility: the MI355X path always keeps the sample store in HBM.')
-    p.add_argument('-g', '--gru4rec_model', metavar='GRFILE', type=str, default='gru4rec_amd.gru4rec', help='Module containing the GRU4Rec class. (Default: gru4rec_amd.gru4rec)')
-    p.add_argument('-ik', '--item_key', metavar='IK', type=str, default='ItemId', help='Column name corresponding to the item IDs (detault: ItemId).')
-    p.add_argument('-sk', '--session_key', metavar='SK', type=str, default='SessionId', help='Column name corresponding to the session IDs (default: SessionId).')
-    p.add_argument('-tk', '--time_key', metavar='TK', type=str, default='Time', help='Column name corresponding to the timestamp (default: Time).')
-    p.add_argument('-pm', '--primary_metric', metavar='METRIC', choices=['recall', 'mrr'], default='recall', help='Set primary metric, recall or mrr (e.g. for paropt). (Default: recall)')
-    p.add_argument('-lpm', '--log_primary_metric', action='store_true', help='If provided, evaluation will log the value of the primary metric at the end of the run.')
-    return p
+    ap = argparse.ArgumentParser(description='Train a GRU4Rec model on an MI355X (or load one) and report Recall@N / MRR@N.')
+    ap.add_argument('path', metavar='PATH', help='training data (.tsv / .txt with TAB separators, or a pickled DataFrame) -- or the model file when -l is given')
+    for short, long_, kw in OPTIONS:
+        ap.add_argument(*([short, long_] if short else [long_]), **kw)
+    return ap
 
 
-def _column_error(kind, key, fname):
-    print('ERROR. The column specified for {} "{}" is not in the data file ({})'.format(kind, key, fname))
-    default = {'session IDs': ('SessionId', 'session_key'), 'item IDs': ('ItemId', 'item_key'), 'time': ('Time', 'time_key')}[kind]
-    print('The default column name is "{}", but you can specify otherwise by setting the `{}` parameter of the model.'.format(*default))
+def fail_missing_column(what, column, default, fname):
+    print('ERROR. The column specified for {} "{}" is not in the data file ({})'.format(what, column, fname))
+    print('The default column name is "{}", but you can specify otherwise by setting the `{}` parameter of the model.'.format(
+        default, {'session IDs': 'session_key', 'item IDs': 'item_key', 'time': 'time_key'}[what]))
     sys.exit(1)
 
 
-def load_data(fname, args):
-    """TSV or pickled DataFrame with the three key columns; ItemId is read as str like the reference (run.py:77)."""
-    import joblib
+def read_events(fname, opts):
+    """Event table with the three key columns.  Item ids are kept as strings, session ids as int32."""
     import pandas as pd
-    keys = (('session IDs', args.session_key), ('item IDs', args.item_key), ('time', args.time_key))
-    if fname.endswith('.pickle'):
+    wanted = [(what, getattr(opts, attr), default) for what, attr, default in KEY_COLUMNS]
+    pickled = fname.endswith('.pickle')
+    if pickled:
+        import joblib
         print('Loading data from pickle file: {}'.format(fname))
-        data = joblib.load(fname)
-        for kind, key in keys:
-            if key not in data.columns:
-                _column_error(kind, key, fname)
-        return data
-    with open(fname, 'rt') as f:
-        header = f.readline().strip().split('\t')
-    for kind, key in keys:
-        if key not in header:
-            _column_error(kind, key, fname)
+        table = joblib.load(fname)
+        present = set(table.columns)
+    else:
+        with open(fname, 'rt') as fh:
+            present = set(fh.readline().rstrip('\n').split('\t'))
+    for what, column, default in wanted:
+        if column not in present:
+            fail_missing_column(what, column, default, fname)
+    if pickled:
+        return table
     print('Loading data from TAB separated file: {}'.format(fname))
-    return pd.read_csv(fname, sep='\t', usecols=[args.session_key, args.item_key, args.time_key],
-                       dtype={args.session_key: 'int32', args.item_key: 'str'})
+    cols = [c for _, c, _ in wanted]
+    return pd.read_csv(fname, sep='\t', usecols=cols, dtype={opts.session_key: 'int32', opts.item_key: 'str'})
+
+
+def hyper_parameters(opts):
+    if opts.parameter_file:
+        where = os.path.abspath(opts.parameter_file)
+        spec = importlib.util.spec_from_file_location(os.path.splitext(os.path.basename(where))[0], where)
+        module = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(module)
+        print('Loaded parameters from file: {}'.format(where))
+        return module.gru4rec_params
+    return OrderedDict(item.split('=') for item in opts.parameter_string.split(','))
+
+
+def train(model_cls, opts):
+    params = hyper_parameters(opts)
+    print('Creating GRU4Rec model')
+    model = model_cls()
+    model.set_params(**params)
+    print('Loading training data...')
+    events = read_events(opts.path, opts)
+    if opts.sample_store_on_cpu:
+        print('WARNING! The sample store is set to be on the CPU. This will make training significantly slower on the GPU.')
+    print('Started training')
+    started = time.time()
+    model.fit(events, sample_store=opts.sample_store_size, store_type='cpu' if opts.sample_store_on_cpu else 'gpu')
+    print('Total training time: {:.2f}s'.format(time.time() - started))
+    if opts.save_model is not None:
+        print('Saving trained model to: {}'.format(opts.save_model))
+        model.savemodel(opts.save_model)
+    return model
+
+
+def evaluate(model, opts):
+    from gru4rec_amd import evaluation
+    which = ('recall', 'mrr').index(opts.primary_metric.lower())
+    for fname in opts.test:
+        print('Loading test data...')
+        events = read_events(fname, opts)
+        print('Starting evaluation (cut-off={}, using {} mode for tiebreaking)'.format(opts.measure, opts.eval_type))
+        started = time.time()
+        scores = evaluation.evaluate_gpu(model, events, batch_size=512, cut_off=opts.measure, mode=opts.eval_type,
+                                         item_key=opts.item_key, session_key=opts.session_key, time_key=opts.time_key)
+        print('Evaluation took {:.2f}s'.format(time.time() - started))
+        for pos, cut in enumerate(opts.measure):
+            print('Recall@{}: {:.6f} MRR@{}: {:.6f}'.format(cut, scores[0][pos], cut, scores[1][pos]))
+        if opts.log_primary_metric:
+            print('PRIMARY METRIC: {}'.format(scores[which][0]))
 
 
 def main(argv=None):
-    args = build_parser().parse_args(argv)
-    if (args.parameter_string is not None) + (args.parameter_file is not None) + (args.load_model) != 1:
+    opts = build_parser().parse_args(argv)
+    sources = [opts.parameter_string is not None, opts.parameter_file is not None, bool(opts.load_model)]
+    if sum(sources) != 1:
         print('ERROR. Exactly one of the following parameters must be provided: --parameter_string, --parameter_file, --load_model')
         sys.exit(1)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    GRU4Rec = importlib.import_module(args.gru4rec_model).GRU4Rec
-    from gru4rec_amd import evaluation
-    if args.load_model:
-        print('Loading trained model from file: {}'.format(args.path))
-        gru = GRU4Rec.loadmodel(args.path)
+    model_cls = importlib.import_module(opts.gru4rec_model).GRU4Rec
+    if opts.load_model:
+        print('Loading trained model from file: {}'.format(opts.path))
+        model = model_cls.loadmodel(opts.path)
     else:
-        if args.parameter_file:
-            param_file_path = os.path.abspath(args.parameter_file)
-            spec = importlib.util.spec_from_file_location(os.path.basename(param_file_path).split('.py')[0], param_file_path)
-            params = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(params)
-            gru4rec_params = params.gru4rec_params
-            print('Loaded parameters from file: {}'.format(param_file_path))
-        if args.parameter_string:
-            gru4rec_params = OrderedDict([x.split('=') for x in args.parameter_string.split(',')])
-        print('Creating GRU4Rec model')
-        gru = GRU4Rec()
-        gru.set_params(**gru4rec_params)
-        print('Loading training data...')
-        data = load_data(args.path, args)
-        store_type = 'cpu' if args.sample_store_on_cpu else 'gpu'
-        if store_type == 'cpu':
-            print('WARNING! The sample store is set to be on the CPU. This will make training significantly slower on the GPU.')
-        print('Started training')
-        t0 = time.time()
-        gru.fit(data, sample_store=args.sample_store_size, store_type=store_type)
-        print('Total training time: {:.2f}s'.format(time.time() - t0))
-        if args.save_model is not None:
-            print('Saving trained model to: {}'.format(args.save_model))
-            gru.savemodel(args.save_model)
-    if args.test is not None:
-        pm_index = {'recall': 0, 'mrr': 1}[args.primary_metric.lower()]
-        for test_file in args.test:
-            print('Loading test data...')
-            test_data = load_data(test_file, args)
-            print('Starting evaluation (cut-off={}, using {} mode for tiebreaking)'.format(args.measure, args.eval_type))
-            t0 = time.time()
-            res = evaluation.evaluate_gpu(gru, test_data, batch_size=512, cut_off=args.measure, mode=args.eval_type,
-                                          item_key=args.item_key, session_key=args.session_key, time_key=args.time_key)
-            print('Evaluation took {:.2f}s'.format(time.time() - t0))
-            for i, c in enumerate(args.measure):
-                print('Recall@{}: {:.6f} MRR@{}: {:.6f}'.format(c, res[0][i], c, res[1][i]))
-            if args.log_primary_metric:
-                print('PRIMARY METRIC: {}'.format(res[pm_index][0]))
+        model = train(model_cls, opts)
+    if opts.test is not None:
+        evaluate(model, opts)
 
 
 if __name__ == '__main__':
