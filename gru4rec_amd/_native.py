@@ -40,7 +40,7 @@ SYMBOLS = [
     'g4r_get_param', 'g4r_set_popularity', 'g4r_set_sample_store', 'g4r_get_sample_store',
     'g4r_sample_store_rows', 'g4r_build_plan', 'g4r_set_plan', 'g4r_train_steps', 'g4r_get_losses',
     'g4r_synchronize', 'g4r_global_step', 'g4r_kernel_time', 'g4r_profile', 'g4r_reset_hidden',
-    'g4r_predict_begin', 'g4r_predict_hidden', 'g4r_predict_step', 'g4r_rank_targets', 'g4r_comm_unique_id',
+    'g4r_predict_begin', 'g4r_predict_hidden', 'g4r_predict_step', 'g4r_rank_targets', 'g4r_evaluate', 'g4r_comm_unique_id',
     'g4r_comm_init', 'g4r_comm_sync_sparse', 'g4r_comm_min_i64', 'g4r_get_debug', 'g4r_selftest_mfma',
 ]
 
@@ -90,6 +90,8 @@ def lib():
     L.g4r_predict_hidden.argtypes = [vp, u8p, i32p, i32]
     L.g4r_predict_step.argtypes = [vp, i32p, i32, i32p, i64, f32p]
     L.g4r_rank_targets.argtypes = [vp, i32p, i32, i64, i32, f32p]
+    L.g4r_evaluate.argtypes = [vp, i32p, i32p, u8p, i32p, i64, i32, i64p, i32p, i64, i32p, i64, i32p, i32, i32,
+                               C.POINTER(C.c_double), C.POINTER(C.c_double), i64p]
     L.g4r_comm_unique_id.argtypes = [C.c_char_p]
     L.g4r_comm_init.argtypes = [vp, C.c_char_p, i32, i32]
     L.g4r_comm_sync_sparse.argtypes = [vp]
@@ -297,6 +299,24 @@ class Model:
         return r
 
     # -- multi-GPU
+    def evaluate(self, plan, batch, items, cutoffs, mode):
+        """Whole evaluation in one call (g4r_evaluate).  Returns (recall_sum[n_cut], mrr_sum[n_cut], n_events)."""
+        T = int(plan['T'])
+        cuts = np.ascontiguousarray(cutoffs, dtype=np.int32)
+        rec = np.zeros(len(cuts), dtype=np.float64)
+        mrr = np.zeros(len(cuts), dtype=np.float64)
+        n = C.c_int64(0)
+        it = None if items is None else np.ascontiguousarray(items, dtype=np.int32)
+        nc = int(plan.get('n_compact', 0))
+        cs = np.ascontiguousarray(plan['compact_steps'], dtype=np.int64) if nc else np.zeros(1, dtype=np.int64)
+        cm = np.ascontiguousarray(plan['compact_maps'], dtype=np.int32) if nc else np.zeros((1, batch), dtype=np.int32)
+        arr = {k: np.ascontiguousarray(plan[k]) for k in ('in_idx', 'out_idx', 'reset', 'M')}
+        _chk(lib().g4r_evaluate(self.h, _i32(arr['in_idx']), _i32(arr['out_idx']), _u8(arr['reset']), _i32(arr['M']), T, batch,
+                                _i64(cs), _i32(cm), nc, None if it is None else _i32(it), 0 if it is None else len(it),
+                                _i32(cuts), len(cuts), RANK_MODES[mode], rec.ctypes.data_as(C.POINTER(C.c_double)),
+                                mrr.ctypes.data_as(C.POINTER(C.c_double)), C.byref(n)))
+        return rec, mrr, int(n.value)
+
     def comm_init(self, unique_id, nranks, rank):
         _chk(lib().g4r_comm_init(self.h, unique_id, nranks, rank))
 

@@ -805,6 +805,8 @@ int g4r_predict_hidden(g4r_model* m, const uint8_t* zero_mask, const int32_t* ke
     return 0;
 }
 
+static int predict_forward(g4r_model* m, const int* d_in_idx, int mrows, const int* d_items, int64_t n_sel);
+
 int g4r_predict_step(g4r_model* m, const int32_t* in_idx, int32_t mrows, const int32_t* item_idx, int64_t n_sel,
                      float* out_scores) {
     if (!m || !in_idx) return fail("null argument");
@@ -827,35 +829,8 @@ int g4r_predict_step(g4r_model* m, const int32_t* in_idx, int32_t mrows, const i
             if (item_idx[i] < 0 || item_idx[i] >= d.n_items) return fail("item index out of range");
         HIPCHK(hipMemcpyAsync(m->p_items, item_idx, n_sel * sizeof(int), hipMemcpyHostToDevice, m->stream));
     }
-    const int64_t ldo = (n_sel + 3) & ~3LL;
-    if ((int64_t)m->pbatch * ldo > m->p_scores_cap) {
-        HIPCHK(hipStreamSynchronize(m->stream));
-        dfree(m, m->p_scores);
-        if (dalloc(m, &m->p_scores, (size_t)m->pbatch * ldo, false)) return -1;
-        m->p_scores_cap = (int64_t)m->pbatch * ldo;
-    }
-    for (int l = 0; l < d.n_layers; ++l) {
-        GruFwdPredict pa;
-        pa.in_idx = (GP(const int))m->p_in;
-        pa.ysrc = (GP(const float))(l > 0 ? m->phout[l - 1] : nullptr);
-        pa.Hcur = (GP(const float))m->pH[l][m->ppar];
-        pa.Hnext = (GP(float))m->pH[l][m->ppar ^ 1];
-        pa.hout = (GP(float))m->phout[l];
-        pa.Vc = (GP(float))m->pVc[l]; pa.z = (GP(float))m->pz[l]; pa.Hr = (GP(float))m->pHr[l];
-        pa.M = mrows;
-        hipLaunchKernelGGL(k_gru_p1, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1, m->stream,
-                           (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, 0, pa);
-        hipLaunchKernelGGL(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(GT_NTH), SMEM_NN, m->stream,
-                           (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, pa);
-    }
-    m->ppar ^= 1;
-    const bool sm = (d.final_act == G4R_ACT_SOFTMAX || d.final_act == G4R_ACT_SOFTMAX_LOGIT);   // gru4rec.py:499-500
-    hipLaunchKernelGGL(k_score_all<32>, dim3(cdiv(n_sel, 32), cdiv(mrows, SC_BM)), dim3(256), m->smem_score, m->stream, (const DevModel*)m->d_dm,
-                       (const float*)m->phout[d.n_layers - 1], (int)mrows, item_idx ? (const int*)m->p_items : (const int*)nullptr,
-                       (long long)n_sel, m->p_scores, (long long)ldo, sm ? 0 : 1);
-    if (sm) hipLaunchKernelGGL(k_softmax_rows, dim3(mrows), dim3(256), 0, m->stream, m->p_scores, (long long)n_sel, (long long)ldo);
-    HIPCHK(hipGetLastError());
-    m->p_nsel = n_sel; m->p_ldo = ldo;
+    if (predict_forward(m, m->p_in, mrows, item_idx ? (const int*)m->p_items : (const int*)nullptr, n_sel)) return -1;
+    const int64_t ldo = m->p_ldo;
     if (out_scores) {
         HIPCHK(hipMemcpy2DAsync(out_scores, n_sel * sizeof(float), m->p_scores, ldo * sizeof(float), n_sel * sizeof(float), mrows,
                                 hipMemcpyDeviceToHost, m->stream));
@@ -877,6 +852,126 @@ int g4r_rank_targets(g4r_model* m, const int32_t* target_col, int32_t mrows, int
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ranks, m->p_ranks, mrows * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+// forward GRU + scores of `mrows` rows whose input items sit on the device (shared by g4r_predict_step / g4r_evaluate)
+static int predict_forward(g4r_model* m, const int* d_in_idx, int mrows, const int* d_items, int64_t n_sel) {
+    DevModel& d = m->dm;
+    const int64_t ldo = (n_sel + 3) & ~3LL;
+    if ((int64_t)m->pbatch * ldo > m->p_scores_cap) {
+        HIPCHK(hipStreamSynchronize(m->stream));
+        dfree(m, m->p_scores);
+        if (dalloc(m, &m->p_scores, (size_t)m->pbatch * ldo, false)) return -1;
+        m->p_scores_cap = (int64_t)m->pbatch * ldo;
+    }
+    for (int l = 0; l < d.n_layers; ++l) {
+        GruFwdPredict pa;
+        pa.in_idx = (GP(const int))d_in_idx;
+        pa.ysrc = (GP(const float))(l > 0 ? m->phout[l - 1] : nullptr);
+        pa.Hcur = (GP(const float))m->pH[l][m->ppar];
+        pa.Hnext = (GP(float))m->pH[l][m->ppar ^ 1];
+        pa.hout = (GP(float))m->phout[l];
+        pa.Vc = (GP(float))m->pVc[l]; pa.z = (GP(float))m->pz[l]; pa.Hr = (GP(float))m->pHr[l];
+        pa.M = mrows;
+        hipLaunchKernelGGL(k_gru_p1, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1, m->stream,
+                           (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, 0, pa);
+        hipLaunchKernelGGL(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(GT_NTH), SMEM_NN, m->stream,
+                           (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, pa);
+    }
+    m->ppar ^= 1;
+    const bool sm = (d.final_act == G4R_ACT_SOFTMAX || d.final_act == G4R_ACT_SOFTMAX_LOGIT);   // gru4rec.py:499-500
+    hipLaunchKernelGGL(k_score_all<32>, dim3(cdiv(n_sel, 32), cdiv(mrows, SC_BM)), dim3(256), m->smem_score, m->stream, (const DevModel*)m->d_dm,
+                       (const float*)m->phout[d.n_layers - 1], (int)mrows, d_items, (long long)n_sel, m->p_scores, (long long)ldo, sm ? 0 : 1);
+    if (sm) hipLaunchKernelGGL(k_softmax_rows, dim3(mrows), dim3(256), 0, m->stream, m->p_scores, (long long)n_sel, (long long)ldo);
+    HIPCHK(hipGetLastError());
+    m->p_nsel = n_sel; m->p_ldo = ldo;
+    return 0;
+}
+
+int g4r_evaluate(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, const uint8_t* reset, const int32_t* M, int64_t T,
+                 int32_t batch, const int64_t* compact_steps, const int32_t* compact_maps, int64_t n_compact,
+                 const int32_t* items, int64_t n_items_sel, const int32_t* cutoffs, int32_t n_cut, int32_t mode,
+                 double* recall_sum, double* mrr_sum, int64_t* n_events) {
+    if (!m || !in_idx || !out_idx || !reset || !M || !cutoffs || !recall_sum || !mrr_sum || !n_events) return fail("null argument");
+    if (T < 0 || batch < 1 || n_cut < 1 || n_cut > 64) return fail("bad evaluation sizes");
+    if (mode < 0 || mode > G4R_RANK_MEDIAN) return fail("unknown rank mode");
+    if (n_compact > 0 && (!compact_steps || !compact_maps)) return fail("compaction arrays missing");
+    DevModel& d = m->dm;
+    const int B = batch;
+    for (int64_t i = 0; i < T * B; ++i)
+        if (in_idx[i] < 0 || in_idx[i] >= d.n_items || out_idx[i] < 0 || out_idx[i] >= d.n_items) return fail("plan item index out of range");
+    for (int64_t i = 0; i < n_items_sel; ++i)
+        if (items[i] < 0 || items[i] >= d.n_items) return fail("item index out of range");
+    if (g4r_predict_begin(m, batch)) return -1;            // fresh (zero) hidden state, scratch for `batch` rows
+    int *e_in = nullptr, *e_out = nullptr, *e_M = nullptr, *e_maps = nullptr, *e_items = nullptr, *e_cand = nullptr, *e_cut = nullptr, *e_iota = nullptr;
+    unsigned char* e_reset = nullptr;
+    double* e_acc = nullptr;            // [rec(n_cut) | mrr(n_cut)]
+    long long* e_n = nullptr;
+    const size_t TB = (size_t)std::max<int64_t>(T, 1) * B;
+    auto cleanup = [&]() {
+        dfree(m, e_in); dfree(m, e_out); dfree(m, e_M); dfree(m, e_maps); dfree(m, e_items); dfree(m, e_cand); dfree(m, e_cut);
+        dfree(m, e_iota); dfree(m, e_reset); dfree(m, e_acc); dfree(m, e_n);
+    };
+    if (dalloc(m, &e_in, TB, false) || dalloc(m, &e_out, TB, false) || dalloc(m, &e_reset, TB, false) ||
+        dalloc(m, &e_maps, (size_t)std::max<int64_t>(n_compact, 1) * B, false) || dalloc(m, &e_cut, n_cut, false) ||
+        dalloc(m, &e_acc, 2 * (size_t)n_cut) || dalloc(m, &e_n, 1) || dalloc(m, &e_iota, B, false) ||
+        (items && (dalloc(m, &e_items, (size_t)n_items_sel, false) || dalloc(m, &e_cand, (size_t)B + n_items_sel, false)))) {
+        cleanup();
+        return -1;
+    }
+#define EVCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(std::string(#x ": ") + hipGetErrorString(e_)); } } while (0)
+    hipStream_t s = m->stream;
+    if (T > 0) {
+        EVCHK(hipMemcpyAsync(e_in, in_idx, TB * sizeof(int), hipMemcpyHostToDevice, s));
+        EVCHK(hipMemcpyAsync(e_out, out_idx, TB * sizeof(int), hipMemcpyHostToDevice, s));
+        EVCHK(hipMemcpyAsync(e_reset, reset, TB, hipMemcpyHostToDevice, s));
+    }
+    if (n_compact > 0) EVCHK(hipMemcpyAsync(e_maps, compact_maps, (size_t)n_compact * B * sizeof(int), hipMemcpyHostToDevice, s));
+    EVCHK(hipMemcpyAsync(e_cut, cutoffs, n_cut * sizeof(int), hipMemcpyHostToDevice, s));
+    if (items) EVCHK(hipMemcpyAsync(e_items, items, (size_t)n_items_sel * sizeof(int), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_iota, dim3(cdiv(B, 256)), dim3(256), 0, s, e_iota, B);
+    int64_t ci = 0;
+    for (int64_t t = 0; t < T; ++t) {
+        const int Mt = M[t];
+        if (Mt < 1 || Mt > B) { cleanup(); return fail("plan M out of range"); }
+        // rows of exhausted slots are dropped before this step (evaluation.py:138; gru4rec.py:647-651 for the same plan format)
+        while (ci < n_compact && compact_steps[ci] == t) {
+            for (int l = 0; l < d.n_layers; ++l)
+                hipLaunchKernelGGL(k_gather_rows, dim3(cdiv((long long)B * d.D[l], 256)), dim3(256), 0, s, m->pH[l][m->ppar ^ 1],
+                                   (const float*)m->pH[l][m->ppar], (const int*)(e_maps + ci * B), B, d.D[l]);
+            m->ppar ^= 1;
+            ++ci;
+        }
+        const int* tgt = e_out + t * B;
+        if (items) {
+            hipLaunchKernelGGL(k_eval_candidates, dim3(cdiv((long long)Mt + n_items_sel, 256)), dim3(256), 0, s, e_cand, tgt, Mt,
+                               (const int*)e_items, (long long)n_items_sel);
+            if (predict_forward(m, e_in + t * B, Mt, e_cand, Mt + n_items_sel)) { cleanup(); return -1; }
+            hipLaunchKernelGGL(k_rank_rows, dim3(Mt), dim3(256), 0, s, (const float*)m->p_scores, (long long)m->p_nsel, (long long)m->p_ldo,
+                               (const int*)e_iota, (long long)Mt, (int)mode, m->p_ranks);
+        } else {
+            if (predict_forward(m, e_in + t * B, Mt, nullptr, d.n_items)) { cleanup(); return -1; }
+            hipLaunchKernelGGL(k_rank_rows, dim3(Mt), dim3(256), 0, s, (const float*)m->p_scores, (long long)m->p_nsel, (long long)m->p_ldo,
+                               tgt, 0LL, (int)mode, m->p_ranks);
+        }
+        hipLaunchKernelGGL(k_eval_accum, dim3(1), dim3(256), 0, s, (const float*)m->p_ranks, Mt, (const int*)e_cut, (int)n_cut, e_acc,
+                           e_acc + n_cut, e_n);
+        // hidden rows of sessions that ended with this step start from zero (evaluation.py:137)
+        for (int l = 0; l < d.n_layers; ++l)
+            hipLaunchKernelGGL(k_zero_rows, dim3(cdiv((long long)Mt * d.D[l], 256)), dim3(256), 0, s, m->pH[l][m->ppar],
+                               (const unsigned char*)(e_reset + t * B), Mt, d.D[l]);
+    }
+    EVCHK(hipGetLastError());
+    std::vector<double> acc(2 * (size_t)n_cut);
+    long long n = 0;
+    EVCHK(hipMemcpyAsync(acc.data(), e_acc, acc.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    EVCHK(hipMemcpyAsync(&n, e_n, sizeof(n), hipMemcpyDeviceToHost, s));
+    EVCHK(hipStreamSynchronize(s));
+#undef EVCHK
+    for (int c = 0; c < n_cut; ++c) { recall_sum[c] = acc[c]; mrr_sum[c] = acc[n_cut + c]; }
+    *n_events = n;
+    cleanup();
     return 0;
 }
 

@@ -128,6 +128,41 @@ __global__ __launch_bounds__(256) void k_zero_rows(float* H, const unsigned char
     if (zero_mask[e / W]) H[e] = 0.f;
 }
 
+// ---- device-resident evaluation (evaluation.py:15-147 as one call, g4r_evaluate) -------------------------------
+// candidate list of one step when `items` are given: [targets of the M rows | items]   (evaluation.py:103-104)
+__global__ __launch_bounds__(256) void k_eval_candidates(int* cand, const int* tgt, int M, const int* items, long long n_items_sel) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e < M) cand[e] = tgt[e];
+    else if (e < M + n_items_sel) cand[e] = items[e - M];
+}
+__global__ __launch_bounds__(256) void k_iota(int* p, int n) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n) p[e] = e;
+}
+// recall[c] += #(rank <= cut_c), mrr[c] += sum over those rows of 1 / rank, n += M  (evaluation.py:66-72,106-114);
+// one workgroup, fixed summation order, double accumulators
+__global__ __launch_bounds__(256) void k_eval_accum(const float* ranks, int M, const int* cuts, int n_cut, double* rec, double* mrr,
+                                                    long long* n) {
+    __shared__ double sh[2][256];
+    for (int c = 0; c < n_cut; ++c) {
+        const float cut = (float)cuts[c];
+        double h = 0.0, r = 0.0;
+        for (int i = threadIdx.x; i < M; i += 256) {
+            const float rk = ranks[i];
+            if (rk <= cut) { h += 1.0; r += 1.0 / (double)rk; }
+        }
+        sh[0][threadIdx.x] = h; sh[1][threadIdx.x] = r;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { rec[c] += sh[0][0]; mrr[c] += sh[1][0]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n += M;
+}
+
 // 16x16x4 fp32 MFMA operand/accumulator layout self-test: C = A(16xK) * B(Kx16), asymmetric inputs
 __global__ void k_selftest_mfma(const float* A, const float* Bm, float* C, int K) {
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;

@@ -1,17 +1,58 @@
 """Recall@N / MRR@N on the device: same signature and results as the reference's
 `evaluation.evaluate_gpu` (evaluation.py:15-147), without the Theano graph.
 
-The session-parallel test loop (evaluation.py:90-139) runs on the host; every step is one
-`g4r_predict_step` (GRU forward + scores against all / the given items, final activation applied in
-fp32 as the reference does) followed by `g4r_rank_targets` (the > / >= / == counts of :62-65).
+`evaluate_gpu` hands the whole test loop to the device in ONE call (`g4r_evaluate`): the session-parallel schedule
+of evaluation.py:96-139 is the schedule of `fit` (same author, same loop), so the C++ plan builder produces it; every
+step runs the GRU forward, scores all / the given items (final activation applied in fp32 as the reference does), ranks
+the targets with the > / >= / == counts of :62-65 and adds the hits and reciprocal ranks of every cut-off into device
+accumulators; hidden rows of finished sessions are zeroed / dropped on the device.  `evaluate_gpu_stepwise` is the
+host-driven variant (one `g4r_predict_step` + `g4r_rank_targets` per step), kept as a cross-check.
 """
 import numpy as np
 import pandas as pd
 
 
+def _prepare(gru, test_data, items, session_key, item_key, time_key):
+    lookup = pd.DataFrame({'ItemIdx': gru.itemidmap.values, item_key: gru.itemidmap.index})
+    test_data = pd.merge(test_data, lookup, on=item_key, how='inner')
+    test_data.sort_values([session_key, time_key, item_key], inplace=True)
+    titems = test_data.ItemIdx.values.astype(np.int32)
+    item_idxs = None if items is None else gru.itemidmap[items].values.astype(np.int32)
+    sizes = test_data.groupby(session_key).size().values
+    offs = np.zeros(len(sizes) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(sizes)
+    return titems, item_idxs, offs
+
+
 def evaluate_gpu(gru, test_data, items=None, session_key='SessionId', item_key='ItemId', time_key='Time',
                  cut_off=[20], batch_size=100, mode='standard'):
-    """Returns (recall list, mrr list) -- one entry per cut-off, like the reference."""
+    """Returns (recall list, mrr list) -- one entry per cut-off, like the reference.  One device call for the whole test."""
+    from . import _native
+    if gru.error_during_train:
+        raise Exception
+    if mode not in ('standard', 'conservative', 'median', 'tiebreaking'):
+        raise NotImplementedError
+    multi = isinstance(cut_off, (list, tuple))
+    cuts = list(cut_off) if multi else [cut_off]
+    print('Measuring Recall@{} and MRR@{}'.format(','.join(str(c) for c in cuts), ','.join(str(c) for c in cuts)))
+    if mode == 'tiebreaking':
+        # the reference adds uniform*1e-10 to the scores (evaluation.py:55) and then ranks as 'standard'; the
+        # perturbation is below fp32 resolution for scores of ordinary magnitude, so ranks equal 'standard'
+        mode = 'standard'
+    model = gru._ensure_model()
+    titems, item_idxs, offs = _prepare(gru, test_data, items, session_key, item_key, time_key)
+    n_sessions = len(offs) - 1
+    if n_sessions < batch_size:
+        raise IndexError('fewer test sessions ({}) than batch_size ({})'.format(n_sessions, batch_size))
+    # sessions in id order (evaluation.py:90-95); n_sample = 1 selects "run until no session is left" (:124-127)
+    plan = _native.build_plan(offs.astype(np.int32), np.arange(n_sessions), titems, batch_size, 1)
+    rec, mrr, n = model.evaluate(plan, batch_size, item_idxs, cuts, mode)
+    return (rec / n).tolist(), (mrr / n).tolist()
+
+
+def evaluate_gpu_stepwise(gru, test_data, items=None, session_key='SessionId', item_key='ItemId', time_key='Time',
+                          cut_off=[20], batch_size=100, mode='standard'):
+    """Host-driven variant of evaluate_gpu: the loop of evaluation.py:96-139 in Python, one device step at a time."""
     if gru.error_during_train:
         raise Exception
     if mode not in ('standard', 'conservative', 'median', 'tiebreaking'):

@@ -132,6 +132,17 @@ int g4r_predict_step(g4r_model* m, const int32_t* in_idx, int32_t mrows, const i
 int g4r_rank_targets(g4r_model* m, const int32_t* target_col, int32_t mrows, int64_t col_begin, int32_t mode,
                      float* ranks);
 
+/* The whole of evaluation.evaluate_gpu (evaluation.py:86-147) as ONE call with no host round trip per step: the
+ * session-parallel test loop comes as a plan (g4r_build_plan on the test sessions in id order with n_sample = 1: the loop of
+ * evaluation.py:96-139 is the loop of fit), every step runs the GRU forward, scores all items (items == NULL) or
+ * [targets | items], ranks the targets (mode = G4R_RANK_*), and adds #(rank <= cut) and sum 1/rank for each cut-off into
+ * device accumulators; hidden rows of finished sessions are zeroed / dropped on the device (evaluation.py:134-139).
+ * Outputs: recall_sum[n_cut], mrr_sum[n_cut] (divide by *n_events). */
+int g4r_evaluate(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, const uint8_t* reset, const int32_t* M, int64_t T,
+                 int32_t batch, const int64_t* compact_steps, const int32_t* compact_maps, int64_t n_compact,
+                 const int32_t* items, int64_t n_items_sel, const int32_t* cutoffs, int32_t n_cut, int32_t mode,
+                 double* recall_sum, double* mrr_sum, int64_t* n_events);
+
 /* ---- multi-GPU (new: the reference is single-GPU).  RCCL all-reduce of dense GRU gradients ---- */
 int g4r_comm_unique_id(char* out128);                         /* rank 0: ncclGetUniqueId */
 int g4r_comm_init(g4r_model* m, const char* id128, int32_t nranks, int32_t rank);

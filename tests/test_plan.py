@@ -67,3 +67,45 @@ def test_too_few_sessions_is_an_error():
     off = np.array([0, 2, 4], dtype=np.int32)
     with pytest.raises(_native.NativeError):
         _native.build_plan(off, np.arange(2), np.arange(4, dtype=np.int32), 4, 0)
+
+
+def test_train_plan_builder_reproduces_the_evaluation_schedule():
+    """evaluation.py:96-139 is the loop of fit (gru4rec.py:594-651): the C++ plan builder with n_sample = 1 (run until no
+    session is left) must emit exactly the steps / zeroed rows / dropped rows of the restated evaluation loop."""
+    from oracle.scheduler import eval_schedule
+    rng = np.random.RandomState(3)
+    for B, n_sess in ((4, 9), (7, 40), (16, 16), (5, 23)):
+        lens = rng.randint(1, 9, size=n_sess)
+        lens[rng.randint(0, n_sess, size=3)] = 1          # sessions without a target are skipped over by both loops
+        offs = np.zeros(n_sess + 1, dtype=np.int32)
+        offs[1:] = np.cumsum(lens)
+        items = rng.randint(0, 50, size=offs[-1]).astype(np.int32)
+        if (offs[1:B + 1] - offs[:B]).min() < 1:
+            continue
+        plan = _native.build_plan(offs, np.arange(n_sess), items, B, 1)
+        t = 0
+        nrows = B
+        ci = 0
+        stepped = False
+        for ev in eval_schedule(offs, items, B):
+            if ev[0] == 'step':
+                _, cur_in, cur_out, M = ev
+                assert plan['M'][t] == M == nrows
+                np.testing.assert_array_equal(plan['in_idx'][t, :M], cur_in)
+                np.testing.assert_array_equal(plan['out_idx'][t, :M], cur_out)
+                t += 1
+                stepped = True
+            else:
+                _, zero_mask, valid = ev
+                # rows zeroed by the evaluation loop carry the reset flag of the step that ended their session (a slot that
+                # was just refilled with a one-event session is zeroed again without a step in between: still zero)
+                if stepped:
+                    assert (plan['reset'][t - 1, :nrows][zero_mask] == 1).all()
+                stepped = False
+                if not valid.all():
+                    assert plan['compact_steps'][ci] == t
+                    keep = np.nonzero(valid)[0]
+                    np.testing.assert_array_equal(plan['compact_maps'][ci][:len(keep)], keep)
+                    ci += 1
+                nrows = int(valid.sum())
+        assert t == plan['T'] and ci == plan['n_compact']
