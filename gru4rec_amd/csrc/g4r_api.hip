@@ -83,6 +83,7 @@ struct g4r_model {
     int *p_in = nullptr, *p_items = nullptr, *p_tgt = nullptr, *p_keep = nullptr;
     unsigned char* p_zero = nullptr;
     float *p_scores = nullptr, *p_ranks = nullptr;
+    int* p_cnt = nullptr;                        // [pbatch][2] streamed (greater, equal) counts of the evaluation
     int64_t p_scores_cap = 0, p_items_cap = 0, p_nsel = 0, p_ldo = 0;
     // rccl
     ncclComm_t comm = nullptr;
@@ -106,6 +107,8 @@ static void dfree(g4r_model* m, void* p) {
     (void)hipFree(p);
 }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static constexpr auto k_score_store = k_score_all<32, false>;     // scores -> memory
+static constexpr auto k_score_count = k_score_all<32, true>;      // scores compared with the row's target on the fly
 
 // dynamic LDS of the tile-GEMM kernels (g4r_gemm.cuh)
 template <int BM, int BN, int BK, bool AKM, bool BNK>
@@ -280,7 +283,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_score_all<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_score_store, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_score_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel"); }
     if (getenv("G4R_CLK")) { if (dalloc(m, &d.dbgclk, 64 + 8 * (size_t)d.R)) { g4r_destroy(m); return -1; } }
@@ -764,9 +768,9 @@ int g4r_predict_begin(g4r_model* m, int32_t batch) {
                 dalloc(m, &m->phout[l], (size_t)batch * d.D[l]))
                 return -1;
         }
-        dfree(m, m->p_in); dfree(m, m->p_tgt); dfree(m, m->p_keep); dfree(m, m->p_zero); dfree(m, m->p_ranks);
+        dfree(m, m->p_in); dfree(m, m->p_tgt); dfree(m, m->p_keep); dfree(m, m->p_zero); dfree(m, m->p_ranks); dfree(m, m->p_cnt);
         if (dalloc(m, &m->p_in, batch) || dalloc(m, &m->p_tgt, batch) || dalloc(m, &m->p_keep, batch) ||
-            dalloc(m, &m->p_zero, batch) || dalloc(m, &m->p_ranks, batch))
+            dalloc(m, &m->p_zero, batch) || dalloc(m, &m->p_ranks, batch) || dalloc(m, &m->p_cnt, 2 * (size_t)batch))
             return -1;
         m->pbatch = batch;
     } else {
@@ -805,7 +809,8 @@ int g4r_predict_hidden(g4r_model* m, const uint8_t* zero_mask, const int32_t* ke
     return 0;
 }
 
-static int predict_forward(g4r_model* m, const int* d_in_idx, int mrows, const int* d_items, int64_t n_sel);
+struct StreamRank;
+static int predict_forward(g4r_model* m, const int* d_in_idx, int mrows, const int* d_items, int64_t n_sel, const StreamRank* stream);
 
 int g4r_predict_step(g4r_model* m, const int32_t* in_idx, int32_t mrows, const int32_t* item_idx, int64_t n_sel,
                      float* out_scores) {
@@ -829,7 +834,7 @@ int g4r_predict_step(g4r_model* m, const int32_t* in_idx, int32_t mrows, const i
             if (item_idx[i] < 0 || item_idx[i] >= d.n_items) return fail("item index out of range");
         HIPCHK(hipMemcpyAsync(m->p_items, item_idx, n_sel * sizeof(int), hipMemcpyHostToDevice, m->stream));
     }
-    if (predict_forward(m, m->p_in, mrows, item_idx ? (const int*)m->p_items : (const int*)nullptr, n_sel)) return -1;
+    if (predict_forward(m, m->p_in, mrows, item_idx ? (const int*)m->p_items : (const int*)nullptr, n_sel, nullptr)) return -1;
     const int64_t ldo = m->p_ldo;
     if (out_scores) {
         HIPCHK(hipMemcpy2DAsync(out_scores, n_sel * sizeof(float), m->p_scores, ldo * sizeof(float), n_sel * sizeof(float), mrows,
@@ -856,14 +861,20 @@ int g4r_rank_targets(g4r_model* m, const int32_t* target_col, int32_t mrows, int
 }
 
 // forward GRU + scores of `mrows` rows whose input items sit on the device (shared by g4r_predict_step / g4r_evaluate)
-static int predict_forward(g4r_model* m, const int* d_in_idx, int mrows, const int* d_items, int64_t n_sel) {
+// stream = nullptr: scores of all candidates go to p_scores (final activation applied).  Otherwise (evaluation with an
+// element-wise final activation) nothing is materialised: stream->tgt lists the target item of every row; their scores are
+// computed first (mrows x mrows tile, diagonal used), then every candidate tile is compared with them on the fly and
+// p_ranks receives the ranks (stream->mode, candidates from column stream->col_begin on).
+struct StreamRank { const int* tgt; long long col_begin; int mode; };
+static int predict_forward(g4r_model* m, const int* d_in_idx, int mrows, const int* d_items, int64_t n_sel, const StreamRank* stream) {
     DevModel& d = m->dm;
-    const int64_t ldo = (n_sel + 3) & ~3LL;
-    if ((int64_t)m->pbatch * ldo > m->p_scores_cap) {
+    const int64_t ldo = stream ? ((mrows + 3) & ~3) : ((n_sel + 3) & ~3LL);
+    const int64_t need = stream ? (int64_t)m->pbatch * ((m->pbatch + 3) & ~3) : (int64_t)m->pbatch * ldo;
+    if (need > m->p_scores_cap) {
         HIPCHK(hipStreamSynchronize(m->stream));
         dfree(m, m->p_scores);
-        if (dalloc(m, &m->p_scores, (size_t)m->pbatch * ldo, false)) return -1;
-        m->p_scores_cap = (int64_t)m->pbatch * ldo;
+        if (dalloc(m, &m->p_scores, (size_t)need, false)) return -1;
+        m->p_scores_cap = need;
     }
     for (int l = 0; l < d.n_layers; ++l) {
         GruFwdPredict pa;
@@ -881,8 +892,20 @@ static int predict_forward(g4r_model* m, const int* d_in_idx, int mrows, const i
     }
     m->ppar ^= 1;
     const bool sm = (d.final_act == G4R_ACT_SOFTMAX || d.final_act == G4R_ACT_SOFTMAX_LOGIT);   // gru4rec.py:499-500
-    hipLaunchKernelGGL(k_score_all<32>, dim3(cdiv(n_sel, 32), cdiv(mrows, SC_BM)), dim3(256), m->smem_score, m->stream, (const DevModel*)m->d_dm,
-                       (const float*)m->phout[d.n_layers - 1], (int)mrows, d_items, (long long)n_sel, m->p_scores, (long long)ldo, sm ? 0 : 1);
+    const float* hsrc = (const float*)m->phout[d.n_layers - 1];
+    if (stream) {
+        if (sm) return fail("internal: streaming ranks need an element-wise final activation");
+        hipLaunchKernelGGL(k_score_store, dim3(cdiv(mrows, 32), cdiv(mrows, SC_BM)), dim3(256), m->smem_score, m->stream, (const DevModel*)m->d_dm,
+                           hsrc, (int)mrows, stream->tgt, (long long)mrows, m->p_scores, (long long)ldo, 1, (int*)nullptr, 0LL);
+        hipLaunchKernelGGL(k_score_count, dim3(cdiv(n_sel, 32), cdiv(mrows, SC_BM)), dim3(256), m->smem_score, m->stream, (const DevModel*)m->d_dm,
+                           hsrc, (int)mrows, d_items, (long long)n_sel, m->p_scores, (long long)ldo, 1, m->p_cnt, stream->col_begin);
+        hipLaunchKernelGGL(k_rank_counts, dim3(cdiv(mrows, 256)), dim3(256), 0, m->stream, m->p_cnt, (int)mrows, stream->mode, m->p_ranks);
+        HIPCHK(hipGetLastError());
+        m->p_nsel = 0; m->p_ldo = ldo;        // no score matrix to read back
+        return 0;
+    }
+    hipLaunchKernelGGL(k_score_store, dim3(cdiv(n_sel, 32), cdiv(mrows, SC_BM)), dim3(256), m->smem_score, m->stream, (const DevModel*)m->d_dm,
+                       hsrc, (int)mrows, d_items, (long long)n_sel, m->p_scores, (long long)ldo, sm ? 0 : 1, (int*)nullptr, 0LL);
     if (sm) hipLaunchKernelGGL(k_softmax_rows, dim3(mrows), dim3(256), 0, m->stream, m->p_scores, (long long)n_sel, (long long)ldo);
     HIPCHK(hipGetLastError());
     m->p_nsel = n_sel; m->p_ldo = ldo;
@@ -931,6 +954,8 @@ int g4r_evaluate(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
     EVCHK(hipMemcpyAsync(e_cut, cutoffs, n_cut * sizeof(int), hipMemcpyHostToDevice, s));
     if (items) EVCHK(hipMemcpyAsync(e_items, items, (size_t)n_items_sel * sizeof(int), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_iota, dim3(cdiv(B, 256)), dim3(256), 0, s, e_iota, B);
+    const bool sm_act = (d.final_act == G4R_ACT_SOFTMAX || d.final_act == G4R_ACT_SOFTMAX_LOGIT);
+    const bool streaming = !sm_act && !getenv("G4R_EVAL_MATERIALIZE");
     int64_t ci = 0;
     for (int64_t t = 0; t < T; ++t) {
         const int Mt = M[t];
@@ -944,16 +969,23 @@ int g4r_evaluate(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
             ++ci;
         }
         const int* tgt = e_out + t * B;
+        const int* cand = nullptr;
+        int64_t n_sel = d.n_items;
         if (items) {
             hipLaunchKernelGGL(k_eval_candidates, dim3(cdiv((long long)Mt + n_items_sel, 256)), dim3(256), 0, s, e_cand, tgt, Mt,
                                (const int*)e_items, (long long)n_items_sel);
-            if (predict_forward(m, e_in + t * B, Mt, e_cand, Mt + n_items_sel)) { cleanup(); return -1; }
-            hipLaunchKernelGGL(k_rank_rows, dim3(Mt), dim3(256), 0, s, (const float*)m->p_scores, (long long)m->p_nsel, (long long)m->p_ldo,
-                               (const int*)e_iota, (long long)Mt, (int)mode, m->p_ranks);
+            cand = e_cand;
+            n_sel = Mt + n_items_sel;
+        }
+        if (streaming) {
+            // element-wise final activation: candidate tiles are ranked against the target score as they are produced
+            const StreamRank sr = {tgt, items ? (long long)Mt : 0LL, (int)mode};
+            if (predict_forward(m, e_in + t * B, Mt, cand, n_sel, &sr)) { cleanup(); return -1; }
         } else {
-            if (predict_forward(m, e_in + t * B, Mt, nullptr, d.n_items)) { cleanup(); return -1; }
+            // softmax needs the whole row first (max, sum): scores are materialised, then ranked
+            if (predict_forward(m, e_in + t * B, Mt, cand, n_sel, nullptr)) { cleanup(); return -1; }
             hipLaunchKernelGGL(k_rank_rows, dim3(Mt), dim3(256), 0, s, (const float*)m->p_scores, (long long)m->p_nsel, (long long)m->p_ldo,
-                               tgt, 0LL, (int)mode, m->p_ranks);
+                               items ? (const int*)e_iota : tgt, items ? (long long)Mt : 0LL, (int)mode, m->p_ranks);
         }
         hipLaunchKernelGGL(k_eval_accum, dim3(1), dim3(256), 0, s, (const float*)m->p_ranks, Mt, (const int*)e_cut, (int)n_cut, e_acc,
                            e_acc + n_cut, e_n);

@@ -10,9 +10,14 @@
 #define SC_BM 128
 #define SC_KC 128
 
-template <int TN>
+// COUNT = false: out[row, n] = score.  COUNT = true (streaming evaluation, no score matrix): `out` holds the target score of
+// every row (out[row * ldo + row], produced by a COUNT = false launch over the target items, i.e. by the very same
+// k-ordered MFMA chain, so equal scores compare equal); the tile's scores are compared with it and the number of
+// candidates in columns >= col_begin that are greater / equal is added to cnt[2 * row], cnt[2 * row + 1] (integer atomics).
+template <int TN, bool COUNT = false>
 __global__ __launch_bounds__(256) void k_score_all(const DevModel* __restrict__ mp, const float* h, int mrows, const int* item_idx,
-                                                   long long n_sel, float* out, long long ldo, int apply_act) {
+                                                   long long n_sel, float* out, long long ldo, int apply_act,
+                                                   int* cnt = nullptr, long long col_begin = 0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lg = lane >> 4;
@@ -67,23 +72,66 @@ __global__ __launch_bounds__(256) void k_score_all(const DevModel* __restrict__ 
         }
         __syncthreads();
     }
+    if constexpr (!COUNT) {
 #pragma unroll
-    for (int cj = 0; cj < CT; ++cj) {
-        const long long n = n0 + 16 * cj + li;
-        const int item = sItem[16 * cj + li];
-        const float add = item >= 0 ? m.By[item] : 0.f;
+        for (int cj = 0; cj < CT; ++cj) {
+            const long long n = n0 + 16 * cj + li;
+            const int item = sItem[16 * cj + li];
+            const float add = item >= 0 ? m.By[item] : 0.f;
+#pragma unroll
+            for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int row = rbase + 32 * wid + 16 * ri + 4 * lg + rg;
+                    if (row < mrows && n < n_sel) {
+                        float v = acc[ri][cj][rg] + add;
+                        if (apply_act) v = act_fwd(m.final_act, m.fa_p0, m.fa_p1, v);
+                        out[(size_t)row * ldo + n] = v;
+                    }
+                }
+        }
+    } else {
+        float add[CT];
+#pragma unroll
+        for (int cj = 0; cj < CT; ++cj) { const int item = sItem[16 * cj + li]; add[cj] = item >= 0 ? m.By[item] : 0.f; }
 #pragma unroll
         for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int row = rbase + 32 * wid + 16 * ri + 4 * lg + rg;
-                if (row < mrows && n < n_sel) {
-                    float v = acc[ri][cj][rg] + add;
+                const float t = out[(size_t)min(row, mrows - 1) * ldo + min(row, mrows - 1)];
+                float gt = 0.f, eq = 0.f;
+#pragma unroll
+                for (int cj = 0; cj < CT; ++cj) {
+                    const long long n = n0 + 16 * cj + li;
+                    float v = acc[ri][cj][rg] + add[cj];
                     if (apply_act) v = act_fwd(m.final_act, m.fa_p0, m.fa_p1, v);
-                    out[(size_t)row * ldo + n] = v;
+                    const bool in = n < n_sel && n >= col_begin;
+                    gt += (in && v > t) ? 1.f : 0.f;
+                    eq += (in && v == t) ? 1.f : 0.f;
+                }
+                // the 16 lanes that share this row (same lg): quad swaps, mirrored half row, mirrored row
+                gt += dpp_mov<0xB1>(gt); gt += dpp_mov<0x4E>(gt); gt += dpp_mov<0x141>(gt); gt += dpp_mov<0x140>(gt);
+                eq += dpp_mov<0xB1>(eq); eq += dpp_mov<0x4E>(eq); eq += dpp_mov<0x141>(eq); eq += dpp_mov<0x140>(eq);
+                if (li == 0 && row < mrows) {
+                    if (gt != 0.f) atomicAdd(cnt + 2 * row, (int)gt);
+                    if (eq != 0.f) atomicAdd(cnt + 2 * row + 1, (int)eq);
                 }
             }
     }
+}
+
+// ranks from the streamed counts (evaluation.py:62-65); clears the counters for the next step
+__global__ __launch_bounds__(256) void k_rank_counts(int* cnt, int mrows, int mode, float* ranks) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= mrows) return;
+    const float gt = (float)cnt[2 * i], eq = (float)cnt[2 * i + 1];
+    cnt[2 * i] = 0; cnt[2 * i + 1] = 0;
+    float r;
+    if (mode == G4R_RANK_CONSERVATIVE) r = gt + eq;
+    else if (mode == G4R_RANK_MEDIAN) r = gt + 0.5f * (eq - 1.f) + 1.f;
+    else r = gt + 1.f;
+    ranks[i] = r;
 }
 
 // in-place softmax over n_sel columns of each row (one 256-thread workgroup per row)
@@ -181,4 +229,5 @@ template __global__ void k_sparse_update<1>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update<2>(const DevModel*, StepState*, int);
 template __global__ void k_update<1>(const DevModel*, StepState*, const DenseTile*, int, int);
 template __global__ void k_update<2>(const DevModel*, StepState*, const DenseTile*, int, int);
-template __global__ void k_score_all<32>(const DevModel*, const float*, int, const int*, long long, float*, long long, int);
+template __global__ void k_score_all<32, false>(const DevModel*, const float*, int, const int*, long long, float*, long long, int, int*, long long);
+template __global__ void k_score_all<32, true>(const DevModel*, const float*, int, const int*, long long, float*, long long, int, int*, long long);

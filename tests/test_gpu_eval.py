@@ -19,6 +19,32 @@ def trained():
     return gru, test
 
 
+@pytest.fixture(scope='module', params=['elu-0.5', 'relu'])
+def trained_elementwise(request):
+    """Element-wise final activations take the streaming path (no score matrix); relu produces many exact ties."""
+    data = synth.make_sessions(9000, n_items=400, seed=11)
+    train, test = synth.train_test_split(data)
+    gru = GRU4Rec(loss='bpr-max', final_act=request.param, layers=[36], batch_size=32, n_sample=64, constrained_embedding=True,
+                  n_epochs=2, learning_rate=0.1)
+    gru.fit(train, sample_store=64 * 50)
+    return gru, test
+
+
+@pytest.mark.parametrize('mode', ['standard', 'conservative', 'median'])
+@pytest.mark.parametrize('batch', [5, 130])
+def test_streaming_ranks_equal_materialised_ranks(trained_elementwise, mode, batch):
+    gru, test = trained_elementwise
+    a = evaluation.evaluate_gpu(gru, test.copy(), cut_off=[1, 5, 20], batch_size=batch, mode=mode)
+    b = evaluation.evaluate_gpu_stepwise(gru, test.copy(), cut_off=[1, 5, 20], batch_size=batch, mode=mode)
+    np.testing.assert_allclose(a[0], b[0], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-6, atol=1e-9)
+    items = np.array(list(gru.itemidmap.index))[1::4]
+    a = evaluation.evaluate_gpu(gru, test.copy(), items=items, cut_off=[2, 10], batch_size=batch, mode=mode)
+    b = evaluation.evaluate_gpu_stepwise(gru, test.copy(), items=items, cut_off=[2, 10], batch_size=batch, mode=mode)
+    np.testing.assert_allclose(a[0], b[0], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-6, atol=1e-9)
+
+
 @pytest.mark.parametrize('mode', ['standard', 'conservative', 'median'])
 @pytest.mark.parametrize('batch', [7, 50])
 def test_one_call_equals_stepwise_all_items(trained, mode, batch):
