@@ -48,6 +48,22 @@ SCENARIOS = {
     'onehot_default': dict(loss='bpr-max', final_act='elu-0.5', hidden_act='tanh', layers=[12], n_epochs=2, batch_size=8,
                            dropout_p_embed=0.0, dropout_p_hidden=0.2, learning_rate=0.1, momentum=0.1, n_sample=16,
                            sample_alpha=0.75, bpreg=1.0, constrained_embedding=False, embedding=0),
+    'rmsprop_mom': dict(loss='bpr-max', final_act='elu-0.5', hidden_act='tanh', layers=[12], n_epochs=2, batch_size=8,
+                        dropout_p_embed=0.0, dropout_p_hidden=0.0, learning_rate=0.01, momentum=0.2, n_sample=16,
+                        sample_alpha=0.5, bpreg=1.0, constrained_embedding=True, adapt='rmsprop', adapt_params=[0.9]),
+    'adadelta_xe': dict(loss='cross-entropy', final_act='softmax', hidden_act='tanh', layers=[12], n_epochs=2, batch_size=8,
+                        dropout_p_embed=0.0, dropout_p_hidden=0.0, learning_rate=1.0, momentum=0.0, n_sample=16,
+                        sample_alpha=0.5, constrained_embedding=True, adapt='adadelta', adapt_params=[0.95]),
+    'adam_sep_embed': dict(loss='bpr-max', final_act='elu-0.5', hidden_act='tanh', layers=[12], n_epochs=2, batch_size=8,
+                           dropout_p_embed=0.0, dropout_p_hidden=0.0, learning_rate=0.01, momentum=0.0, n_sample=16,
+                           sample_alpha=0.5, bpreg=1.0, constrained_embedding=False, embedding=8, adapt='adam',
+                           adapt_params=[0.9, 0.999]),
+    'sgd_gradcap': dict(loss='top1-max', final_act='tanh', hidden_act='tanh', layers=[12], n_epochs=2, batch_size=8,
+                        dropout_p_embed=0.0, dropout_p_hidden=0.0, learning_rate=0.05, momentum=0.1, n_sample=16,
+                        sample_alpha=0.5, constrained_embedding=True, adapt=None, grad_cap=0.05),
+    'adagrad_gradcap_lmbd': dict(loss='bpr-max', final_act='elu-0.5', hidden_act='tanh', layers=[12], n_epochs=2, batch_size=8,
+                                 dropout_p_embed=0.0, dropout_p_hidden=0.0, learning_rate=0.1, momentum=0.0, n_sample=16,
+                                 sample_alpha=0.5, bpreg=1.0, constrained_embedding=True, grad_cap=0.02, lmbd=0.01),
     'bpr_linear': dict(loss='bpr', final_act='linear', hidden_act='tanh', layers=[12], n_epochs=2, batch_size=8,
                        dropout_p_embed=0.0, dropout_p_hidden=0.0, learning_rate=0.1, momentum=0.0, n_sample=16,
                        sample_alpha=0.5, constrained_embedding=True),

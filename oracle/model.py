@@ -192,7 +192,7 @@ class OracleGRU4Rec:
                  hidden_act='tanh', n_sample=2048, sample_alpha=0.75, learning_rate=0.1, momentum=0.0,
                  lmbd=0.0, bpreg=1.0, logq=0.0, dropout_p_hidden=0.0, dropout_p_embed=0.0,
                  constrained_embedding=False, embedding=0, sigma=0.0, init_as_normal=False,
-                 dtype=np.float32, seed=12345, smoothing=0.0):
+                 dtype=np.float32, seed=12345, smoothing=0.0, adapt='adagrad', adapt_params=(), grad_cap=0.0):
         self.n_items = n_items
         self.layers = list(layers)
         self.batch_size = batch_size
@@ -206,6 +206,11 @@ class OracleGRU4Rec:
         self.lmbd = lmbd
         self.bpreg = bpreg
         self.smoothing = smoothing
+        self.adapt = adapt                    # None | 'adagrad' | 'rmsprop' | 'adadelta' | 'adam' (gru4rec.py:392-399)
+        self.adapt_params = list(adapt_params)
+        self.grad_cap = grad_cap
+        if adapt == 'adadelta':
+            self.learning_rate = learning_rate = 1.0      # gru4rec.py:362-364
         self.logq = logq
         self.dropout_p_hidden = dropout_p_hidden
         self.dropout_p_embed = dropout_p_embed
@@ -272,6 +277,9 @@ class OracleGRU4Rec:
         for n in ('Wx', 'Wh', 'Wrz', 'Bh'):
             self.acc[n] = [z(a) for a in getattr(self, n)]
             self.vel[n] = [z(a) for a in getattr(self, n)]
+        # second statistic (adadelta: upd, adam: meang) and adam's step counter, same shapes
+        self.acc2 = {k: ([z(a) for a in v] if isinstance(v, list) else z(v)) for k, v in self.acc.items()}
+        self.cnt = {k: ([z(a) for a in v] if isinstance(v, list) else z(v)) for k, v in self.acc.items()}
 
     # -- gru4rec.py:539-545 ; P is float32 on the device (:556)
     def set_popularity(self, support):
@@ -428,6 +436,20 @@ class OracleGRU4Rec:
         # data-parallel hook (not in the reference): all-reduce of the dense GRU gradients across ranks
         if getattr(self, 'dense_grad_hook', None) is not None:
             dense_grads = self.dense_grad_hook(dense_grads)
+        # ---- global gradient-norm clipping over the dense gradients and the per-occurrence sparse gradients (gru4rec.py:386-389)
+        if self.grad_cap > 0:
+            sq = dt(0)
+            for (i, dWx, dWh, dWrz, dBh) in dense_grads:
+                for g in (dWx, dWh, dWrz, dBh):
+                    if g is not None:
+                        sq = sq + (g.astype(self.dtype) ** 2).sum(dtype=self.dtype)
+            for g in (dSx, dSy, dSBy):
+                sq = sq + (g.astype(self.dtype) ** 2).sum(dtype=self.dtype)
+            norm = np.sqrt(sq)
+            if norm >= self.grad_cap:
+                c = dt(self.grad_cap) / norm
+                dense_grads = [(i,) + tuple(None if g is None else (g * c).astype(self.dtype) for g in gs) for (i, *gs) in dense_grads]
+                dSx, dSy, dSBy = (dSx * c).astype(self.dtype), (dSy * c).astype(self.dtype), (dSBy * c).astype(self.dtype)
         # ---- updates: everything reads pre-step values (Theano updates are simultaneous)
         newH = []
         for i in range(len(L)):
@@ -453,14 +475,41 @@ class OracleGRU4Rec:
             return cost, dbg
         return cost
 
-    # -- gru4rec.py:390-406 with adagrad :330-334
+    # -- learning-rate adaptation of a dense gradient: adagrad :330-334, rmsprop :366-381, adadelta :341-365, adam :300-329
+    def _adapt_dense(self, g, acc, acc2, cnt):
+        """Returns (scaled gradient, new acc, new acc2, new cnt)."""
+        dt = self.dtype.type
+        eps = dt(EPS_ADAGRAD)
+        if self.adapt == 'adagrad':
+            an = acc + g * g
+            return g / np.sqrt(an + eps), an, acc2, cnt
+        if self.adapt == 'rmsprop':
+            v1 = dt(self.adapt_params[0])
+            an = v1 * acc + (dt(1) - v1) * g * g
+            return g / np.sqrt(an + eps), an, acc2, cnt
+        if self.adapt == 'adadelta':
+            v1 = dt(self.adapt_params[0])
+            an = v1 * acc + (dt(1) - v1) * g * g
+            gs = (acc2 + eps) / (an + eps)
+            un = v1 * acc2 + (dt(1) - v1) * gs * g * g
+            return g * np.sqrt(gs), an, un, cnt
+        if self.adapt == 'adam':
+            v1, v3 = dt(self.adapt_params[0]), dt(self.adapt_params[1])
+            an = v3 * acc + (dt(1) - v3) * g * g
+            mn = v1 * acc2 + (dt(1) - v1) * g
+            cn = cnt + dt(1)
+            corr = dt(1) - v1 ** cn                       # both moments are corrected with v1 (:329)
+            return (mn / corr) / (np.sqrt(an / corr) + eps), an, mn, cn
+        return g, acc, acc2, cnt                        # adapt=None: plain SGD
+
+    # -- gru4rec.py:390-406
     def _dense_update(self, name, i, g):
         dt = self.dtype.type
         p = getattr(self, name)[i]
-        acc = self.acc[name][i]
-        acc_new = acc + g * g
-        gs = g / np.sqrt(acc_new + dt(EPS_ADAGRAD))
-        self.acc[name][i] = acc_new.astype(self.dtype)
+        gs, an, a2, cn = self._adapt_dense(g, self.acc[name][i], self.acc2[name][i], self.cnt[name][i])
+        self.acc[name][i] = an.astype(self.dtype)
+        self.acc2[name][i] = a2.astype(self.dtype)
+        self.cnt[name][i] = cn.astype(self.dtype)
         lr = dt(self.learning_rate)
         if self.momentum > 0:
             v = self.vel[name][i]
@@ -480,15 +529,49 @@ class OracleGRU4Rec:
             P, acc, vel = self.Wx[0], self.acc['Wx'][0], self.vel['Wx'][0]
         else:
             P, acc, vel = getattr(self, name), self.acc[name], self.vel[name]
-        acc_s = acc[idx]
-        acc_new = acc_s + g * g
-        gs = g / np.sqrt(acc_new + dt(EPS_ADAGRAD))
+        if name == 'Wx0':
+            acc2, cnt = self.acc2['Wx'][0], self.cnt['Wx'][0]
+        else:
+            acc2, cnt = self.acc2[name], self.cnt[name]
+        eps = dt(EPS_ADAGRAD)
+        if self.adapt == 'adagrad':
+            acc_new = acc[idx] + g * g
+            gs = g / np.sqrt(acc_new + eps)
+            acc[idx] = acc_new                                  # set_subtensor: last write wins (:336-338)
+        elif self.adapt in ('rmsprop', 'adadelta', 'adam'):
+            # the "accurate" duplicate handling of the reference (:321-326,349-358,373-378): the statistic of an index is
+            # decayed once and receives the contribution of every occurrence; all occurrences see the final value
+            v1 = dt(self.adapt_params[0])
+            va = dt(self.adapt_params[1]) if self.adapt == 'adam' else v1
+            uniq = np.unique(idx)
+            acc_pre2 = acc2[idx].copy()
+            acc[uniq] = acc[uniq] * va
+            np.add.at(acc, idx, ((dt(1) - va) * g * g).astype(self.dtype))
+            acc_new = acc[idx]
+            if self.adapt == 'rmsprop':
+                gs = g / np.sqrt(acc_new + eps)
+            elif self.adapt == 'adadelta':
+                sc = (acc_pre2 + eps) / (acc_new + eps)
+                acc2[uniq] = acc2[uniq] * v1
+                np.add.at(acc2, idx, ((dt(1) - v1) * sc * g * g).astype(self.dtype))
+                gs = g * np.sqrt(sc)
+            else:
+                # adam, sparse branch as written: the mean accumulator also receives grad**2 (:325) and both moments are
+                # bias-corrected with v1 (:329); the result does not depend on the occurrence's own gradient
+                acc2[uniq] = acc2[uniq] * v1
+                np.add.at(acc2, idx, ((dt(1) - v1) * g * g).astype(self.dtype))
+                cn = cnt[idx] + dt(1)
+                cnt[idx] = cn
+                corr = dt(1) - v1 ** cn
+                gs = (acc2[idx] / corr) / (np.sqrt(acc_new / corr) + eps)
+        else:
+            gs = g
+        gs = gs.astype(self.dtype)
         lr = dt(self.learning_rate)
         if self.lmbd > 0:
             delta = lr * (gs + dt(self.lmbd) * P[idx])
         else:
             delta = lr * gs
-        acc[idx] = acc_new                                  # last write wins
         if self.momentum > 0:
             v2 = dt(self.momentum) * vel[idx] - delta
             vel[idx] = v2                                   # last write wins

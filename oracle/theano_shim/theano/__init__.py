@@ -78,6 +78,7 @@ class Var:
     def __rtruediv__(self, o): return self._bin(o, 'div', True)
     def __floordiv__(self, o): return self._bin(o, 'floordiv')
     def __pow__(self, o): return self._bin(o, 'pow')
+    def __rpow__(self, o): return self._bin(o, 'pow', True)
     def __neg__(self): return Var('elem1', [self], fn='neg', ndim=self.ndim)
     def __gt__(self, o): return self._bin(o, 'gt')
     def __ge__(self, o): return self._bin(o, 'ge')

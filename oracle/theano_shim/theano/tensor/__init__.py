@@ -58,6 +58,13 @@ def concatenate(parts, axis=0):
 
 
 def sum(x, axis=None, keepdims=False):  # noqa: A001
+    if isinstance(x, (list, tuple)) and any(isinstance(e, Var) for e in x):
+        # T.sum of a Python list of scalars (gru4rec.py:387): the list is first stacked by as_tensor_variable
+        total = None
+        for e in x:
+            e = _as_var(e)
+            total = e if total is None else total + e
+        return total
     return _as_var(x).sum(axis=axis, keepdims=keepdims)
 
 

@@ -59,7 +59,7 @@ def test_oracle_reproduces_reference_run(path):
     for mode in ('standard', 'conservative', 'median'):
         rec, mrr = oracle_evaluate(m, run.itemidmap, test, cut_off=[1, 5, 20], batch_size=5, mode=mode)
         np.testing.assert_allclose(rec, g['recall_' + mode], atol=1e-9)
-        np.testing.assert_allclose(mrr, g['mrr_' + mode], atol=1e-9)
+        np.testing.assert_allclose(mrr, g['mrr_' + mode], atol=2e-7)      # the reference sums float32 reciprocal ranks
 
 
 def test_goldens_exist():
