@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get('G4R_LIB') or os.path.join(_HERE, 'libgru4rec_hip.so')
 G4R_MAX_LAYERS = 8
 LOSS_IDS = {'cross-entropy': 0, 'bpr-max': 1, 'top1-max': 2, 'bpr': 3, 'top1': 4, 'xe_logit': 5}
 ACT_IDS = {'linear': 0, 'relu': 1, 'tanh': 2, 'leaky': 3, 'elu': 4, 'selu': 5, 'softmax': 6, 'softmax_logit': 7}
+ADAPT_IDS = {'adagrad': 0, 'rmsprop': 1, 'adadelta': 2, 'adam': 3, None: 4}
 RANK_MODES = {'standard': 0, 'conservative': 1, 'median': 2}
 EMBED_CONSTRAINED, EMBED_SEPARATE, EMBED_ONEHOT = 0, 1, 2
 
@@ -30,7 +31,8 @@ class G4RConfig(C.Structure):
         ('dropout_p_hidden', C.c_float), ('dropout_p_embed', C.c_float),
         ('sample_store', C.c_int64), ('seed', C.c_uint64),
         ('device', C.c_int32), ('rank', C.c_int32), ('nranks', C.c_int32), ('use_graph', C.c_int32),
-        ('smoothing', C.c_float), ('reserved', C.c_int32 * 6),
+        ('smoothing', C.c_float), ('adapt', C.c_int32), ('adapt_p0', C.c_float), ('adapt_p1', C.c_float),
+        ('grad_cap', C.c_float), ('reserved', C.c_int32 * 2),
     ]
 
 

@@ -153,6 +153,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     if (cfg->loss < 0 || cfg->loss > G4R_LOSS_XE_LOGIT) return fail("unsupported loss");
     if (cfg->smoothing != 0.f && cfg->loss != G4R_LOSS_XE && cfg->loss != G4R_LOSS_XE_LOGIT) return fail("smoothing needs a cross-entropy loss");
     if (cfg->hidden_act == G4R_ACT_SOFTMAX_LOGIT) return fail("softmax_logit is not a hidden activation");
+    if (cfg->adapt < 0 || cfg->adapt > G4R_ADAPT_NONE) return fail("unknown adapt");
+    if (cfg->grad_cap < 0.f) return fail("grad_cap must be >= 0");
     if (cfg->hidden_act == G4R_ACT_SOFTMAX) return fail("softmax is not a hidden activation");
     int ndev = g4r_device_count();
     if (ndev <= 0) return fail("no HIP device visible: the gfx950 path has no CPU fallback");
@@ -180,6 +182,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     d.lr = cfg->learning_rate; d.mom = cfg->momentum; d.lmbd = cfg->lmbd; d.bpreg = cfg->bpreg; d.logq = cfg->logq;
     d.inv_B = 1.0f / (float)B;
     d.smoothing = cfg->smoothing;
+    d.adapt = cfg->adapt; d.ap0 = cfg->adapt_p0; d.ap1 = cfg->adapt_p1; d.grad_cap = cfg->grad_cap;
+    d.generic = (cfg->adapt != G4R_ADAPT_ADAGRAD || cfg->grad_cap > 0.f) ? 1 : 0;
     d.drop_h = cfg->dropout_p_hidden; d.drop_e = cfg->dropout_p_embed;
     d.seed = cfg->seed;
     d.Dtop = cfg->layers[L - 1];
@@ -196,7 +200,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     }
     d.dense_count = off;
     // G4R_FORCE_STAGED=1: exercise the multi-rank data path (gradient staging -> RCCL -> k_dense_apply) on one GPU
-    d.apply_dense_inplace = (cfg->nranks <= 1 && !getenv("G4R_FORCE_STAGED")) ? 1 : 0;
+    d.apply_dense_inplace = (cfg->nranks <= 1 && !getenv("G4R_FORCE_STAGED") && !d.generic) ? 1 : 0;
     d.grad_scale = 1.0f / (float)std::max(cfg->nranks, 1);
     const size_t I = cfg->n_items;
 #define DA(p, n) if (dalloc(m, &(p), (n))) { g4r_destroy(m); return -1; }
@@ -206,6 +210,16 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     if (cfg->embed_mode != G4R_EMBED_CONSTRAINED) {     // E table, or Wx[0] as a row table (one-hot input)
         DA(d.E, I * d.Ein); DA(d.accE, I * d.Ein);
         if (cfg->momentum > 0.f) DA(d.velE, I * d.Ein);
+    }
+    if (d.generic) {
+        const bool two = (cfg->adapt == G4R_ADAPT_ADADELTA || cfg->adapt == G4R_ADAPT_ADAM), cnt = (cfg->adapt == G4R_ADAPT_ADAM);
+        if (two) { DA(d.acc2Wy, I * d.Dtop); DA(d.acc2By, I); DA(d.dense_acc2, off); if (d.E) DA(d.acc2E, I * d.Ein); }
+        if (cnt) { DA(d.cntWy, I * d.Dtop); DA(d.cntBy, I); DA(d.dense_cnt, off); if (d.E) DA(d.cntE, I * d.Ein); }
+        DA(d.gsq_part, G4R_NORM_BLOCKS); DA(d.gclip, 1);
+        const float one = 1.f;
+        if (hipMemcpyAsync(d.gclip, &one, sizeof(float), hipMemcpyHostToDevice, m->stream) != hipSuccess || hipStreamSynchronize(m->stream) != hipSuccess) {
+            g4r_destroy(m); return fail("gclip init");
+        }
     }
     int maxD = 0;
     for (int l = 0; l < L; ++l) {
@@ -281,6 +295,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_dense_grad, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update_generic<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update_generic<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_store, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -315,21 +331,25 @@ static int locate(g4r_model* m, const char* name, int layer, float** p, int64_t*
     DevModel& d = m->dm;
     std::string s(name);
     float *base_p = d.dense_p;
-    bool want_acc = false, want_vel = false;
-    if (s.rfind("acc_", 0) == 0) { want_acc = true; s = s.substr(4); }
+    bool want_acc = false, want_vel = false, want_acc2 = false, want_cnt = false;
+    if (s.rfind("acc2_", 0) == 0) { want_acc2 = true; s = s.substr(5); }
+    else if (s.rfind("cnt_", 0) == 0) { want_cnt = true; s = s.substr(4); }
+    else if (s.rfind("acc_", 0) == 0) { want_acc = true; s = s.substr(4); }
     else if (s.rfind("vel_", 0) == 0) { want_vel = true; s = s.substr(4); }
     if (want_vel && m->cfg.momentum <= 0.f && (s == "Wy" || s == "By" || s == "E" || (d.embed_mode == G4R_EMBED_ONEHOT && s == "Wx" && layer == 0)))
         return fail("no velocity state without momentum");
     const int64_t I = d.n_items;
-    if (s == "Wy") { *p = want_acc ? d.accWy : (want_vel ? d.velWy : d.Wy); *n = I * d.Dtop; return 0; }
-    if (s == "By") { *p = want_acc ? d.accBy : (want_vel ? d.velBy : d.By); *n = I; return 0; }
+    if ((want_acc2 && !d.dense_acc2) || (want_cnt && !d.dense_cnt)) return fail("this optimizer keeps no such statistic");
+    if (s == "Wy") { *p = want_acc2 ? d.acc2Wy : want_cnt ? d.cntWy : want_acc ? d.accWy : (want_vel ? d.velWy : d.Wy); *n = I * d.Dtop; return 0; }
+    if (s == "By") { *p = want_acc2 ? d.acc2By : want_cnt ? d.cntBy : want_acc ? d.accBy : (want_vel ? d.velBy : d.By); *n = I; return 0; }
     if (d.embed_mode == G4R_EMBED_ONEHOT && s == "Wx" && layer == 0) s = "E";    // Wx[0] is the (I, 3D) row table
     if (s == "E") {
         if (!d.E) return fail("model has no separate embedding");
-        *p = want_acc ? d.accE : (want_vel ? d.velE : d.E); *n = I * d.Ein; return 0;
+        *p = want_acc2 ? d.acc2E : want_cnt ? d.cntE : want_acc ? d.accE : (want_vel ? d.velE : d.E); *n = I * d.Ein; return 0;
     }
     if (layer < 0 || layer >= d.n_layers) return fail("layer out of range");
     if (want_acc) base_p = d.dense_acc; else if (want_vel) base_p = d.dense_vel;
+    else if (want_acc2) base_p = d.dense_acc2; else if (want_cnt) base_p = d.dense_cnt;
     const int D = d.D[layer], IN = d.IN[layer];
     if (s == "Wx") { *p = base_p + d.offWx[layer]; *n = (int64_t)IN * 3 * D; return 0; }
     if (s == "Wh") { *p = base_p + d.offWh[layer]; *n = (int64_t)D * D; return 0; }
@@ -597,17 +617,36 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     // (measured on one MI355X with a one-rank communicator: the two cross-stream event dependencies cost ~20 us per
     // step, more than the ~11 us of sparse update they can hide, so the overlap is opt-in: G4R_OVERLAP=1)
     static const bool want_overlap = getenv("G4R_OVERLAP") != nullptr;
-    const bool overlap = !d.apply_dense_inplace && !recs && !trace && want_overlap;
+    const bool overlap = !d.apply_dense_inplace && !recs && !trace && want_overlap && !d.generic && (m->cfg.nranks > 1 || m->comm_ready);
     if (!d.apply_dense_inplace) {
-        if (!m->comm_ready) return fail("nranks > 1 but g4r_comm_init was not called");
+        // staged dense path: (RCCL all-reduce when there are ranks) -> (global gradient norm -> clip factor, generic path with
+        // grad_cap) -> dense rule on the flat gradient buffer
+        const bool dist = m->cfg.nranks > 1 || m->comm_ready;
+        if (m->cfg.nranks > 1 && !m->comm_ready) return fail("nranks > 1 but g4r_comm_init was not called");
         hipStream_t cs = overlap ? m->comm_stream : s;
-        if (overlap) { HIPCHK(hipEventRecord(m->ev_fork, s)); HIPCHK(hipStreamWaitEvent(cs, m->ev_fork, 0)); }
-        if (!overlap) { begin(KN_ALLREDUCE); if (recs) (void)hipEventRecord(cur_a, cs); }
-        NCCLCHK(ncclAllReduce(d.dense_g, d.dense_g, d.dense_count, ncclFloat, ncclSum, m->comm, cs));
-        if (!overlap) { if (recs) (void)hipEventRecord(cur_b, cs); end(); begin(KN_DENSE_APPLY); }
+        if (dist) {
+            if (overlap) { HIPCHK(hipEventRecord(m->ev_fork, s)); HIPCHK(hipStreamWaitEvent(cs, m->ev_fork, 0)); }
+            if (!overlap) { begin(KN_ALLREDUCE); if (recs) (void)hipEventRecord(cur_a, cs); }
+            NCCLCHK(ncclAllReduce(d.dense_g, d.dense_g, d.dense_count, ncclFloat, ncclSum, m->comm, cs));
+            if (!overlap) { if (recs) (void)hipEventRecord(cur_b, cs); end(); }
+        }
+        if (d.generic && d.grad_cap > 0.f) {
+            hipLaunchKernelGGL(k_grad_sqsum, dim3(G4R_NORM_BLOCKS), dim3(256), 0, cs, dmp, stp);
+            hipLaunchKernelGGL(k_grad_clip, dim3(1), dim3(64), 0, cs, dmp);
+        }
+        if (!overlap) begin(KN_DENSE_APPLY);
         LK(k_dense_apply, dim3(cdiv(d.dense_count, 256)), dim3(256), 0, cs, (const DevModel*)m->d_dm);
         if (!overlap) end();
-        if (overlap) HIPCHK(hipEventRecord(m->ev_join, cs));
+        if (dist && overlap) HIPCHK(hipEventRecord(m->ev_join, cs));
+    }
+    if (d.generic) {
+        // generic optimizer path: the sparse rule on raw per-occurrence gradients
+        begin(KN_SPARSE);
+        if (std::max(d.Dtop, d.Ein) <= 256) LK(k_sparse_update_generic<1>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
+        else LK(k_sparse_update_generic<2>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
+        end();
+        HIPCHK(hipGetLastError());
+        return 0;
     }
     begin(KN_SPARSE);
     if (std::max(d.Dtop, d.Ein) <= 256) LK(k_sparse_update<1>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);

@@ -53,6 +53,8 @@ __device__ __forceinline__ float ldf_if(const GAS float* base, size_t off, bool 
 // step kernels is step-agnostic: the first kernel of a step reads *_a and republishes it as *_b,
 // the middle kernels read *_b, the last kernel writes *_a = *_b + 1.  No kernel both reads and
 // writes the same word, so stream order alone makes it race-free.
+#define G4R_NORM_BLOCKS 256
+
 struct StepState {
     long long t_a, t_b;   // plan step within the epoch
     long long g_a, g_b;   // global step (drives sample-store row, dropout counters, H ping-pong parity)
@@ -68,6 +70,14 @@ struct DevModel {
     int loss, final_act, hidden_act, embed_mode;
     float fa_p0, fa_p1, ha_p0, ha_p1;
     float lr, mom, lmbd, bpreg, logq, inv_B, smoothing, pad_f;
+    // generic optimizer path (adapt != adagrad, or grad_cap > 0): gradient producers leave RAW gradients in dS* / dense_g,
+    // the update kernels apply the rule (gru4rec.py:300-381) and the global-norm clip (:386-389)
+    int generic, adapt;
+    float ap0, ap1, grad_cap, pad_g;
+    GP(float) acc2Wy; GP(float) acc2By; GP(float) acc2E; GP(float) cntWy; GP(float) cntBy; GP(float) cntE;
+    GP(float) dense_acc2; GP(float) dense_cnt;
+    GP(float) gsq_part;      // [G4R_NORM_BLOCKS] partial sums of squares
+    GP(float) gclip;         // [1] clip factor of this step (1 when the norm is below grad_cap)
     float drop_h, drop_e;
     unsigned long long seed;
     int D[G4R_MAX_LAYERS], IN[G4R_MAX_LAYERS];

@@ -227,6 +227,8 @@ __global__ void k_scale(float* p, long long n, float s) {
 // explicit instantiations: the launching host code is not visible to the device pass
 template __global__ void k_sparse_update<1>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update<2>(const DevModel*, StepState*, int);
+template __global__ void k_sparse_update_generic<1>(const DevModel*, StepState*, int);
+template __global__ void k_sparse_update_generic<2>(const DevModel*, StepState*, int);
 template __global__ void k_update<1>(const DevModel*, StepState*, const DenseTile*, int, int);
 template __global__ void k_update<2>(const DevModel*, StepState*, const DenseTile*, int, int);
 template __global__ void k_score_all<32, false>(const DevModel*, const float*, int, const int*, long long, float*, long long, int, int*, long long);

@@ -545,6 +545,7 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
         const GAS float *accWy = m.accWy, *accBy = m.accBy;
         GAS float *dSy = m.dSy, *dAy = m.dAy, *dSBy = m.dSBy, *dABy = m.dABy;
         const float lr = m.lr;
+        const bool generic = m.generic != 0;
         auto pre = [&](int n, int d) -> float4 {
             const int item = (n - n0 < GT_BM) ? sIt[n - n0] : -1;
             const bool ok = item >= 0 && d <= D;
@@ -554,7 +555,8 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
         auto epi = [&](int n, int d, float g, float4 p) {
             if (n >= N || d > D) return;
             const float an = p.x + g * g;
-            const float step = (p.y != 0.f) ? lr * g * frsq(an + G4R_EPS_ADAGRAD) : 0.f;
+            float step = (p.y != 0.f) ? lr * g * frsq(an + G4R_EPS_ADAGRAD) : 0.f;
+            if (generic) step = (p.y != 0.f) ? g : 0.f;      // raw per-occurrence gradient: the update kernel applies the rule
             if (d < D) { dSy[(size_t)n * D + d] = step; dAy[(size_t)n * D + d] = an; }
             else { dSBy[n] = step; dABy[n] = an; }
         };
@@ -674,6 +676,7 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_bwd_b(const DevModel* __rest
     };
     const GAS float* accT = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.accWy : m.accE;
     const float lr = m.lr, drop_e = m.drop_e;
+    const bool generic = m.generic != 0;
     const unsigned long long seed = m.seed;
     GAS float *dSx = m.dSx, *dAx = m.dAx, *dylo = (l > 0) ? m.dyl[l - 1] : nullptr;
     auto pre = [&](int row, int n) -> float4 {      // pre-step accumulator of the input item's row (layer 0)
@@ -685,7 +688,7 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_bwd_b(const DevModel* __rest
         if (l == 0) {
             if (drop_e > 0.f) v *= drop_mult(seed, (unsigned)c.g, G4R_STREAM_DROP_EMBED, row, n, 1.0f - drop_e);
             const float an = p.x + v * v;
-            dSx[(size_t)row * IN + n] = lr * v * frsq(an + G4R_EPS_ADAGRAD);
+            dSx[(size_t)row * IN + n] = generic ? v : lr * v * frsq(an + G4R_EPS_ADAGRAD);
             dAx[(size_t)row * IN + n] = an;
         } else {
             dylo[(size_t)row * IN + n] = v;
@@ -719,6 +722,7 @@ __global__ __launch_bounds__(256) void k_onehot_step(const DevModel* __restrict_
     const float4 a = ld4(m.accE + (size_t)item * W + 4 * c4);
     const float4 an = make_float4(a.x + g.x * g.x, a.y + g.y * g.y, a.z + g.z * g.z, a.w + g.w * g.w);
     st4(m.dAx + (size_t)row * W + 4 * c4, an);
+    if (m.generic) { st4(m.dSx + (size_t)row * W + 4 * c4, g); return; }
     st4(m.dSx + (size_t)row * W + 4 * c4, make_float4(lr * g.x * frsq(an.x + G4R_EPS_ADAGRAD), lr * g.y * frsq(an.y + G4R_EPS_ADAGRAD),
                                                          lr * g.z * frsq(an.z + G4R_EPS_ADAGRAD), lr * g.w * frsq(an.w + G4R_EPS_ADAGRAD)));
 }
@@ -797,11 +801,88 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_dense_grad(const DevModel* __res
     dense_grad_tile(*mp, st, tiles_, blockIdx.x, smem);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Generic optimizer path (adapt != adagrad or grad_cap > 0; gru4rec.py:300-381,386-432).  For one parameter element that
+// received n gradients g_1..g_n this step (dense: n = 1): S = sum g_i, Q = sum g_i^2, T1 = sum g_i / sqrt(a0 + g_i^2 + eps)
+// (adagrad only), gk = the last one.  Returns the summed scaled gradient G, the scaled last gradient gl (momentum) and the
+// new statistics.  `dense` selects Adam's proper first moment; its sparse branch feeds grad**2 into the mean (:325), and
+// both bias corrections use beta1 (:329) -- reproduced.
+struct OptOut { float G, gl, A, U, C; };
+__device__ __forceinline__ OptOut opt_rule(int adapt, float v1, float v3, bool dense, float a0, float u0, float c0, float S, float Q,
+                                           float T1, float gk, float fn) {
+    OptOut o;
+    o.U = u0; o.C = c0;
+    const float eps = G4R_EPS_ADAGRAD;
+    if (adapt == G4R_ADAPT_RMSPROP) {
+        const float an = v1 * a0 + (1.f - v1) * Q, sc = 1.f / sqrtf(an + eps);
+        o.G = S * sc; o.gl = gk * sc; o.A = an;
+    } else if (adapt == G4R_ADAPT_ADADELTA) {
+        const float an = v1 * a0 + (1.f - v1) * Q, r = (u0 + eps) / (an + eps), sc = sqrtf(r);
+        o.U = v1 * u0 + (1.f - v1) * r * Q;
+        o.G = S * sc; o.gl = gk * sc; o.A = an;
+    } else if (adapt == G4R_ADAPT_ADAM) {
+        const float an = v3 * a0 + (1.f - v3) * Q, mn = v1 * u0 + (1.f - v1) * (dense ? S : Q), cn = c0 + 1.f;
+        const float corr = 1.f - powf(v1, cn), out = (mn / corr) / (sqrtf(an / corr) + eps);
+        o.G = fn * out; o.gl = out; o.A = an; o.U = mn; o.C = cn;
+    } else if (adapt == G4R_ADAPT_NONE) {
+        o.G = S; o.gl = gk; o.A = a0;
+    } else {
+        o.A = a0 + gk * gk;
+        o.G = T1; o.gl = gk / sqrtf(o.A + eps);
+    }
+    return o;
+}
+
+// sum of squares of every gradient of the step (dense buffer + per-occurrence sparse rows), gru4rec.py:387
+__global__ __launch_bounds__(256) void k_grad_sqsum(const DevModel* __restrict__ mp, StepState* st) {
+    __shared__ float red[8];
+    const DevModel& m = *mp;
+    const StepCtx c = load_ctx(st);
+    const long long nx = (long long)c.M * m.Ein, ny = (long long)m.N * m.Dtop, nb = m.N, nd = m.dense_count;
+    const long long total = nx + ny + nb + nd;
+    float s = 0.f;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)G4R_NORM_BLOCKS * 256) {
+        float g;
+        if (e < nx) g = m.dSx[e];
+        else if (e < nx + ny) g = m.dSy[e - nx];
+        else if (e < nx + ny + nb) g = m.dSBy[e - nx - ny];
+        else g = m.dense_g[e - nx - ny - nb] * m.grad_scale;
+        s += g * g;
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) m.gsq_part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(64) void k_grad_clip(const DevModel* __restrict__ mp) {
+    const DevModel& m = *mp;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < G4R_NORM_BLOCKS; i += 64) s += m.gsq_part[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf(s);
+        m.gclip[0] = (norm >= m.grad_cap) ? m.grad_cap / norm : 1.f;      // T.switch(T.ge(norm, cap), g * cap / norm, g)
+    }
+}
+
 // after the RCCL all-reduce: element-wise dense Adagrad on the averaged gradient
 __global__ __launch_bounds__(256) void k_dense_apply(const DevModel* __restrict__ mp) {
     const DevModel& m = *mp;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < m.dense_count) dense_adagrad(m, (size_t)i, m.dense_g[i] * m.grad_scale);
+    if (i >= m.dense_count) return;
+    if (!m.generic) { dense_adagrad(m, (size_t)i, m.dense_g[i] * m.grad_scale); return; }
+    const float g = m.dense_g[i] * m.grad_scale * m.gclip[0];
+    const float a0 = m.dense_acc[i], u0 = m.dense_acc2 ? m.dense_acc2[i] : 0.f, c0 = m.dense_cnt ? m.dense_cnt[i] : 0.f;
+    const OptOut o = opt_rule(m.adapt, m.ap0, m.ap1, true, a0, u0, c0, g, g * g, g / sqrtf(a0 + g * g + G4R_EPS_ADAGRAD), g, 1.f);
+    m.dense_acc[i] = o.A;
+    if (m.dense_acc2) m.dense_acc2[i] = o.U;
+    if (m.dense_cnt) m.dense_cnt[i] = o.C;
+    const float p = m.dense_p[i];
+    if (m.mom > 0.f) {      // gru4rec.py:400-404
+        const float v = m.mom * m.dense_vel[i] - m.lr * (o.G + m.lmbd * p);
+        m.dense_vel[i] = v;
+        m.dense_p[i] = p + v;
+    } else {
+        m.dense_p[i] = p * (1.0f - m.lr * m.lmbd) - m.lr * o.G;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1105,6 +1186,179 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_update(const DevModel* __r
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if ((int)blockIdx.x < ntiles) dense_grad_tile(*mp, st, tiles_, (int)blockIdx.x, smem);
     else sparse_update_block<MAXCH>(mp, st, nblk_occ, (int)blockIdx.x - ntiles, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sparse update of the generic optimizer path (rmsprop / adadelta / adam / plain SGD, and adagrad under grad_cap).
+// Same ownership scheme as k_sparse_update (the wave of an item's last occurrence owns its rows; first / last / count table),
+// but the gradient rows are RAW: the owner sums S = sum g, Q = sum g^2 (and adagrad's per-occurrence scaled sum) over all
+// occurrences of the item, applies opt_rule once per element and writes parameter, statistics and velocity.  With the
+// reference's "accurate" duplicate handling (gru4rec.py:321-326,349-358,373-378) every occurrence of an item sees the same
+// final statistic, so sums are all that is needed.  Simple rather than fast: the owner walks its occurrences alone.
+template <int MAXCH>
+__global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const DevModel* __restrict__ mp, StepState* st, int nblk_occ) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevModel& m = *mp;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const StepCtx c = load_ctx(st);
+    const int B = m.B, R = m.R;
+    if ((int)blockIdx.x == nblk_occ) {       // bookkeeping block, as in k_sparse_update
+        if (wid == 0) {
+            float s = 0.f;
+            for (int i = lane; i < c.M; i += 64) s += m.lossrow[i];
+            s = wave_sum(s);
+            if (lane == 0) {
+                const float cost = s * m.inv_B;
+                m.loss_steps[c.t] = cost;
+                GAS StepState* sg = (GAS StepState*)st;
+                if (isnan(cost)) sg->nan_flag = 1;
+                sg->t_a = c.t + 1;
+                sg->g_a = c.g + 1;
+                sg->M_a = m.Mplan[c.t + 1];
+            }
+        }
+        return;
+    }
+    const int Rpad = ((R + 255) & ~255) + 256;
+    int* sOcc = reinterpret_cast<int*>(smem);
+    int* myList = sOcc + Rpad + 64 * wid;
+    for (int j = tid; j < Rpad; j += SP_WAVES * 64) sOcc[j] = j < R ? m.occ_idx[j] : -2;
+    __syncthreads();
+    const int k = blockIdx.x * SP_WAVES + wid;
+    if (k >= R) return;
+    const int item = sOcc[k];
+    if (item < 0) return;
+    const bool constrained = (m.embed_mode == G4R_EMBED_CONSTRAINED);
+    const bool tableE = (k < B && !constrained);
+    GAS int* flp = m.occ_fl + 4 * ((tableE ? (size_t)m.n_items : 0) + item);
+    const int4 fl = ldi4(flp);
+    if (fl.x != k + 1) return;               // not the last occurrence of the item
+    if (lane == 0) *(GAS int4*)flp = make_int4(0, 0, 0, 0);
+    const int lo = (constrained || k < B) ? 0 : B;
+    const int first_j = max(lo, R - fl.y);
+    GAS float *P = tableE ? m.E : m.Wy, *A = tableE ? m.accE : m.accWy, *A2 = tableE ? m.acc2E : m.acc2Wy,
+              *Cn = tableE ? m.cntE : m.cntWy, *V = tableE ? m.velE : m.velWy;
+    const int W = tableE ? m.Ein : m.Dtop, nc4 = W >> 2;
+    const bool bias = (k >= B), mom = m.mom > 0.f;
+    const int adapt = m.adapt;
+    const float v1 = m.ap0, v3 = m.ap1, lr = m.lr, lmbd = m.lmbd, momc = m.mom, clip = m.gclip[0];
+    const bool adagrad = (adapt == G4R_ADAPT_ADAGRAD);
+    const GAS float *g_dSx = m.dSx, *g_dSy = m.dSy, *g_dSBy = m.dSBy;
+    // row state
+    float4 p0[MAXCH], a0[MAXCH], u0[MAXCH], c0[MAXCH], w0[MAXCH], S[MAXCH], Q[MAXCH], T1[MAXCH], gk[MAXCH];
+    auto sq = [](float4 x) { return make_float4(x.x * x.x, x.y * x.y, x.z * x.z, x.w * x.w); };
+    auto add4 = [](float4& a, float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    auto ada = [](float4 g, float4 a) {      // g / sqrt(a + g^2 + eps), per component
+        return make_float4(g.x / sqrtf(a.x + g.x * g.x + G4R_EPS_ADAGRAD), g.y / sqrtf(a.y + g.y * g.y + G4R_EPS_ADAGRAD),
+                           g.z / sqrtf(a.z + g.z * g.z + G4R_EPS_ADAGRAD), g.w / sqrtf(a.w + g.w * g.w + G4R_EPS_ADAGRAD));
+    };
+    auto grow = [&](int j, int q) {          // clipped gradient row chunk of occurrence j
+        const GAS float* srow = (j < B) ? g_dSx + (size_t)j * W : g_dSy + (size_t)(j - B) * W;
+        const float4 g = ld4(srow + 4 * min(lane + 64 * q, nc4 - 1));
+        return make_float4(clip * g.x, clip * g.y, clip * g.z, clip * g.w);
+    };
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) {
+        const size_t o = (size_t)item * W + 4 * min(lane + 64 * q, nc4 - 1);
+        p0[q] = ld4(P + o); a0[q] = ld4(A + o);
+        u0[q] = A2 ? ld4(A2 + o) : z4; c0[q] = Cn ? ld4(Cn + o) : z4; w0[q] = mom ? ld4(V + o) : z4;
+        gk[q] = grow(k, q);
+        S[q] = z4; Q[q] = z4; T1[q] = z4;
+    }
+    float bp0 = 0.f, ba0 = 0.f, bu0 = 0.f, bc0 = 0.f, bw0 = 0.f, bgk = 0.f, bS = 0.f, bQ = 0.f, bT1 = 0.f;
+    if (bias) {
+        bp0 = m.By[item]; ba0 = m.accBy[item]; bgk = clip * g_dSBy[k - B];
+        if (m.acc2By) bu0 = m.acc2By[item];
+        if (m.cntBy) bc0 = m.cntBy[item];
+        if (mom) bw0 = m.velBy[item];
+    }
+    // earlier occurrences in [first, k), 64 per pass, 4 rows per round trip
+    int n = 1, nb = bias ? 1 : 0;
+    if (fl.z > 1) {
+        for (int pass = 0;; ++pass) {
+            int idx = 0;
+            for (int base = first_j & ~63; base < k; base += 64) {
+                const int j = base + lane;
+                const bool hit = j >= first_j && j < k && sOcc[j] == item;
+                const unsigned long long mask = __ballot(hit);
+                const int ord = idx - 64 * pass + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (hit && ord >= 0 && ord < 64) myList[ord] = j;
+                idx += __popcll(mask);
+            }
+            const int cnt = min(idx - 64 * pass, 64);
+            const int myj = lane < cnt ? myList[lane] : -1;
+            if (bias) {
+                const float g = (myj >= B) ? clip * g_dSBy[myj - B] : 0.f;
+                bS += wave_sum(g); bQ += wave_sum(g * g);
+                bT1 += wave_sum((myj >= B) ? g / sqrtf(ba0 + g * g + G4R_EPS_ADAGRAD) : 0.f);
+                nb += __popcll(__ballot(myj >= B));
+            }
+            for (int i0 = 0; i0 < cnt; i0 += 4) {
+                float4 g[4][MAXCH];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int jj = __builtin_amdgcn_readlane(myj, min(i0 + u, cnt - 1) & 63);
+#pragma unroll
+                    for (int q = 0; q < MAXCH; ++q) g[u][q] = grow(jj, q);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (i0 + u < cnt) {
+#pragma unroll
+                        for (int q = 0; q < MAXCH; ++q) {
+                            add4(S[q], g[u][q]); add4(Q[q], sq(g[u][q]));
+                            if (adagrad) add4(T1[q], ada(g[u][q], a0[q]));
+                        }
+                    }
+                }
+            }
+            n += cnt;
+            if (idx <= 64 * (pass + 1)) break;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) {
+        add4(S[q], gk[q]); add4(Q[q], sq(gk[q]));
+        if (adagrad) add4(T1[q], ada(gk[q], a0[q]));
+        const float fn = (float)n;
+        const float pp[4] = {p0[q].x, p0[q].y, p0[q].z, p0[q].w}, aa[4] = {a0[q].x, a0[q].y, a0[q].z, a0[q].w};
+        const float uu[4] = {u0[q].x, u0[q].y, u0[q].z, u0[q].w}, cc[4] = {c0[q].x, c0[q].y, c0[q].z, c0[q].w};
+        const float ww[4] = {w0[q].x, w0[q].y, w0[q].z, w0[q].w}, ss[4] = {S[q].x, S[q].y, S[q].z, S[q].w};
+        const float qq[4] = {Q[q].x, Q[q].y, Q[q].z, Q[q].w}, tt[4] = {T1[q].x, T1[q].y, T1[q].z, T1[q].w};
+        const float gg[4] = {gk[q].x, gk[q].y, gk[q].z, gk[q].w};
+        float pn[4], an[4], un[4], cn[4], vn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const OptOut o = opt_rule(adapt, v1, v3, false, aa[e], uu[e], cc[e], ss[e], qq[e], tt[e], gg[e], fn);
+            const float reg = (lmbd > 0.f) ? lmbd * pp[e] : 0.f;
+            const float dsum = lr * (o.G + fn * reg);                  // sum of the per-occurrence deltas (gru4rec.py:419-423)
+            an[e] = o.A; un[e] = o.U; cn[e] = o.C;
+            if (mom) { vn[e] = momc * ww[e] - lr * (o.gl + reg); pn[e] = pp[e] + (fn * (momc * ww[e]) - dsum); }
+            else { vn[e] = 0.f; pn[e] = pp[e] - dsum; }
+        }
+        const int c4 = lane + 64 * q;
+        if (c4 < nc4) {
+            const size_t o = (size_t)item * W + 4 * c4;
+            st4(P + o, make_float4(pn[0], pn[1], pn[2], pn[3]));
+            st4(A + o, make_float4(an[0], an[1], an[2], an[3]));
+            if (A2) st4(A2 + o, make_float4(un[0], un[1], un[2], un[3]));
+            if (Cn) st4(Cn + o, make_float4(cn[0], cn[1], cn[2], cn[3]));
+            if (mom) st4(V + o, make_float4(vn[0], vn[1], vn[2], vn[3]));
+        }
+    }
+    if (bias && lane == 0) {
+        bS += bgk; bQ += bgk * bgk; bT1 += bgk / sqrtf(ba0 + bgk * bgk + G4R_EPS_ADAGRAD);
+        const float fb = (float)nb;
+        const OptOut o = opt_rule(adapt, v1, v3, false, ba0, bu0, bc0, bS, bQ, bT1, bgk, fb);
+        const float reg = (lmbd > 0.f) ? lmbd * bp0 : 0.f;
+        const float dsum = lr * (o.G + fb * reg);
+        m.accBy[item] = o.A;
+        if (m.acc2By) m.acc2By[item] = o.U;
+        if (m.cntBy) m.cntBy[item] = o.C;
+        if (mom) { m.velBy[item] = momc * bw0 - lr * (o.gl + reg); m.By[item] = bp0 + (fb * (momc * bw0) - dsum); }
+        else m.By[item] = bp0 - dsum;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -232,10 +232,11 @@ class GRU4Rec:
 
     # ------------------------------------------------------------------ native model management
     def _check_supported(self):
-        if self.adapt != 'adagrad':
-            raise NotImplementedError('adapt={} is outside the MI355X hot path (adagrad only)'.format(self.adapt))
-        if self.grad_cap:
-            raise NotImplementedError('grad_cap is outside the MI355X hot path')
+        if self.adapt not in _native.ADAPT_IDS:
+            raise NotImplementedError('adapt={}'.format(self.adapt))
+        need = {'rmsprop': 1, 'adadelta': 1, 'adam': 2}.get(self.adapt, 0)
+        if len(self.adapt_params) < need:
+            raise IndexError('adapt={} needs {} value(s) in adapt_params'.format(self.adapt, need))     # the reference indexes adapt_params[0..1]
         if self.smoothing and self.loss not in ('cross-entropy', 'xe_logit'):
             raise NotImplementedError('smoothing is only defined for cross-entropy / xe_logit (gru4rec.py:226-235)')
         if not self.constrained_embedding and not self.embedding and 3 * self.layers[0] > 512:
@@ -244,6 +245,9 @@ class GRU4Rec:
 
     def _create_model(self, sample_store, batch_size=None):
         self._check_supported()
+        if self.adapt == 'adadelta' and self.learning_rate != 1.0:      # gru4rec.py:362-364
+            print('Warn: learning_rate is not 1.0 while using adadelta. Setting learning_rate to 1.0')
+            self.learning_rate = 1.0
         nranks = self._dist['nranks'] if self._dist else 1
         rank = self._dist['rank'] if self._dist else 0
         m = _native.Model(
@@ -255,6 +259,8 @@ class GRU4Rec:
                 _native.EMBED_SEPARATE if self.embedding else _native.EMBED_ONEHOT),
             embedding=int(self.embedding or 0), learning_rate=self.learning_rate, momentum=self.momentum,
             lmbd=self.lmbd, bpreg=self.bpreg, logq=self.logq, sample_alpha=self.sample_alpha, smoothing=float(self.smoothing),
+            adapt=_native.ADAPT_IDS[self.adapt], adapt_p0=float(self.adapt_params[0]) if len(self.adapt_params) > 0 else 0.0,
+            adapt_p1=float(self.adapt_params[1]) if len(self.adapt_params) > 1 else 0.0, grad_cap=float(self.grad_cap),
             dropout_p_hidden=self.dropout_p_hidden, dropout_p_embed=self.dropout_p_embed,
             sample_store=int(sample_store), seed=int(self.seed) + 7919 * rank, device=int(self.device),
             rank=rank, nranks=nranks, use_graph=1 if self.use_graph else 0)

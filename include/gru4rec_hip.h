@@ -36,6 +36,8 @@ enum { G4R_ACT_LINEAR = 0, G4R_ACT_RELU = 1, G4R_ACT_TANH = 2, G4R_ACT_LEAKY = 3
 /* gru4rec.py:438-470: where the GRU input comes from */
 enum { G4R_EMBED_CONSTRAINED = 0 /* Wy shared, :438-448 */, G4R_EMBED_SEPARATE = 1 /* E, :449-456 */,
        G4R_EMBED_ONEHOT = 2 /* no embedding, layer 0 reads rows of Wx[0] (I x 3D), :457-470; the constructor default */ };
+/* gru4rec.py:392-399,411-418: learning-rate adaptation (`adapt`); NONE = plain SGD */
+enum { G4R_ADAPT_ADAGRAD = 0, G4R_ADAPT_RMSPROP = 1, G4R_ADAPT_ADADELTA = 2, G4R_ADAPT_ADAM = 3, G4R_ADAPT_NONE = 4 };
 /* evaluation.py:62-65 */
 enum { G4R_RANK_STANDARD = 0, G4R_RANK_CONSERVATIVE = 1, G4R_RANK_MEDIAN = 2 };
 
@@ -61,7 +63,10 @@ typedef struct g4r_config {
     int32_t rank, nranks;        /* data-parallel rank layout (1 process per GPU) */
     int32_t use_graph;           /* capture steady-state steps into a hipGraph */
     float   smoothing;           /* label smoothing of cross-entropy / xe_logit, gru4rec.py:226-235 */
-    int32_t reserved[6];
+    int32_t adapt;               /* G4R_ADAPT_* */
+    float   adapt_p0, adapt_p1;  /* adapt_params (rmsprop / adadelta: decay; adam: beta1, beta2), gru4rec.py:301-304,342,368 */
+    float   grad_cap;            /* global gradient-norm clip, 0 = off, gru4rec.py:386-389 */
+    int32_t reserved[2];
 } g4r_config;
 
 typedef struct g4r_model g4r_model;

@@ -59,7 +59,9 @@ def make_pair(I, B, ns, store_rows, seed=3, **kw):
         hidden_act=_native.ACT_IDS[ha[0]], hidden_act_p0=ha[1], hidden_act_p1=ha[2],
         embed_mode=0 if o.constrained_embedding else (1 if o.embedding else 2), embedding=int(o.embedding or 0),
         learning_rate=o.learning_rate, momentum=o.momentum, lmbd=o.lmbd, bpreg=o.bpreg, logq=o.logq,
-        smoothing=float(o.smoothing),
+        smoothing=float(o.smoothing), adapt=_native.ADAPT_IDS[o.adapt],
+        adapt_p0=float(o.adapt_params[0]) if len(o.adapt_params) > 0 else 0.0,
+        adapt_p1=float(o.adapt_params[1]) if len(o.adapt_params) > 1 else 0.0, grad_cap=float(o.grad_cap),
         sample_alpha=o.sample_alpha, dropout_p_hidden=o.dropout_p_hidden, dropout_p_embed=o.dropout_p_embed,
         sample_store=store_rows * ns if ns else 0, seed=seed, device=0, rank=0, nranks=1,
         use_graph=use_graph)
@@ -144,6 +146,19 @@ CASES = {
     'xe_smooth_sep': dict(loss='cross-entropy', final_act='softmax', constrained_embedding=False, embedding=8,
                           layers=(12,), smoothing=0.2),
     'xelogit_elu': dict(loss='xe_logit', final_act='elu-1.0', constrained_embedding=True, layers=(12,)),
+    # generic optimizer path (raw gradients -> rule in the update kernels), incl. global-norm clipping
+    'rmsprop_mom': dict(loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(12,), adapt='rmsprop',
+                        adapt_params=(0.9,), learning_rate=0.01, momentum=0.2),
+    'adadelta_xe': dict(loss='cross-entropy', final_act='softmax', constrained_embedding=True, layers=(12,), adapt='adadelta',
+                        adapt_params=(0.95,), learning_rate=1.0),
+    'adam_sep': dict(loss='bpr-max', final_act='elu-0.5', constrained_embedding=False, embedding=8, layers=(12,), adapt='adam',
+                     adapt_params=(0.9, 0.999), learning_rate=0.01),
+    'sgd_cap_2layer': dict(loss='top1-max', final_act='tanh', constrained_embedding=True, layers=(8, 12), adapt=None,
+                           grad_cap=0.05, learning_rate=0.05, momentum=0.1),
+    'adagrad_cap_lmbd': dict(loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(12,), grad_cap=0.02,
+                             lmbd=0.01),
+    'adam_onehot': dict(loss='cross-entropy', final_act='softmax', layers=(12,), adapt='adam', adapt_params=(0.9, 0.99),
+                        learning_rate=0.01, dropout_p_hidden=0.2),
     # one-hot input (the reference's constructor default: no embedding, layer 0 reads rows of Wx[0])
     'onehot_bprmax': dict(loss='bpr-max', final_act='elu-0.5', layers=(12,), momentum=0.2),
     'onehot_xe_2layer': dict(loss='cross-entropy', final_act='softmax', layers=(8, 12), dropout_p_hidden=0.2, dropout_p_embed=0.3,
@@ -179,9 +194,11 @@ def test_first_step_intermediates(name):
     close('ds', ds[:M][:, cols], dbg['ds'], atol=1e-6, rtol=1e-3, errs=errs)
     assert not ds[:M][:, M:B].any(), 'inactive in-batch columns must carry zero gradient'
     # the gradient producers store the per-occurrence Adagrad STEP lr * g / sqrt(acc_pre + g^2 + eps); acc_pre = 0 here
+    generic = (o.adapt != 'adagrad' or o.grad_cap > 0)       # generic optimizer path: the producers leave raw gradients
+
     def step_of(g):
         g = np.asarray(g, dtype=np.float64)
-        return o.learning_rate * g / np.sqrt(g * g + 1e-6)
+        return g if generic else o.learning_rate * g / np.sqrt(g * g + 1e-6)
     close('dSy(step)', m.get_debug('dSy', (ld, o.layers[-1]))[cols], step_of(dbg['dSy']), atol=2e-6, rtol=2e-3, errs=errs)
     close('dSBy(step)', m.get_debug('dSBy', (ld,))[cols], step_of(dbg['dSBy']), atol=2e-6, rtol=2e-3, errs=errs)
     ks = int(m.get_debug('ksplit', (1,))[0])

@@ -61,7 +61,7 @@ def test_reference_paramfiles_load(tmp_path):
 
 def test_out_of_scope_options_fail_loudly_at_fit():
     data = synth.make_sessions(50, n_items=30, seed=1)
-    for kw in (dict(adapt='adam', constrained_embedding=True), dict(grad_cap=1.0, constrained_embedding=True),
+    for kw in (dict(adapt='nadam', constrained_embedding=True),
                dict(smoothing=0.1, loss='bpr-max', constrained_embedding=True),
                dict(layers=[256])):   # last: one-hot input wider than the 512-float row limit
         kw.setdefault('layers', [8])
