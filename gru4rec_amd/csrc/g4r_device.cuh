@@ -43,6 +43,10 @@ __device__ __forceinline__ float4 ld4_if(const GAS float* base, size_t off, bool
     const float4 v = ld4(base + (ok ? off : (size_t)0));
     return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
+// raw variants: the element at `off` if ok, otherwise SOME valid element (no select after the load, so a group of them
+// stays in flight together); for values that are only consumed under the same condition
+__device__ __forceinline__ float4 ld4_at(const GAS float* base, size_t off, bool ok) { return ld4(base + (ok ? off : (size_t)0)); }
+__device__ __forceinline__ float ldf_at(const GAS float* base, size_t off, bool ok) { return base[ok ? off : (size_t)0]; }
 __device__ __forceinline__ float ldf_if(const GAS float* base, size_t off, bool ok) {
     const float v = base[ok ? off : (size_t)0];
     return ok ? v : 0.f;

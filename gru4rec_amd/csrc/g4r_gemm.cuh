@@ -55,8 +55,12 @@ __device__ __forceinline__ void stage_issue(StageRegs<ROWS, COLS, NTH>& r, int k
         }
     }
 }
-template <int ROWS, int COLS, int LD, int NTH>
-__device__ __forceinline__ void stage_commit(float* s, const StageRegs<ROWS, COLS, NTH>& r, int tid) {
+// `fix(kk, row, col, v)` (optional) post-processes a staged quad on its way to LDS: providers whose masking / dropout would
+// otherwise sit between the loads (and make the compiler wait for every load separately) return the raw quad and do that
+// work here, after all loads of the chunk have been issued.
+struct NoFix { __device__ __forceinline__ float4 operator()(int, int, int, float4 v) const { return v; } };
+template <int ROWS, int COLS, int LD, int NTH, class Fix = NoFix>
+__device__ __forceinline__ void stage_commit(float* s, const StageRegs<ROWS, COLS, NTH>& r, int tid, int kk = 0, Fix fix = Fix()) {
     constexpr int C4 = COLS / 4, TOTAL = ROWS * C4;
 #pragma unroll
     for (int q = 0; q < StageRegs<ROWS, COLS, NTH>::NQ; ++q) {
@@ -66,11 +70,12 @@ __device__ __forceinline__ void stage_commit(float* s, const StageRegs<ROWS, COL
         else { const int e = tid + NTH * q; row = e / C4; col = 4 * (e % C4); ok = e < TOTAL; }
         if (ok) {
             float* d = s + row * LD + col;
+            const float4 v = fix(kk, row, col, r.v[q]);
             if constexpr (LD % 4 == 0) {
-                *reinterpret_cast<float4*>(d) = r.v[q];
+                *reinterpret_cast<float4*>(d) = v;
             } else {
-                reinterpret_cast<float2*>(d)[0] = make_float2(r.v[q].x, r.v[q].y);
-                reinterpret_cast<float2*>(d)[1] = make_float2(r.v[q].z, r.v[q].w);
+                reinterpret_cast<float2*>(d)[0] = make_float2(v.x, v.y);
+                reinterpret_cast<float2*>(d)[1] = make_float2(v.z, v.w);
             }
         }
     }
@@ -87,9 +92,10 @@ struct NoHook { __device__ __forceinline__ void operator()(const float*, int, in
 // split every K chunk between them (so 2 waves per SIMD overlap their load-issue and MFMA latencies: the GEMMs of the
 // step only occupy a few dozen CUs, one workgroup each) and add their accumulators through LDS at the end; the
 // epilogue and its `pre` loads run on group 0.
-template <int BM, int BN, int BK, bool AKM, bool BNK, int NTH = 256, class ALoad, class BLoad, class Pre, class Epi, class Hook = NoHook>
+template <int BM, int BN, int BK, bool AKM, bool BNK, int NTH = 256, class ALoad, class BLoad, class Pre, class Epi, class Hook = NoHook,
+          class AFix = NoFix, class BFix = NoFix>
 __device__ __forceinline__ void gemm_tile(int m0, int n0, int K, ALoad aload, BLoad bload, Pre pre, Epi epi, float* smem,
-                                          GAS long long* clk = nullptr, Hook hook = Hook()) {      // clk: optional phase timestamps (debug)
+                                          GAS long long* clk = nullptr, Hook hook = Hook(), AFix afix = AFix(), BFix bfix = BFix()) {      // clk: optional phase timestamps (debug)
     using C = TileCfg<BM, BN, BK, AKM, BNK>;
     static_assert(NTH == 256 || NTH == 512, "4 or 8 waves");
     float* sA = smem;
@@ -113,8 +119,8 @@ __device__ __forceinline__ void gemm_tile(int m0, int n0, int K, ALoad aload, BL
         for (int rg = 0; rg < 4; ++rg) pf[q][rg] = pre(m0 + ms * 16 + 4 * lg + rg, n0 + ns * 16 + li);   // (both groups: branch-free)
     }
     if (clk && tid == 0) clk[0] = wall_clock64();      // loads issued
-    stage_commit<C::A_ROWS, C::A_COLS, C::LDA>(sA, ra, tid);
-    stage_commit<C::B_ROWS, C::B_COLS, C::LDB>(sB, rb, tid);
+    stage_commit<C::A_ROWS, C::A_COLS, C::LDA>(sA, ra, tid, 0, afix);
+    stage_commit<C::B_ROWS, C::B_COLS, C::LDB>(sB, rb, tid, 0, bfix);
     __syncthreads();
     if (clk && tid == 0) clk[1] = wall_clock64();      // first chunk in LDS
     for (int kk = 0; kk < K; kk += BK) {
@@ -140,8 +146,8 @@ __device__ __forceinline__ void gemm_tile(int m0, int n0, int K, ALoad aload, BL
         }
         if (more) {
             __syncthreads();
-            stage_commit<C::A_ROWS, C::A_COLS, C::LDA>(sA, ra, tid);
-            stage_commit<C::B_ROWS, C::B_COLS, C::LDB>(sB, rb, tid);
+            stage_commit<C::A_ROWS, C::A_COLS, C::LDA>(sA, ra, tid, kk + BK, afix);
+            stage_commit<C::B_ROWS, C::B_COLS, C::LDB>(sB, rb, tid, kk + BK, bfix);
             __syncthreads();
         }
     }

@@ -114,29 +114,39 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_p1(const DevModel* __restric
     const float retain_e = 1.0f - m.drop_e;
     const float drop_e = m.drop_e;
     const unsigned long long seed = m.seed;
+    // raw loads from clamped addresses, no selects or branches between them; zeroing of the out-of-range part and the
+    // embedding dropout happen in afix / bfix on the way to LDS (g4r_gemm.cuh: stage_commit)
     auto aload = [&](int kk, int r, int c) -> float4 {
-        const int row = m0 + r, k = kk + c;
-        const bool ok = row < M && k < K, isy = k < IN;
-        const int rowc = min(row, M - 1);      // rows past the batch must not even form an out-of-range address
+        const int k = min(kk + c, K - 4);
+        const bool isy = k < IN;
+        const int rowc = min(m0 + r, M - 1);      // rows past the batch must not even form an out-of-range address
         const GAS float* src = isy ? ((l == 0) ? table + (size_t)max(sRow[r], 0) * IN : ysrc + (size_t)rowc * IN)
                                    : Hcur + (size_t)rowc * D;
-        float4 v = ld4_if(src, isy ? k : k - IN, ok);
-        if (train && l == 0 && drop_e > 0.f && ok && isy) {
+        return ld4(src + (isy ? k : k - IN));
+    };
+    auto afix = [&](int kk, int r, int c, float4 v) -> float4 {
+        const int row = m0 + r, k = kk + c;
+        if (!(row < M && k < K)) return make_float4(0.f, 0.f, 0.f, 0.f);
+        if (train && l == 0 && drop_e > 0.f && k < IN) {
             const float4 mk = drop_mult4(seed, (unsigned)g, G4R_STREAM_DROP_EMBED, row, k >> 2, retain_e);
             v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
         }
         return v;
     };
     auto bload = [&](int kk, int r, int c) -> float4 {
-        const int k = kk + r, n = n0 + c;
+        const int k = min(kk + r, K - 1), n = min(n0 + c, D3 - 4);
         const bool isx = k < IN;
-        const bool ok = k < K && n < D3 && (isx || n >= D);
-        return ld4_if(isx ? Wx : Wrz, isx ? (size_t)k * D3 + n : (size_t)(k - IN) * (2 * D) + (n - D), ok);
+        return ld4(isx ? Wx + (size_t)k * D3 + n : Wrz + (size_t)(k - IN) * (2 * D) + max(n - D, 0));
+    };
+    auto bfix = [&](int kk, int r, int c, float4 v) -> float4 {
+        const int k = kk + r, n = n0 + c;
+        const bool ok = k < K && n < D3 && (k < IN || n >= D);
+        return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto pre = [&](int row, int n) -> float4 {      // bias and (for the r block) the hidden value
         const bool ok = row < M && n < D3;
-        const float oh = onehot ? ldf_if(table, (size_t)max(sRow[row - m0], 0) * D3 + n, ok) : 0.f;
-        return make_float4(ldf_if(Bh, n, ok), ldf_if(Hcur, (size_t)row * D + (n - D), ok && n >= D && n < 2 * D), oh, 0.f);
+        const float oh = onehot ? ldf_at(table, (size_t)max(sRow[row - m0], 0) * D3 + n, ok) : 0.f;
+        return make_float4(ldf_at(Bh, n, ok), ldf_at(Hcur, (size_t)row * D + (n - D), ok && n >= D && n < 2 * D), oh, 0.f);
     };
     auto epi = [&](int row, int n, float v, float4 p) {
         if (row >= M || n >= D3) return;
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_p1(const DevModel* __restric
             if (m0 + r < M) yin0[(size_t)(m0 + r) * IN + kk + k] = sA[r * LDA + k];
         }
     };
-    gemm_tile<GT_BM, GT_BN, P1_BK, false, false, GT_NTH_FEW>(m0, n0, K, aload, bload, pre, epi, smem, clk, hook);
+    gemm_tile<GT_BM, GT_BN, P1_BK, false, false, GT_NTH_FEW>(m0, n0, K, aload, bload, pre, epi, smem, clk, hook, afix, bfix);
 }
 
 // GRU phase 2: c = act(Hr * Wh + Vc) ; h = (1 - z) H + z c ; hidden dropout ; reset switch (gru4rec.py:474-479)
@@ -204,7 +214,7 @@ __global__ __launch_bounds__(GT_NTH) void k_gru_p2(const DevModel* __restrict__ 
     auto pre = [&](int row, int n) -> float4 {
         const bool ok = row < M && n < D;
         const size_t o = (size_t)row * D + n;
-        float4 p = make_float4(ldf_if(Vc, o, ok), ldf_if(zb, o, ok), ldf_if(Hcur, o, ok), 0.f);
+        float4 p = make_float4(ldf_at(Vc, o, ok), ldf_at(zb, o, ok), ldf_at(Hcur, o, ok), 0.f);
         if (train) p.w = rst[ok ? row : 0] ? 1.f : 0.f;
         return p;
     };
@@ -278,9 +288,9 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
     auto pre = [&](int row, int n) -> float4 {      // bias - logQ correction of the column's item
         const int item = (n < N) ? sItem[n - n0] : -1;
         const bool ok = item >= 0;
-        float x = ldf_if(By, max(item, 0), ok);
+        float x = ldf_at(By, max(item, 0), ok);
         const bool lq = ok && logq != 0.f;      // branch-free: the logQ table is only touched when it exists
-        x -= logq * ldf_if(lq ? (n < B ? lq_tgt : lq_smp) : By, max(item, 0), lq);
+        x -= logq * ldf_at(lq ? (n < B ? lq_tgt : lq_smp) : By, max(item, 0), lq);
         return make_float4(x, 0.f, 0.f, 0.f);
     };
     auto epi = [&](int row, int n, float v, float4 p) {
@@ -549,7 +559,7 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
         auto pre = [&](int n, int d) -> float4 {
             const int item = (n - n0 < GT_BM) ? sIt[n - n0] : -1;
             const bool ok = item >= 0 && d <= D;
-            const float a = (d < D) ? ldf_if(accWy, (size_t)max(item, 0) * D + d, ok) : ldf_if(accBy, max(item, 0), ok);
+            const float a = (d < D) ? ldf_at(accWy, (size_t)max(item, 0) * D + d, ok) : ldf_at(accBy, max(item, 0), ok);
             return make_float4(a, ok ? 1.f : 0.f, 0.f, 0.f);
         };
         auto epi = [&](int n, int d, float g, float4 p) {
@@ -644,7 +654,7 @@ __global__ __launch_bounds__(GT_NTH) void k_gru_bwd_a(const DevModel* __restrict
     auto pre = [&](int row, int n) -> float4 {
         const bool ok = row < M && n < D;
         const size_t o = (size_t)row * D + n;
-        return make_float4(ldf_if(rl, o, ok), ldf_if(Hcur, o, ok), 0.f, 0.f);
+        return make_float4(ldf_at(rl, o, ok), ldf_at(Hcur, o, ok), 0.f, 0.f);
     };
     auto epi = [&](int row, int n, float v, float4 p) {
         if (row >= M || n >= D) return;
@@ -681,7 +691,7 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_bwd_b(const DevModel* __rest
     GAS float *dSx = m.dSx, *dAx = m.dAx, *dylo = (l > 0) ? m.dyl[l - 1] : nullptr;
     auto pre = [&](int row, int n) -> float4 {      // pre-step accumulator of the input item's row (layer 0)
         const int item = (row - m0 < GT_BM) ? sRow[row - m0] : -1;
-        return make_float4(ldf_if(accT, (size_t)max(item, 0) * IN + n, item >= 0 && n < IN), 0.f, 0.f, 0.f);
+        return make_float4(ldf_at(accT, (size_t)max(item, 0) * IN + n, item >= 0 && n < IN), 0.f, 0.f, 0.f);
     };
     auto epi = [&](int row, int n, float v, float4 p) {
         if (row >= M || n >= IN) return;
@@ -777,7 +787,7 @@ __device__ __forceinline__ void dense_grad_tile(const DevModel& m, StepState* st
     auto pre = [&](int row, int col) -> float4 {      // optimizer state of the element (accumulator, parameter, velocity)
         const bool ok = inplace && row < tl.nrows && col < tl.ncols;
         const size_t off = (size_t)tl.base + (size_t)row * tl.ldo + col;
-        return make_float4(ldf_if(dacc, off, ok), ldf_if(dp, off, ok), ldf_if(dvel, off, ok && momc > 0.f), 0.f);
+        return make_float4(ldf_at(dacc, off, ok), ldf_at(dp, off, ok), ldf_at(dvel, off, ok && momc > 0.f), 0.f);
     };
     auto epi = [&](int row, int col, float g, float4 p) {
         if (row >= tl.nrows || col >= tl.ncols) return;

@@ -3,7 +3,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-cfg = bench.CONFIGS['cfg2']
+cfg = bench.CONFIGS[os.environ.get('CFG', 'cfg2')]
 plan, support = bench.make_plan(cfg, 400, 0, 1)
 m = bench.create_model(cfg, support, 0, 1, 0, None, use_graph=False)
 for k in ('in_idx', 'out_idx', 'reset', 'M'):
