@@ -130,3 +130,51 @@ def test_predict_shape(ci):
     got = m.predict_step(in_idx, sel)
     np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-6, err_msg=str(c))
     m.close()
+
+
+def test_large_catalogue_properties():
+    """BASELINE configs[2] scale (Rees46 shape: D = 512, batch 240, 2048 negatives; 1 M items here) where the oracle is too slow:
+    size-independent properties instead -- graph replay == eager launches bit for bit, rows of items that never occur keep
+    their initial bits (parameters AND accumulators), input / target rows all move, costs finite and decreasing on a repeated batch."""
+    I, D, B, ns, T = 1000003, 512, 240, 2048, 40
+    rng = np.random.RandomState(0)
+    Wy = (rng.rand(I, D).astype(np.float32) - 0.5) * 0.05
+    support = np.maximum(1, (1e6 / (1 + np.arange(I))).astype(np.int64))
+    pop = support.astype(np.float64) ** 0.5
+    P = (pop.cumsum() / pop.sum()).astype(np.float32)
+    P[-1] = 1
+    dense = {n: (rng.rand(*shape).astype(np.float32) - 0.5) * 0.1 for n, shape in
+             (('Wx', (D, 3 * D)), ('Wh', (D, D)), ('Wrz', (D, 2 * D)))}
+    base = rng.randint(0, I, size=(2, B)).astype(np.int32)
+    plan = dict(in_idx=np.tile(base[0], (T, 1)), out_idx=np.tile(base[1], (T, 1)), reset=np.zeros((T, B), dtype=np.uint8),
+                M=np.full(T, B, dtype=np.int32), T=T, n_compact=0)
+    outs = []
+    for use_graph in (0, 1):
+        m = _native.Model(n_items=I, layers=[D], batch_size=B, n_sample=ns, loss=_native.LOSS_IDS['cross-entropy'],
+                          final_act=_native.ACT_IDS['softmax'], hidden_act=_native.ACT_IDS['tanh'], embed_mode=0, embedding=0,
+                          learning_rate=0.065, momentum=0.0, logq=1.0, sample_alpha=0.5, dropout_p_embed=0.45,
+                          sample_store=ns * 64, seed=5, device=0, rank=0, nranks=1, use_graph=use_graph)
+        for n, a in dense.items():
+            m.set_param(n, a, 0)
+        m.set_param('Wy', Wy)
+        lq_t = np.log(support.astype(np.float32))
+        m.set_popularity(P, lq_t, np.log(support.astype(np.float32) ** np.float32(0.5)))
+        m.set_plan(plan)
+        m.train_steps(0, T)
+        store = m.get_sample_store(ns)
+        outs.append((m.get_losses(0, T), m.get_param('Wy', (I, D)), m.get_param('acc_Wy', (I, D)), m.get_param('Wh', (D, D), 0), store))
+        m.close()
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)                       # graph replay == eager, bit for bit
+    losses, Wy2, acc, _, store = outs[0]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    touched = np.zeros(I, dtype=bool)
+    touched[base.ravel()] = True
+    touched[store[:T].ravel()] = True
+    changed = (Wy2 != Wy).any(axis=1)
+    assert not changed[~touched].any() and not acc[~touched].any()     # untouched rows keep their bits
+    # every input / target row moved; sampled negatives move unless their softmax weight has underflowed to ~0 (the 40
+    # repeats of one batch make the model confident), and whatever gradient they saw is in the accumulator
+    never = touched & ~changed
+    assert not np.isin(np.nonzero(never)[0], base.ravel()).any()
+    assert never.sum() < 0.2 * touched.sum() and (acc[touched] >= 0).all() and (acc[touched & changed] > 0).any(axis=1).all()
