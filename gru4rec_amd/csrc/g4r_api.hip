@@ -526,6 +526,7 @@ int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
 }
 
 // ------------------------------------------------------------------------------------------------ the step
+static inline bool no_merge_tail() { static const bool v = getenv("G4R_NO_MERGE") != nullptr; return v; }
 // part: 0 = the whole step; 1 = head (everything up to the dense gradients); 2 = tail (all-reduce, dense apply, sparse update)
 static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     DevModel& d = m->dm;
@@ -565,6 +566,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     } while (0)
     const DevModel* dmp = (const DevModel*)m->d_dm;
     StepState* stp = (StepState*)d.st;
+    bool merged = false;      // the sparse update already ran inside k_update
     if (part != 2) {
     for (int l = 0; l < L; ++l) {
         begin(KN_GRU_P1);
@@ -596,28 +598,31 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         end();
     }
     static const bool no_merge = getenv("G4R_NO_MERGE") != nullptr;
-    if (part == 0 && d.apply_dense_inplace && !no_merge) {
-        // single GPU: dense-gradient tiles (+ fused dense Adagrad) and the sparse row update in ONE launch (k_update)
+    merged = !d.generic && !no_merge;
+    if (merged) {
+        // dense-gradient tiles (+ fused dense Adagrad on a single GPU; gradients to the RCCL buffer otherwise) and the sparse row
+        // update in ONE launch (k_update): the two are independent, the all-reduce / dense apply of N > 1 follow behind
         const size_t smem = std::max(SMEM_TN, m->smem_sparse);
         begin(KN_UPDATE);
         if (std::max(d.Dtop, d.Ein) <= 256) LK(k_update<1>, dim3(m->ntiles + m->nblk_occ + 1), dim3(SP_WAVES * 64), smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);
         else LK(k_update<2>, dim3(m->ntiles + m->nblk_occ + 1), dim3(SP_WAVES * 64), smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);
         end();
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
+        if (d.apply_dense_inplace || part == 1) { HIPCHK(hipGetLastError()); return 0; }
+    } else {
     begin(KN_DENSE);
     LK(k_dense_grad, dim3(m->ntiles), dim3(GT_NTH_FEW), SMEM_TN, s, dmp, stp, (const DenseTile*)m->d_tiles);
     end();
     }
+    }
     if (part == 1) { HIPCHK(hipGetLastError()); return 0; }
+    if (part == 2) merged = !d.generic && !no_merge_tail();
     // multi-rank: dense-gradient all-reduce, dense Adagrad, then the sparse embedding update, in stream order.
     // Optionally the first two run on their own stream next to the sparse update (which touches item rows only)
     // and join before the next step reads the GRU weights
     // (measured on one MI355X with a one-rank communicator: the two cross-stream event dependencies cost ~20 us per
     // step, more than the ~11 us of sparse update they can hide, so the overlap is opt-in: G4R_OVERLAP=1)
     static const bool want_overlap = getenv("G4R_OVERLAP") != nullptr;
-    const bool overlap = !d.apply_dense_inplace && !recs && !trace && want_overlap && !d.generic && (m->cfg.nranks > 1 || m->comm_ready);
+    const bool overlap = !d.apply_dense_inplace && !recs && !trace && want_overlap && !d.generic && !merged && (m->cfg.nranks > 1 || m->comm_ready);
     if (!d.apply_dense_inplace) {
         // staged dense path: (RCCL all-reduce when there are ranks) -> (global gradient norm -> clip factor, generic path with
         // grad_cap) -> dense rule on the flat gradient buffer
@@ -648,6 +653,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         HIPCHK(hipGetLastError());
         return 0;
     }
+    if (merged) { HIPCHK(hipGetLastError()); return 0; }
     begin(KN_SPARSE);
     if (std::max(d.Dtop, d.Ein) <= 256) LK(k_sparse_update<1>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
     else LK(k_sparse_update<2>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
