@@ -301,14 +301,14 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// Per-row final activation, loss and d cost / d s, in place in Sc.  One 512-thread workgroup per batch row; the row's
+// Per-row final activation, loss and d cost / d s, in place in Sc.  One 1024-thread workgroup per batch row; the row's
 // yhat and softmax numerators live in LDS (every thread only revisits the columns it wrote itself, so the passes need
 // no barriers besides the three block reductions); row statistics via DPP wave reductions.
 // Column j is active iff j < M (in-batch targets) or j >= B (sampled negatives); row i's positive is
 // column i.  Losses: gru4rec.py:225-230 (cross_entropy), :239-241 (bpr_max), :245-248 (top1_max),
 // softmax_neg :199-203.  The gradient goes through the softmax weights, as T.grad does.
 #ifndef LOSS_T
-#define LOSS_T 512
+#define LOSS_T 1024
 #endif
 #define LOSS_NW (LOSS_T / 64)
 // NV simultaneous block sums / maxima; `red` = NV * LOSS_NW floats that no other reduction of the kernel touches
