@@ -241,7 +241,9 @@ __global__ __launch_bounds__(GT_NTH) void k_gru_p2(const DevModel* __restrict__ 
 // Scoring GEMM: Sc[B, N] = h[B, D] * Wy[items]^T + By[items] - logq * lq[items]    (gru4rec.py:493-495)
 // 64 x 32 tiles; the B provider gathers the TN output-embedding rows of the tile's columns (in-batch targets,
 // then the step's row of the negative-sample store).  Publishes the column -> item map for the later kernels.
+#ifndef SF_BM
 #define SF_BM 64
+#endif
 __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict__ mp, StepState* st) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
@@ -914,7 +916,10 @@ __global__ __launch_bounds__(256) void k_dense_apply(const DevModel* __restrict_
 // every SP_WAVES-th occurrence, partial sums combined through LDS in wave order.  No atomics, bit-reproducible.
 // The extra last block folds the per-row losses into loss_steps[t] and advances the step state.
 #define SP_WAVES 8   // occurrences (waves) per workgroup
-#define SP_UB 8      // float4 step-row chunks one lane fetches together; items with more earlier occurrences are "hot"
+#ifndef SP_UB
+#define SP_UB 8
+#endif
+// SP_UB: float4 step-row chunks one lane fetches together; items with more earlier occurrences are "hot"
 
 // MAXCH = float4 chunks per lane (1: row width <= 256, 2: <= 512).
 template <int MAXCH>
