@@ -116,6 +116,12 @@ static constexpr size_t tile_smem() { return (size_t)TileCfg<BM, BN, BK, AKM, BN
 static const size_t SMEM_NN = tile_smem<GT_BM, GT_BN, GT_BK, false, false>() + GT_BM * sizeof(int);   // A [m][k], B [k][n] (+ row items)
 static const size_t SMEM_NT = tile_smem<GT_BM, GT_BN, GT_BK, false, true>() + GT_BM * sizeof(int);    // A [m][k], B [n][k] (+ row items)
 static const size_t SMEM_TN = tile_smem<GT_BM, GT_BN, GT_BK, true, false>();    // A [k][m], B [k][n]
+// wide layers: 64-column tiles halve the number of GRU phase-1 workgroups (all resident at once) and read the weights in
+// 256-byte runs; the 32-column tiles spread the tiny GEMMs of D ~ 100 over more CUs
+static constexpr auto k_gru_p1_n32 = k_gru_p1<GT_BN, P1_BK>;
+static constexpr auto k_gru_p1_n64 = k_gru_p1<64, 256>;
+static const size_t SMEM_P1_N64 = tile_smem<GT_BM, 64, 256, false, false>() + GT_BM * sizeof(int);
+static inline bool wide_layer(int D) { static const bool off = getenv("G4R_NARROW_TILES") != nullptr; return D >= 256 && !off; }
 static const size_t SMEM_P1 = tile_smem<GT_BM, GT_BN, P1_BK, false, false>() + GT_BM * sizeof(int);
 static const size_t SMEM_BB = tile_smem<GT_BM, GT_BN, BB_BK, false, true>() + GT_BM * sizeof(int);
 static const size_t SMEM_SF = tile_smem<SF_BM, GT_BN, GT_BK, false, true>() + GT_BN * sizeof(int);
@@ -286,7 +292,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     m->smem_score = ((size_t)(SC_BM + 32) * (SC_KC + 2) + 32) * sizeof(float);
     m->smem_loss = (size_t)(2 * d.ldSc + 18 * LOSS_NW) * sizeof(float);
     const int big = 156 * 1024;      // leaves room for the few bytes of static LDS some kernels use (__syncthreads_or)
-    HIPCHK(hipFuncSetAttribute((const void*)k_gru_p1, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gru_p1_n32, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gru_p1_n64, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_p2, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -570,7 +577,8 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     if (part != 2) {
     for (int l = 0; l < L; ++l) {
         begin(KN_GRU_P1);
-        LK(k_gru_p1, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
+        if (wide_layer(d.D[l])) LK(k_gru_p1_n64, dim3(cdiv(3 * d.D[l], 64), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1_N64, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
+        else LK(k_gru_p1_n32, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
         end();
         begin(KN_GRU_P2);
         LK(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH), SMEM_NN, s, dmp, stp, l, 1, nopa);
@@ -930,8 +938,12 @@ static int predict_forward(g4r_model* m, const int* d_in_idx, int mrows, const i
         pa.hout = (GP(float))m->phout[l];
         pa.Vc = (GP(float))m->pVc[l]; pa.z = (GP(float))m->pz[l]; pa.Hr = (GP(float))m->pHr[l];
         pa.M = mrows;
-        hipLaunchKernelGGL(k_gru_p1, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1, m->stream,
-                           (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, 0, pa);
+        if (wide_layer(d.D[l]))
+            hipLaunchKernelGGL(k_gru_p1_n64, dim3(cdiv(3 * d.D[l], 64), cdiv(mrows, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1_N64, m->stream,
+                               (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, 0, pa);
+        else
+            hipLaunchKernelGGL(k_gru_p1_n32, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1, m->stream,
+                               (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, 0, pa);
         hipLaunchKernelGGL(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(GT_NTH), SMEM_NN, m->stream,
                            (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, pa);
     }

@@ -66,6 +66,7 @@ struct GruFwdPredict {
 // GRU phase 1: V[B, 3D] = [y | H] * [Wx ; 0|Wrz] + Bh over 32x32 tiles, K = IN + D.
 // Epilogue per column block: [0,D) -> Vc (candidate pre-activation part), [D,2D) -> r = sigmoid, Hr = H*r,
 // [2D,3D) -> z = sigmoid.  For layer 0 the A provider gathers Wy[X] / E[X] rows and applies embedding dropout.
+template <int TBN, int TBK>
 __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_p1(const DevModel* __restrict__ mp, StepState* st, int l, int train, int first, GruFwdPredict pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
@@ -85,11 +86,11 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_p1(const DevModel* __restric
     } else {
         M = pa.M; Hcur = pa.Hcur; gidx = pa.in_idx; ysrc = pa.ysrc; Vc = pa.Vc; zb = pa.z; Hrb = pa.Hr;
     }
-    const int m0 = blockIdx.y * GT_BM, n0 = blockIdx.x * GT_BN;
+    const int m0 = blockIdx.y * GT_BM, n0 = blockIdx.x * TBN;
     GAS long long* clk = (m.dbgclk && blockIdx.x == 1 && blockIdx.y == 1) ? m.dbgclk + 0 : nullptr;      // kernel 0 of tools/clk.py
     if (clk && tid == 0) clk[4] = wall_clock64();     // context known
     // gather indices of the tile's rows go to LDS first: the row loads must not chain behind index loads
-    int* sRow = reinterpret_cast<int*>(smem + TileCfg<GT_BM, GT_BN, P1_BK, false, false>::SMEM_FLOATS);
+    int* sRow = reinterpret_cast<int*>(smem + TileCfg<GT_BM, TBN, TBK, false, false>::SMEM_FLOATS);
     if (tid < GT_BM) {
         const int row = m0 + tid;
         const int item = (l == 0 && row < M) ? gidx[row] : -1;
@@ -168,14 +169,14 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_p1(const DevModel* __restric
     const bool pub = train && l == 0 && blockIdx.x == 0 && IN > 0;
     auto hook = [&](const float* sA, int kk, int kend) {
         if (!pub) return;
-        constexpr int LDA = TileCfg<GT_BM, GT_BN, P1_BK, false, false>::LDA;
+        constexpr int LDA = TileCfg<GT_BM, TBN, TBK, false, false>::LDA;
         const int kmax = min(kend, IN - kk);          // columns of this chunk that belong to y
         for (int e = tid; e < GT_BM * kmax; e += GT_NTH_FEW) {
             const int r = e / kmax, k = e - r * kmax;
             if (m0 + r < M) yin0[(size_t)(m0 + r) * IN + kk + k] = sA[r * LDA + k];
         }
     };
-    gemm_tile<GT_BM, GT_BN, P1_BK, false, false, GT_NTH_FEW>(m0, n0, K, aload, bload, pre, epi, smem, clk, hook, afix, bfix);
+    gemm_tile<GT_BM, TBN, TBK, false, false, GT_NTH_FEW>(m0, n0, K, aload, bload, pre, epi, smem, clk, hook, afix, bfix);
 }
 
 // GRU phase 2: c = act(Hr * Wh + Vc) ; h = (1 - z) H + z c ; hidden dropout ; reset switch (gru4rec.py:474-479)
