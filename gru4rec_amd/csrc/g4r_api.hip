@@ -246,8 +246,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     DA(d.st, 1);
     // scoring backward geometry: role A tiles (n x d, one spare d column for dSBy), role B tiles (b x d x k-chunk)
     {
-        d.kch = GT_BK;
-        d.ksplit = cdiv(d.ldSc, GT_BK);
+        d.kch = GT_BK * std::max(1, (cdiv(d.ldSc, GT_BK) + 8) / 17);      // ~17 slabs whatever the number of negatives
+        d.ksplit = cdiv(d.ldSc, d.kch);
         DA(d.dhpart, (size_t)d.ksplit * B * d.Dtop);
         m->ndtA = cdiv(d.Dtop + 1, GT_BN);
         m->nblkA = cdiv(d.ldSc, GT_BM) * m->ndtA;
@@ -591,7 +591,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     LK(k_loss_rows, dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
     end();
     begin(KN_SCORE_BWD);
-    LK(k_score_bwd, dim3(m->nblkA + m->nblkB), dim3(GT_NTH), std::max(SMEM_TN, SMEM_NN) + GT_BK * sizeof(int), s, dmp, stp, m->nblkA, m->ndtA, m->ndtB, m->nrtB);
+    LK(k_score_bwd, dim3(m->nblkA + m->nblkB), dim3(GT_NTH), std::max(SMEM_TN, SMEM_NN) + (size_t)d.kch * sizeof(int), s, dmp, stp, m->nblkA, m->ndtA, m->ndtB, m->nrtB);
     end();
     for (int l = L - 1; l >= 0; --l) {
         begin(KN_BWD_PRE);

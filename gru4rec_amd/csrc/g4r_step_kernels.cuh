@@ -579,9 +579,12 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
     const int w = blockIdx.x - nblkA;
     const int per_kc = nrtB * ndtB;
     const int kc = w / per_kc, rem = w - kc * per_kc, rt = rem / ndtB, dt = rem - rt * ndtB;
-    const int m0 = rt * GT_BM, d0 = dt * GT_BN, kbeg = kc * GT_BK;
+    // a slab covers kch = (multiple of GT_BK) score columns: long score rows (many negatives) use wider slabs so that the
+    // number of split-K partials, and the traffic of writing and re-reading them, stays ~17 (host: d.kch)
+    const int kch = m.kch;
+    const int m0 = rt * GT_BM, d0 = dt * GT_BN, kbeg = kc * kch;
     if (m0 >= M) return;
-    if (tid < GT_BK) sIt[tid] = (kbeg + tid < ld) ? m.col_item[kbeg + tid] : -1;
+    for (int i = tid; i < kch; i += (int)blockDim.x) sIt[i] = (kbeg + i < ld) ? m.col_item[kbeg + i] : -1;
     __syncthreads();
     GAS float* dhpart = m.dhpart;
     auto aload = [&](int kk, int r, int cc) -> float4 {
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
     auto epi = [&](int b, int d, float v, float4) {
         if (b < M && d < D) dhpart[((size_t)kc * B + b) * D + d] = v;
     };
-    gemm_tile<GT_BM, GT_BN, GT_BK, false, false, GT_NTH>(m0, d0, min(GT_BK, ld - kbeg), aload, bload, NoPre(), epi, smem);
+    gemm_tile<GT_BM, GT_BN, GT_BK, false, false, GT_NTH>(m0, d0, min(kch, ld - kbeg), aload, bload, NoPre(), epi, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
