@@ -245,16 +245,17 @@ __global__ __launch_bounds__(GT_NTH) void k_gru_p2(const DevModel* __restrict__ 
 #ifndef SF_BM
 #define SF_BM 64
 #endif
+template <int TBN, int TBK>
 __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict__ mp, StepState* st) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
-    using C = TileCfg<SF_BM, GT_BN, GT_BK, false, true>;
-    int* sItem = reinterpret_cast<int*>(smem + C::SMEM_FLOATS);   // [GT_BN]
+    using C = TileCfg<SF_BM, TBN, TBK, false, true>;
+    int* sItem = reinterpret_cast<int*>(smem + C::SMEM_FLOATS);   // [TBN]
     const int tid = threadIdx.x;
     const StepCtx c = load_ctx(st);
     const int M = c.M, B = m.B, D = m.Dtop, N = m.N;
-    const int n0 = blockIdx.x * GT_BN, m0 = blockIdx.y * SF_BM;
-    if (tid < GT_BN) {
+    const int n0 = blockIdx.x * TBN, m0 = blockIdx.y * SF_BM;
+    if (tid < TBN) {
         const int n = n0 + tid;
         int item = -1;
         if (n < M) item = m.out_idx[c.t * B + n];
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
         if (row >= M || n >= N) return;
         Sc[(size_t)row * ldSc + n] = v + p.x;
     };
-    gemm_tile<SF_BM, GT_BN, GT_BK, false, true, GT_NTH>(m0, n0, D, aload, bload, pre, epi, smem);
+    gemm_tile<SF_BM, TBN, TBK, false, true, GT_NTH>(m0, n0, D, aload, bload, pre, epi, smem);
 }
 
 // ---------------------------------------------------------------------------------------------

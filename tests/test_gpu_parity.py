@@ -347,6 +347,23 @@ def test_wide_layer_and_big_batch():
     assert not errs, errs
 
 
+def test_many_negatives_big_batch():
+    """B = 300, 4200 negatives: the large-shape variants (64-deep K chunks in the scoring kernel, split-K slabs wider than
+    one chunk in its backward, 64-column GRU tiles at D = 256) against the oracle."""
+    I, B, ns, T = 6000, 300, 4200, 2
+    o, m = make_pair(I, B, ns, store_rows=4, loss='bpr-max', final_act='elu-0.5', constrained_embedding=True,
+                     layers=(256,), learning_rate=0.05, bpreg=0.5)
+    plan = random_plan(I, B, T, seed=29)
+    m.set_plan(plan)
+    want = [o.train_step(plan['in_idx'][t], plan['out_idx'][t], B, plan['reset'][t]) for t in range(T)]
+    m.train_steps(0, T)
+    errs = []
+    report('--- many negatives')
+    close('loss curve', m.get_losses(0, T), np.array(want), atol=5e-6, rtol=5e-4, errs=errs)
+    compare_params(o, m, errs, 'manyneg', atol=1e-4, rtol=2e-3)
+    assert not errs, errs
+
+
 @pytest.mark.parametrize('name', ['bprmax_elu', 'xe_softmax_logq', 'top1max_2layer', 'xe_sep_embed', 'xelogit_smooth', 'onehot_bprmax'])
 def test_predict_and_ranks(name):
     kw = CASES[name]
