@@ -44,6 +44,8 @@ SYMBOLS = [
     'g4r_synchronize', 'g4r_global_step', 'g4r_kernel_time', 'g4r_profile', 'g4r_reset_hidden',
     'g4r_predict_begin', 'g4r_predict_hidden', 'g4r_predict_step', 'g4r_rank_targets', 'g4r_evaluate', 'g4r_comm_unique_id',
     'g4r_comm_init', 'g4r_comm_sync_sparse', 'g4r_comm_min_i64', 'g4r_get_debug', 'g4r_selftest_mfma',
+    'g4r_events_load', 'g4r_events_rows', 'g4r_events_items', 'g4r_events_item_bytes', 'g4r_events_time_kind',
+    'g4r_events_copy', 'g4r_events_free',
 ]
 
 _lib = None
@@ -100,6 +102,12 @@ def lib():
     L.g4r_comm_min_i64.argtypes = [vp, i64p]
     L.g4r_get_debug.argtypes = [vp, C.c_char_p, f32p, i64]
     L.g4r_selftest_mfma.argtypes = [f32p]
+    L.g4r_events_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, i32, C.POINTER(vp)]
+    for fn in (L.g4r_events_rows, L.g4r_events_items, L.g4r_events_item_bytes):
+        fn.argtypes, fn.restype = [vp], i64
+    L.g4r_events_time_kind.argtypes, L.g4r_events_time_kind.restype = [vp], i32
+    L.g4r_events_copy.argtypes = [vp, i32p, i32p, vp, i64p, C.c_char_p]
+    L.g4r_events_free.argtypes, L.g4r_events_free.restype = [vp], None
     if L.g4r_sizeof_config() != C.sizeof(G4RConfig):
         raise NativeError('g4r_config layout mismatch between the header and the ctypes binding')
     _lib = L
@@ -129,6 +137,40 @@ def _i64(a):
 
 def _u8(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+IO_UNSUPPORTED = 1      # G4R_IO_UNSUPPORTED
+
+
+def load_events(path, session_col, item_col, time_col=None, threads=0):
+    """Native TSV parse (g4r_events_load): dict(session int32[n], item_idx int32[n], time int64|float64[n] or None,
+    item_ids list[str] in index order = order of first appearance), or None when the file needs pandas' general parser."""
+    L = lib()
+    h = C.c_void_p()
+    rc = L.g4r_events_load(os.fsencode(path), session_col.encode(), item_col.encode(),
+                           None if time_col is None else time_col.encode(), threads, C.byref(h))
+    if rc == IO_UNSUPPORTED:
+        return None
+    _chk(rc)
+    try:
+        n, k, nb, kind = L.g4r_events_rows(h), L.g4r_events_items(h), L.g4r_events_item_bytes(h), L.g4r_events_time_kind(h)
+        session = np.empty(n, dtype=np.int32)
+        item_idx = np.empty(n, dtype=np.int32)
+        time = None if kind == 0 else np.empty(n, dtype=np.int64 if kind == 1 else np.float64)
+        off = np.empty(k + 1, dtype=np.int64)
+        raw = C.create_string_buffer(max(int(nb), 1))
+        _chk(L.g4r_events_copy(h, _i32(session), _i32(item_idx), None if time is None else time.ctypes.data_as(C.c_void_p),
+                               _i64(off), raw))
+    finally:
+        L.g4r_events_free(h)
+    blob = raw.raw[:nb].decode('utf-8')
+    lo = off.tolist()
+    if len(blob) == nb:      # pure ASCII: byte offsets are character offsets
+        ids = [blob[lo[i]:lo[i + 1]] for i in range(k)]
+    else:
+        rb = raw.raw
+        ids = [rb[lo[i]:lo[i + 1]].decode('utf-8') for i in range(k)]
+    return dict(session=session, item_idx=item_idx, time=time, item_ids=ids)
 
 
 def build_plan(offset_sessions, session_order, data_items, batch_size, n_sample):

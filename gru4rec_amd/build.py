@@ -5,9 +5,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'g4r_api.hip')
+SRC_HOST = os.path.join(HERE, 'csrc', 'g4r_io.cpp')      # host-only translation unit (event-table loader)
 OUT = os.path.join(HERE, 'libgru4rec_hip.so')
 DEPS = [os.path.join(HERE, 'csrc', f) for f in ('g4r_api.hip', 'g4r_device.cuh', 'g4r_gemm.cuh', 'g4r_step_kernels.cuh',
-                                                 'g4r_eval_kernels.cuh')] + \
+                                                 'g4r_eval_kernels.cuh', 'g4r_io.cpp')] + \
        [os.path.join(os.path.dirname(HERE), 'include', 'gru4rec_hip.h')]
 
 
@@ -15,8 +16,13 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     rocm = os.environ.get('ROCM_PATH', '/opt/rocm')
+    obj = os.path.join(HERE, 'csrc', 'g4r_io.o')      # host-only unit: plain g++, linked into the same library
+    host = [os.environ.get('CXX', 'g++'), '-O3', '-std=c++17', '-fPIC', '-pthread', '-c', SRC_HOST, '-o', obj]
+    if verbose:
+        print(' '.join(host))
+    subprocess.check_call(host)
     cmd = [os.path.join(rocm, 'bin', 'hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
-           '-I' + os.path.join(rocm, 'include'), '-o', OUT, SRC, '-L' + os.path.join(rocm, 'lib'), '-lrccl',
+           '-I' + os.path.join(rocm, 'include'), '-o', OUT, SRC, '-Wl,' + obj, '-pthread', '-L' + os.path.join(rocm, 'lib'), '-lrccl',
            '-Wl,-rpath,' + os.path.join(rocm, 'lib')]
     if verbose:
         print(' '.join(cmd))

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdarg>
 #include <string>
 #include <vector>
 
@@ -19,6 +20,15 @@
 
 static thread_local std::string g_err;
 static int fail(const std::string& s) { g_err = s; return -1; }
+// printf-style setter for the host-only translation units of the library (g4r_io.cpp)
+void g4r_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
 #define HIPCHK(x)                                                                                        \
     do {                                                                                                 \
         hipError_t e_ = (x);                                                                             \

@@ -12,7 +12,32 @@ import numpy as np
 import pandas as pd
 
 
+def _prepare_categorical(gru, test_data, items, session_key, item_key, time_key):
+    """_prepare for tables from eventio.read_events: the inner join on the item id, the (session, time, item id) ordering and
+    the session sizes of evaluation.py:86-95 as linear passes over integer arrays."""
+    from . import datatools, eventio
+    col = test_data[item_key]
+    idx = eventio.lookup_item_index(col, gru.itemidmap)
+    keep = idx >= 0                                   # how='inner': events of items the model does not know are dropped
+    sess, tm = test_data[session_key].values[keep], test_data[time_key].values[keep]
+    idx, codes = idx[keep], np.asarray(col.cat.codes.values)[keep]
+    n = len(idx)
+    ordered = n < 2 or bool(np.all((sess[1:] > sess[:-1]) | ((sess[1:] == sess[:-1]) & (tm[1:] > tm[:-1]))))
+    if not ordered:
+        # ties on (session, time) are broken by the item id *string*, as sort_values on a str column does
+        cats = np.asarray(col.cat.categories.values, dtype=object).astype(str)
+        lex = np.empty(len(cats), dtype=np.int64)
+        lex[np.argsort(cats, kind='stable')] = np.arange(len(cats))
+        order = np.lexsort((lex[codes], tm, sess))
+        sess, idx = sess[order], idx[order]
+    item_idxs = None if items is None else gru.itemidmap[items].values.astype(np.int32)
+    offs = datatools.compute_offset(pd.DataFrame({session_key: sess}, copy=False), session_key).astype(np.int64)
+    return idx.astype(np.int32), item_idxs, offs
+
+
 def _prepare(gru, test_data, items, session_key, item_key, time_key):
+    if isinstance(test_data[item_key].dtype, pd.CategoricalDtype):
+        return _prepare_categorical(gru, test_data, items, session_key, item_key, time_key)
     lookup = pd.DataFrame({'ItemIdx': gru.itemidmap.values, item_key: gru.itemidmap.index})
     test_data = pd.merge(test_data, lookup, on=item_key, how='inner')
     test_data.sort_values([session_key, time_key, item_key], inplace=True)

@@ -16,7 +16,7 @@ from collections import OrderedDict  # noqa: F401  (kept: parameter files use it
 import numpy as np
 import pandas as pd
 
-from . import _native, datatools
+from . import _native, datatools, eventio
 from .plan import build_rank_plan
 
 _PLAIN_ACTS = ('linear', 'relu', 'tanh', 'softmax')
@@ -53,6 +53,8 @@ def _markers(*names):
 
 class GRU4Rec:
     """Same constructor arguments and defaults as the reference (gru4rec.py:97-101)."""
+
+    accepts_categorical_items = True      # fit / evaluate_gpu take tables from eventio.read_events (run.py asks)
 
     def __init__(self, loss='bpr-max', final_act='linear', hidden_act='tanh', layers=[100],
                  n_epochs=10, batch_size=32, dropout_p_hidden=0.0, dropout_p_embed=0.0, learning_rate=0.1,
@@ -309,15 +311,23 @@ class GRU4Rec:
             raise NotImplementedError
         self.predict = None
         self.error_during_train = False
-        itemids = data[self.item_key].unique()
-        self.n_items = len(itemids)
-        self.itemidmap = pd.Series(data=np.arange(self.n_items), index=itemids, name='ItemIdx')
-        data['ItemIdx'] = self.itemidmap[data[self.item_key].values].values
+        item_col = data[self.item_key]
+        if eventio.is_categorical(item_col):
+            # table from eventio.read_events: the category codes already are the indices (no hash join over the events)
+            itemids, item_idx = eventio.first_appearance_index(item_col)
+            self.n_items = len(itemids)
+            self.itemidmap = pd.Series(data=np.arange(self.n_items), index=itemids, name='ItemIdx')
+            data['ItemIdx'] = item_idx
+        else:
+            itemids = item_col.unique()
+            self.n_items = len(itemids)
+            self.itemidmap = pd.Series(data=np.arange(self.n_items), index=itemids, name='ItemIdx')
+            data['ItemIdx'] = self.itemidmap[item_col.values].values
         datatools.sort_if_needed(data, [self.session_key, self.time_key])
         self._offsets = datatools.compute_offset(data, self.session_key)
         self._init_host_weights()
-        support = data.groupby(self.item_key).size()
-        support = support[self.itemidmap.index.values].values
+        # events per item in itemidmap order: data.groupby(item_key).size()[itemidmap.index] of gru4rec.py:540-541
+        support = np.bincount(data['ItemIdx'].values, minlength=self.n_items)
         if self._model is not None:
             self._model.close()
         self._model = self._create_model(sample_store)
@@ -337,7 +347,9 @@ class GRU4Rec:
         if self.n_sample and m.sample_store_rows() > 0:
             print('Created sample store with {} batches of samples (type=GPU)'.format(m.sample_store_rows()))
         if self.time_sort:
-            self._base_order = np.argsort(data.groupby(self.session_key)[self.time_key].min().values)
+            # data is ordered by (session, time): a session's first row holds its minimum time (the groupby().min() of
+            # gru4rec.py:585-586, sessions in ascending id order)
+            self._base_order = np.argsort(data[self.time_key].values[self._offsets[:-1]])
         else:
             self._base_order = np.arange(len(self._offsets) - 1)
         self._data_items = data.ItemIdx.values.astype(np.int32)
@@ -411,6 +423,13 @@ class GRU4Rec:
             if self._dist:
                 self._model.comm_sync_sparse()
         self._download_weights()
+
+    def close(self):
+        """Releases the device model (parameters stay on the host object); the next predict / fit creates a new one."""
+        if self._model is not None:
+            self._model.close()
+            self._model = None
+        self.predict = None
 
     # ------------------------------------------------------------------ prediction (gru4rec.py:665-728)
     def _ensure_model(self):

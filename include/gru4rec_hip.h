@@ -148,6 +148,26 @@ int g4r_evaluate(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
                  const int32_t* items, int64_t n_items_sel, const int32_t* cutoffs, int32_t n_cut, int32_t mode,
                  double* recall_sum, double* mrr_sum, int64_t* n_events);
 
+/* ---- input pipeline: the pandas work in front of fit() for TAB separated files -------------
+ * run.py:45-78 `pd.read_csv(sep='\t', usecols, dtype={session: int32, item: str})` + gru4rec.py:534-538
+ * `itemids = data[item_key].unique(); itemidmap = Series(arange, index=itemids); data['ItemIdx'] = itemidmap[...]`.
+ * Multi-threaded mmap parse; item indices are assigned in order of first appearance (= pandas unique()).  Host only.
+ * Returns 0, G4R_IO_UNSUPPORTED when the file needs a general CSV parser (quoted fields, missing values, session ids
+ * that are not int32: the caller falls back to pandas), or <0 with g4r_last_error().  time_col may be NULL.
+ * n_threads: 0 = all cores (at most 64, at most one per MiB), > 0 = at most that many, < 0 = exactly -n_threads (tests). */
+#define G4R_IO_UNSUPPORTED 1
+typedef struct g4r_events g4r_events;
+int g4r_events_load(const char* path, const char* session_col, const char* item_col, const char* time_col, int32_t n_threads,
+                    g4r_events** out);
+int64_t g4r_events_rows(const g4r_events* ev);
+int64_t g4r_events_items(const g4r_events* ev);
+int64_t g4r_events_item_bytes(const g4r_events* ev);     /* total length of the distinct item-id strings */
+int32_t g4r_events_time_kind(const g4r_events* ev);      /* 0 = no time column, 1 = int64, 2 = float64 */
+/* session[n_rows] int32, item_idx[n_rows] int32, time[n_rows] (int64 or double by time_kind), item_off[n_items + 1] offsets
+ * into item_bytes (item ids in index order, not terminated).  Any output may be NULL. */
+int g4r_events_copy(const g4r_events* ev, int32_t* session, int32_t* item_idx, void* time, int64_t* item_off, char* item_bytes);
+void g4r_events_free(g4r_events* ev);
+
 /* ---- multi-GPU (new: the reference is single-GPU).  RCCL all-reduce of dense GRU gradients ---- */
 int g4r_comm_unique_id(char* out128);                         /* rank 0: ncclGetUniqueId */
 int g4r_comm_init(g4r_model* m, const char* id128, int32_t nranks, int32_t rank);
