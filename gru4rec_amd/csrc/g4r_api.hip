@@ -255,7 +255,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     DA(d.dSx, (size_t)B * d.Ein); DA(d.dSy, (size_t)d.ldSc * d.Dtop); DA(d.dSBy, d.ldSc);
     DA(d.dAx, (size_t)B * d.Ein); DA(d.dAy, (size_t)d.ldSc * d.Dtop); DA(d.dABy, d.ldSc);
     DA(d.lossrow, B);
-    DA(d.occ_idx, d.R + 64); DA(d.col_item, d.ldSc);
+    DA(d.occ_idx, ((d.R + 255) & ~255) + 256 + 64);      // k_sparse_update stages it with 16-byte loads up to Rpad
+    DA(d.col_item, d.ldSc);
     DA(d.occ_fl, (size_t)(cfg->embed_mode != G4R_EMBED_CONSTRAINED ? 2 : 1) * I * 4);
     DA(d.st, 1);
     // scoring backward geometry: role A tiles (n x d, one spare d column for dSBy), role B tiles (b x d x k-chunk)

@@ -973,7 +973,20 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     int* myList = sList + 64 * wid;
     GAS int* g_fl = m.occ_fl;
     const int nI = m.n_items;
-    const int k = blk * SP_WAVES + wid;
+    // occurrence of this wave: strided over the workgroups (wave w of workgroup b takes k = w * nblk + b).  The last occurrences of
+    // the popular items -- their owners, which have the duplicate sums to do -- sit together at the end of the list; with a
+    // contiguous mapping they would share a few workgroups that then run their hot-item rounds one after the other
+    const int k = wid * nblk_occ + blk;
+    // short occurrence lists (Rpad <= 4096) are requested right away, next to the first loads of the wave, and only written to
+    // LDS if some wave turns out to own an item with earlier occurrences; longer lists are fetched when that is known (for
+    // those the loads below all go to element 0: one cache line per wave, no branch between the loads)
+    constexpr int EARLY = 2;
+    const int n4 = Rpad >> 2;
+    const GAS int4* g_occ4 = (const GAS int4*)g_occ;
+    const bool early = n4 <= EARLY * SP_WAVES * 64;
+    int4 ev[EARLY];
+#pragma unroll
+    for (int q = 0; q < EARLY; ++q) ev[q] = g_occ4[early ? min(q * SP_WAVES * 64 + tid, n4 - 1) : 0];
     int item = g_occ[min(k, R - 1)];
     if (k >= R) item = -1;
     // occurrence range sharing a table with k: constrained -> all of X|Y|samples ; separate -> X alone, Y|samples alone
@@ -1021,21 +1034,39 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     auto scan = [&](int it, int a, int b, int pass, int& nb) {
         int idx = 0;
         nb = 0;
-        for (int base = a & ~255; base < b; base += 256) {
-            int v[4];
+        for (int base0 = a & ~255; base0 < b; base0 += 1024) {
+            // 1024 entries per step: four 16-byte LDS reads per lane (four consecutive entries each) are requested together;
+            // reads past Rpad stay inside the workgroup's LDS allocation and can never match (j < b fails)
+            int4 vv[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = sOcc[base + 64 * e + lane];
+            for (int u = 0; u < 4; ++u) vv[u] = *reinterpret_cast<const int4*>(sOcc + base0 + 256 * u + 4 * lane);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+            const int4 v = vv[u];
+            const int j = base0 + 256 * u + 4 * lane;
+            const bool h0 = v.x == it && j >= a && j < b, h1 = v.y == it && j + 1 >= a && j + 1 < b;
+            const bool h2 = v.z == it && j + 2 >= a && j + 2 < b, h3 = v.w == it && j + 3 >= a && j + 3 < b;
+            if (__ballot(h0 || h1 || h2 || h3) == 0) continue;       // the common case: a few compares and a scalar branch
+            // ascending occurrence order = lane-major: all matches of lower lanes first, then this lane's earlier elements
+            const bool hh[4] = {h0, h1, h2, h3};
+            unsigned long long mk[4];
+            int below = 0, total = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (__ballot(v[e] == it) == 0) continue;       // the common case costs a compare and a scalar branch
-                const int j = base + 64 * e + lane;
-                const bool hit = j >= a && j < b && v[e] == it;
-                const unsigned long long mask = __ballot(hit);
-                const int ord = idx - 64 * pass +
-                                (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                if (hit && ord >= 0 && ord < 64) myList[ord] = j;
-                idx += __popcll(mask);
-                nb += __popcll(__ballot(hit && j >= B));
+                mk[e] = __ballot(hh[e]);
+                below += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[e] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk[e], 0u));
+                total += __popcll(mk[e]);
+                nb += __popcll(__ballot(hh[e] && j + e >= B));
+            }
+            int ord = idx - 64 * pass + below;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (hh[e]) {
+                    if (ord >= 0 && ord < 64) myList[ord] = j + e;
+                    ++ord;
+                }
+            }
+            idx += total;
             }
         }
         return idx;
@@ -1049,17 +1080,24 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     for (int q = 0; q < MAXCH; ++q) S[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lane == 0) { sHot[wid] = hot ? item : -1; sHot[SP_WAVES + wid] = first_j; }
     const bool any_dup = __syncthreads_or(dup ? 1 : 0) != 0;
-    long long t_col = t_own, t_app = t_own;
+    long long t_col = t_own, t_app = t_own, t_h[5] = {0, 0, 0, 0, 0};      // t_h: phases of the last hot round (debug)
     if (any_dup) {
         // ---- some wave of this workgroup owns an item with earlier occurrences: stage the occurrence list
-        for (int j0 = 0; j0 < Rpad; j0 += 4 * SP_WAVES * 64) {     // 4 independent loads in flight per thread
-            int v[4];
+        auto commit4 = [&](int j4, int4 v) {
+            const int j = 4 * j4;
+            if (j4 < n4) *reinterpret_cast<int4*>(sOcc + j) = make_int4(j < R ? v.x : -2, j + 1 < R ? v.y : -2, j + 2 < R ? v.z : -2, j + 3 < R ? v.w : -2);
+        };
+        if (early) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = g_occ[min(j0 + q * SP_WAVES * 64 + tid, R - 1)];
+            for (int q = 0; q < EARLY; ++q) commit4(q * SP_WAVES * 64 + tid, ev[q]);
+        } else {
+            // 16-byte loads, up to 4 in flight per thread: one round trip for R <= 8192 (the buffer is padded to Rpad ints)
+            for (int j0 = 0; j0 < n4; j0 += 4 * SP_WAVES * 64) {
+                int4 v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = j0 + q * SP_WAVES * 64 + tid;
-                if (j < Rpad) sOcc[j] = j < R ? v[q] : -2;
+                for (int q = 0; q < 4; ++q) v[q] = g_occ4[min(j0 + q * SP_WAVES * 64 + tid, n4 - 1)];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) commit4(j0 + q * SP_WAVES * 64 + tid, v[q]);
             }
         }
         __syncthreads();
@@ -1068,13 +1106,15 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
         //   h = -1 : a wave sums the (<= UB) earlier occurrences of its own item, range [first, k)
         //   h >= 0 : hot item of wave h; every wave sums the occurrences found in its slice of [first, k_h), the
         //            partial sums are combined through LDS in wave (= occurrence) order
-        for (int h = -1; h < SP_WAVES; ++h) {
+        // hot owners of this workgroup (one LDS read instead of one per candidate wave)
+        unsigned hm = (unsigned)__ballot(lane < SP_WAVES && sHot[lane & (SP_WAVES - 1)] >= 0);
+        for (int h = -1; h < SP_WAVES; h = hm ? (int)__builtin_ctz(hm) : SP_WAVES, hm &= hm - 1) {
             int it = item, a = first_j, b = k, tW = W, tnc4 = nc4;
             bool tb = bias, active = dup && !hot;
             if (h >= 0) {
                 it = sHot[h];
                 if (it < 0) continue;             // workgroup-uniform
-                const int hk = blk * SP_WAVES + h, hlo = sHot[SP_WAVES + h];
+                const int hk = h * nblk_occ + blk, hlo = sHot[SP_WAVES + h];
                 const int slice = (((hk - hlo + SP_WAVES - 1) / SP_WAVES) + 63) & ~63;
                 a = hlo + wid * slice; b = min(hk, a + slice);
                 tW = (hk < B && !constrained) ? wE : wY; tnc4 = tW >> 2;
@@ -1083,11 +1123,18 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
             float4 T[MAXCH];
             float Tb = 0.f;
             int n_w = 0, nb_w = 0;
+            if (m.dbgclk && h >= 0) t_h[0] = wall_clock64();
 #pragma unroll
             for (int q = 0; q < MAXCH; ++q) T[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (active) {
                 for (int pass = 0;; ++pass) {
-                    n_w = scan(it, a, b, pass, nb_w);
+                    if (h < 0 && fl.z == 2) {          // one earlier occurrence: it is the first one, nothing to search
+                        if (lane == 0) myList[0] = a;
+                        n_w = 1; nb_w = (a >= B) ? 1 : 0;
+                    } else {
+                        n_w = scan(it, a, b, pass, nb_w);
+                    }
+                    if (m.dbgclk && h >= 0 && pass == 0) t_h[1] = wall_clock64();
                     const int cnt = min(n_w - 64 * pass, 64);
                     const int myj = lane < cnt ? myList[lane] : -1;
                     const float bd = (tb && myj >= B) ? g_dSBy[max(myj - B, 0)] : 0.f;
@@ -1125,6 +1172,7 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
                 if (m.dbgclk) t_app = wall_clock64();
                 continue;
             }
+            if (m.dbgclk) t_h[2] = wall_clock64();
             float* part = sPart + wid * PW;
 #pragma unroll
             for (int q = 0; q < MAXCH; ++q) {
@@ -1133,6 +1181,7 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
             }
             if (lane == 0) { part[PW - 4] = Tb; part[PW - 3] = __int_as_float(n_w); part[PW - 2] = __int_as_float(nb_w); }
             __syncthreads();
+            if (m.dbgclk) t_h[3] = wall_clock64();
             if (wid == h) {
                 for (int w = 0; w < SP_WAVES; ++w) {
 #pragma unroll
@@ -1146,6 +1195,7 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
                 }
             }
             __syncthreads();
+            if (m.dbgclk) t_h[4] = wall_clock64();
         }
     }
     // ---- final row values from S + s_k (sum over all occurrences) and the last occurrence's rows, and the stores
@@ -1186,7 +1236,8 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     if (m.dbgclk && lane == 0 && k < R) {
         const long long t_end = wall_clock64();
         GAS long long* tr = m.dbgclk + 64 + 8 * k;
-        tr[0] = t_start; tr[1] = t_own; tr[2] = t_col; tr[3] = t_app; tr[4] = t_end; tr[5] = owner ? fl.z : 0; tr[6] = c.t; tr[7] = item;
+        tr[0] = t_start; tr[1] = t_own; tr[2] = t_col; tr[3] = t_app; tr[4] = t_end; tr[5] = (owner ? fl.z : 0) | ((t_h[0] ? t_h[0] - t_app : 0) << 20); tr[6] = c.t;
+        tr[7] = (t_h[1] - t_h[0]) | ((t_h[2] - t_h[1]) << 16) | ((t_h[3] - t_h[2]) << 32) | ((t_h[4] - t_h[3]) << 48);
     }
 }
 

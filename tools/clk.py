@@ -28,9 +28,16 @@ for rep in range(5):
     tr = tr[(tr[:, 4] > 0) & (tr[:, 6] == 200 + rep)]
     t0 = tr[:, 0].min()
     d = (tr[:, 4] - tr[:, 0]) / 100.0
-    o = np.argsort(-d)[:6]
-    print('  kernel span %.1f us; block start spread %.1f us' % ((tr[:, 4].max() - t0) / 100.0, (tr[:, 0].max() - t0) / 100.0))
-    for q in o:
+    pc = lambda x: np.round(np.percentile(x, [0, 50, 90, 99, 100]), 1)
+    print('  sparse role: span %.1f us; wave start pct(0,50,90,99,100) %s; wave duration pct %s' % (
+        (tr[:, 4].max() - t0) / 100.0, pc((tr[:, 0] - t0) / 100.0), pc(d)))
+    ph = np.stack([tr[:, 1] - tr[:, 0], tr[:, 2] - tr[:, 1], tr[:, 3] - tr[:, 2], tr[:, 4] - tr[:, 3]], 1) / 100.0
+    cnt = tr[:, 5] & 0xFFFFF
+    print('  mean phase us: row fetch %.2f  stage list %.2f  own dups %.2f  hot loops + store %.2f ; owners %d of %d, dup owners %d, hot owners(>8) %d' % (
+        *ph.mean(0), (cnt > 0).sum(), len(tr), (cnt > 1).sum(), (cnt > 9).sum()))
+    for q in np.argsort(-d)[:5]:
         a = tr[q]
-        print('   wave item %6d dups %3d: stage+scan %.1f  collect %.1f  apply %.1f [pre %.1f rows %.1f bias %.1f] store %.1f' % (
-            a[7], a[5], (a[1] - a[0]) / 100.0, (a[2] - a[1]) / 100.0, (a[3] - a[2]) / 100.0, (a[6] >> 40) / 100.0, ((a[6] >> 20) & 0xFFFFF) / 100.0, (a[6] & 0xFFFFF) / 100.0, (a[4] - a[3]) / 100.0))
+        hr = [(a[7] >> sh) & 0xFFFF for sh in (0, 16, 32, 48)]
+        print('   wave count %3d: start +%.1f | row fetch %.1f  stage list %.1f  own dups %.1f  hot loops + store %.1f | last hot round: +%.2f scan %.2f rows %.2f wait %.2f combine %.2f -> end %.2f' % (
+            cnt[q], (a[0] - t0) / 100.0, *ph[q], (a[5] >> 20) / 100.0, *[x / 100.0 for x in hr],
+            (a[4] - a[3] - (a[5] >> 20) - sum(hr)) / 100.0))
