@@ -17,6 +17,10 @@
 #pragma once
 #include "g4r_device.cuh"
 
+#ifndef GT_KU
+#define GT_KU 8      // k-steps (of 4) per unrolled group of the MFMA loop
+#endif
+
 template <int BM, int BN, int BK, bool AKM, bool BNK>
 struct TileCfg {
     static constexpr int A_ROWS = AKM ? BK : BM, A_COLS = AKM ? BM : BK;
@@ -101,7 +105,7 @@ __device__ __forceinline__ void gemm_tile(int m0, int n0, int K, ALoad aload, BL
     float* sA = smem;
     float* sB = smem + C::A_ROWS * C::LDA;
     const int tid = threadIdx.x, lane = tid & 63, wid = (tid >> 6) & 3, li = lane & 15, lg = lane >> 4;
-    const int grp = (NTH == 512) ? (tid >> 8) : 0;
+    const int grp = (NTH == 512) ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;      // wave-uniform: keeps the K loop scalar
     constexpr int NT = BN / 16;
     f32x4 acc[C::NSUB];
     float4 pf[C::NSUB][4];
@@ -131,17 +135,32 @@ __device__ __forceinline__ void gemm_tile(int m0, int n0, int K, ALoad aload, BL
         }
         const int kend = min(BK, K - kk);
         hook(sA, kk, kend);
-        // this wave group's share of the chunk's k-steps
-        int kb = 0, ke = kend;
-        if (NTH == 512) { const int khalf = ((kend + 7) >> 3) << 2; if (grp) kb = khalf; else ke = khalf; }
-#pragma unroll 4
-        for (int k = kb; k < ke; k += 4) {
+        // The k-steps run in groups of GT_KU (fully unrolled: all fragment reads of a group are in flight before its first MFMA;
+        // a rolled loop waits out one LDS round trip per MFMA).  The chunk length is rounded up to whole groups: the staging
+        // tiles are zero-filled past K by the providers, so the extra steps add zeros.  NTH = 512: each wave group takes half
+        // of the groups.
+        constexpr int KG = 4 * GT_KU;
+        static_assert(BK % KG == 0, "K chunk must hold whole k-step groups");
+        const int kend_r = (kend + KG - 1) / KG * KG;
+        int kb = 0, ke = kend_r;
+        if (NTH == 512) { const int khalf = ((kend_r / KG + 1) >> 1) * KG; if (grp) kb = khalf; else ke = khalf; }
+        for (int k0 = kb; k0 < ke; k0 += KG) {
+            float af[GT_KU][C::NSUB], bf[GT_KU][C::NSUB];
 #pragma unroll
-            for (int q = 0; q < C::NSUB; ++q) {
-                const int s = wid * C::NSUB + q, ms = s / NT, ns = s % NT;
-                const float a = AKM ? sA[(k + lg) * C::LDA + ms * 16 + li] : sA[(ms * 16 + li) * C::LDA + k + lg];
-                const float b = BNK ? sB[(ns * 16 + li) * C::LDB + k + lg] : sB[(k + lg) * C::LDB + ns * 16 + li];
-                acc[q] = mfma16(a, b, acc[q]);
+            for (int u = 0; u < GT_KU; ++u) {
+                const int k = k0 + 4 * u;
+#pragma unroll
+                for (int q = 0; q < C::NSUB; ++q) {
+                    const int s = wid * C::NSUB + q, ms = s / NT, ns = s % NT;
+                    af[u][q] = AKM ? sA[(k + lg) * C::LDA + ms * 16 + li] : sA[(ms * 16 + li) * C::LDA + k + lg];
+                    bf[u][q] = BNK ? sB[(ns * 16 + li) * C::LDB + k + lg] : sB[(k + lg) * C::LDB + ns * 16 + li];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the reads above ahead of the MFMAs (the scheduler would sink them back)
+#pragma unroll
+            for (int u = 0; u < GT_KU; ++u) {
+#pragma unroll
+                for (int q = 0; q < C::NSUB; ++q) acc[q] = mfma16(af[u][q], bf[u][q], acc[q]);
             }
         }
         if (more) {
