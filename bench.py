@@ -41,6 +41,10 @@ CONFIGS = {
     'cfg4': dict(n_items=10000000, layers=[256], batch_size=512, n_sample=8192, loss='bpr-max', final_act='elu-0.5',
                  bpreg=1.0, learning_rate=0.1, momentum=0.0, sample_alpha=0.75, logq=0.0, dropout_p_embed=0.0,
                  dropout_p_hidden=0.0, constrained_embedding=True),
+    # diagnostic: the cfg4 step over a cache-resident catalogue (separates GEMM time from the cost of touching a 10 GB table)
+    'cfg4s': dict(n_items=100000, layers=[256], batch_size=512, n_sample=8192, loss='bpr-max', final_act='elu-0.5',
+                  bpreg=1.0, learning_rate=0.1, momentum=0.0, sample_alpha=0.75, logq=0.0, dropout_p_embed=0.0,
+                  dropout_p_hidden=0.0, constrained_embedding=True),
     # BASELINE.json configs[4]
     'cfg5': dict(n_items=37483, layers=[100, 100], batch_size=128, n_sample=2048, loss='top1-max', final_act='elu-0.5',
                  bpreg=1.0, learning_rate=0.1, momentum=0.0, sample_alpha=0.75, logq=0.0, dropout_p_embed=0.2,

@@ -135,8 +135,15 @@ static inline bool wide_layer(int D) { static const bool off = getenv("G4R_NARRO
 static const size_t SMEM_P1 = tile_smem<GT_BM, GT_BN, P1_BK, false, false>() + GT_BM * sizeof(int);
 static const size_t SMEM_BB = tile_smem<GT_BM, GT_BN, BB_BK, false, true>() + GT_BM * sizeof(int);
 static constexpr auto k_score_fwd_k128 = k_score_fwd<GT_BN, GT_BK>;
-static constexpr auto k_score_fwd_k64 = k_score_fwd<GT_BN, 64>;
-static const size_t SMEM_SF64 = tile_smem<SF_BM, GT_BN, 64, false, true>() + GT_BN * sizeof(int);
+// long score rows: 64-deep K chunks (more resident workgroups).  Measured at B = 512, N = 8704, D = 256 (us): 64 x 32 tiles
+// with K chunks of 64: 39.2, 64 x 64 / 64: 41.4, 64 x 64 / 128: 42.4, 64 x 64 / 32: 45.9 -- the tile shape is not what bounds it
+#define SFW_BN 32
+#define SFW_BK 64
+static constexpr auto k_score_fwd_k64 = k_score_fwd<SFW_BN, SFW_BK>;
+static const size_t SMEM_SF64 = tile_smem<SF_BM, SFW_BN, SFW_BK, false, true>() + SFW_BN * sizeof(int);
+static constexpr auto k_score_bwd_n = k_score_bwd<32, GT_BK>;
+static constexpr auto k_score_bwd_w = k_score_bwd<64, 64>;
+static const size_t SMEM_SBW = std::max(tile_smem<64, 64, 64, true, false>(), tile_smem<64, 64, 64, false, false>());
 static inline bool wide_scores(const DevModel& d) { static const bool off = getenv("G4R_NARROW_TILES") != nullptr; return !off && d.B >= 256 && d.ldSc >= 4096; }
 static const size_t SMEM_SF = tile_smem<SF_BM, GT_BN, GT_BK, false, true>() + GT_BN * sizeof(int);
 // publish the host descriptor to the device copy (stream-ordered; pageable source is staged before return)
@@ -264,10 +271,11 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         d.kch = GT_BK * std::max(1, (cdiv(d.ldSc, GT_BK) + 8) / 17);      // ~17 slabs whatever the number of negatives
         d.ksplit = cdiv(d.ldSc, d.kch);
         DA(d.dhpart, (size_t)d.ksplit * B * d.Dtop);
-        m->ndtA = cdiv(d.Dtop + 1, GT_BN);
-        m->nblkA = cdiv(d.ldSc, GT_BM) * m->ndtA;
-        m->ndtB = cdiv(d.Dtop, GT_BN);
-        m->nrtB = cdiv(B, GT_BM);
+        const int TB = wide_scores(d) ? 64 : 32;      // tile edge of k_score_bwd
+        m->ndtA = cdiv(d.Dtop + 1, TB);
+        m->nblkA = cdiv(d.ldSc, TB) * m->ndtA;
+        m->ndtB = cdiv(d.Dtop, TB);
+        m->nrtB = cdiv(B, TB);
         m->nblkB = d.ksplit * m->nrtB * m->ndtB;
         m->nblk_occ = cdiv(d.R, SP_WAVES);
         m->smem_sparse = (size_t)(((d.R + 255) & ~255) + 256) * sizeof(int) + (2 + 64) * SP_WAVES * sizeof(int) +
@@ -312,7 +320,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_p2, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_k128, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_k64, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd_n, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd_w, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_a, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_b, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_dense_grad, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -601,14 +610,15 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         end();
     }
     begin(KN_SCORE_FWD);
-    if (wide_scores(d)) LK(k_score_fwd_k64, dim3(cdiv(d.ldSc, GT_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF64, s, dmp, stp);
+    if (wide_scores(d)) LK(k_score_fwd_k64, dim3(cdiv(d.ldSc, SFW_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF64, s, dmp, stp);
     else LK(k_score_fwd_k128, dim3(cdiv(d.ldSc, GT_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF, s, dmp, stp);
     end();
     begin(KN_LOSS);
     LK(k_loss_rows, dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
     end();
     begin(KN_SCORE_BWD);
-    LK(k_score_bwd, dim3(m->nblkA + m->nblkB), dim3(GT_NTH), std::max(SMEM_TN, SMEM_NN) + (size_t)d.kch * sizeof(int), s, dmp, stp, m->nblkA, m->ndtA, m->ndtB, m->nrtB);
+    if (wide_scores(d)) LK(k_score_bwd_w, dim3(m->nblkA + m->nblkB), dim3(GT_NTH), SMEM_SBW + (size_t)d.kch * sizeof(int), s, dmp, stp, m->nblkA, m->ndtA, m->ndtB, m->nrtB);
+    else LK(k_score_bwd_n, dim3(m->nblkA + m->nblkB), dim3(GT_NTH), std::max(SMEM_TN, SMEM_NN) + (size_t)d.kch * sizeof(int), s, dmp, stp, m->nblkA, m->ndtA, m->ndtB, m->nrtB);
     end();
     for (int l = L - 1; l >= 0; --l) {
         begin(KN_BWD_PRE);

@@ -232,7 +232,9 @@ template __global__ void k_sparse_update_generic<2>(const DevModel*, StepState*,
 template __global__ void k_update<1>(const DevModel*, StepState*, const DenseTile*, int, int);
 template __global__ void k_update<2>(const DevModel*, StepState*, const DenseTile*, int, int);
 template __global__ void k_score_fwd<GT_BN, GT_BK>(const DevModel*, StepState*);
-template __global__ void k_score_fwd<GT_BN, 64>(const DevModel*, StepState*);
+template __global__ void k_score_fwd<32, 64>(const DevModel*, StepState*);
+template __global__ void k_score_bwd<32, GT_BK>(const DevModel*, StepState*, int, int, int, int);
+template __global__ void k_score_bwd<64, 64>(const DevModel*, StepState*, int, int, int, int);
 template __global__ void k_gru_p1<GT_BN, P1_BK>(const DevModel*, StepState*, int, int, int, GruFwdPredict);
 template __global__ void k_gru_p1<64, 256>(const DevModel*, StepState*, int, int, int, GruFwdPredict);
 template __global__ void k_score_all<32, false>(const DevModel*, const float*, int, const int*, long long, float*, long long, int, int*, long long);

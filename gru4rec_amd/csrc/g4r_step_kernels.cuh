@@ -527,6 +527,9 @@ __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict
 //          column d == D of the last d-tile carries a ones column of h, so it accumulates dSBy = colsum(ds).
 //   role B: split-K slabs of dh = ds * Sy: tile (32 rows b, 32 cols d) x one 128-wide chunk of score columns,
 //          B provider = gathered Wy rows of the chunk's columns.  Slabs are summed (fixed order) by k_gru_bwd_pre.
+// TB x TB output tiles, TBK-deep K chunks: 32 / 128 for the RSC15-sized step (more workgroups than CUs matter there),
+// 64 / 64 for long score rows and big batches (twice the flops per operand byte pulled from L2).
+template <int TB, int TBK>
 __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict__ mp, StepState* st, int nblkA, int ndtA, int ndtB, int nrtB) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
@@ -536,12 +539,12 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
     const GAS float* Sc = m.Sc;
     const GAS float* Wy = m.Wy;
     // column -> item map of the tile's score columns, staged in LDS (the gathers must not chain behind index loads)
-    int* sIt = reinterpret_cast<int*>(smem + max(TileCfg<GT_BM, GT_BN, GT_BK, true, false>::SMEM_FLOATS,
-                                                  TileCfg<GT_BM, GT_BN, GT_BK, false, false>::SMEM_FLOATS));
+    int* sIt = reinterpret_cast<int*>(smem + max(TileCfg<TB, TB, TBK, true, false>::SMEM_FLOATS,
+                                                  TileCfg<TB, TB, TBK, false, false>::SMEM_FLOATS));
     if ((int)blockIdx.x < nblkA) {
         const int nt = blockIdx.x / ndtA, dt = blockIdx.x - nt * ndtA;
-        const int n0 = nt * GT_BM, d0 = dt * GT_BN;
-        if (tid < GT_BM) sIt[tid] = (n0 + tid < N) ? m.col_item[n0 + tid] : -1;
+        const int n0 = nt * TB, d0 = dt * TB;
+        if (tid < TB) sIt[tid] = (n0 + tid < N) ? m.col_item[n0 + tid] : -1;
         __syncthreads();
         auto aload = [&](int kk, int r, int cc) -> float4 {      // staging tile [k = b][m = n]
             const int b = kk + r, n = n0 + cc;
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
         const float lr = m.lr;
         const bool generic = m.generic != 0;
         auto pre = [&](int n, int d) -> float4 {
-            const int item = (n - n0 < GT_BM) ? sIt[n - n0] : -1;
+            const int item = (n - n0 < TB) ? sIt[n - n0] : -1;
             const bool ok = item >= 0 && d <= D;
             const float a = (d < D) ? ldf_at(accWy, (size_t)max(item, 0) * D + d, ok) : ldf_at(accBy, max(item, 0), ok);
             return make_float4(a, ok ? 1.f : 0.f, 0.f, 0.f);
@@ -574,16 +577,16 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
             if (d < D) { dSy[(size_t)n * D + d] = step; dAy[(size_t)n * D + d] = an; }
             else { dSBy[n] = step; dABy[n] = an; }
         };
-        gemm_tile<GT_BM, GT_BN, GT_BK, true, false, GT_NTH>(n0, d0, M, aload, bload, pre, epi, smem);
+        gemm_tile<TB, TB, TBK, true, false, GT_NTH>(n0, d0, M, aload, bload, pre, epi, smem);
         return;
     }
     const int w = blockIdx.x - nblkA;
     const int per_kc = nrtB * ndtB;
     const int kc = w / per_kc, rem = w - kc * per_kc, rt = rem / ndtB, dt = rem - rt * ndtB;
-    // a slab covers kch = (multiple of GT_BK) score columns: long score rows (many negatives) use wider slabs so that the
+    // a slab covers kch = (multiple of TBK) score columns: long score rows (many negatives) use wider slabs so that the
     // number of split-K partials, and the traffic of writing and re-reading them, stays ~17 (host: d.kch)
     const int kch = m.kch;
-    const int m0 = rt * GT_BM, d0 = dt * GT_BN, kbeg = kc * kch;
+    const int m0 = rt * TB, d0 = dt * TB, kbeg = kc * kch;
     if (m0 >= M) return;
     for (int i = tid; i < kch; i += (int)blockDim.x) sIt[i] = (kbeg + i < ld) ? m.col_item[kbeg + i] : -1;
     __syncthreads();
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
     auto epi = [&](int b, int d, float v, float4) {
         if (b < M && d < D) dhpart[((size_t)kc * B + b) * D + d] = v;
     };
-    gemm_tile<GT_BM, GT_BN, GT_BK, false, false, GT_NTH>(m0, d0, min(kch, ld - kbeg), aload, bload, NoPre(), epi, smem);
+    gemm_tile<TB, TB, TBK, false, false, GT_NTH>(m0, d0, min(kch, ld - kbeg), aload, bload, NoPre(), epi, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
