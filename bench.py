@@ -70,6 +70,8 @@ def algorithmic_cost(cfg):
         'k_gru_bwd_pre': dict(bound='hbm', bytes=B * D * 4 * 6),
         'k_gru_bwd_a': dict(bound='mfma', flops=2.0 * B * D * D, bytes=B * D * 4 * 4 + D * D * 4),
         'k_gru_bwd_b': dict(bound='mfma', flops=2.0 * B * 3 * D * D, bytes=B * D * 4 * 4 + 3 * D * D * 4),
+        # the three stages above in one launch (stage 0 / 1 are repeated by the column tiles of a row block: not counted)
+        'k_gru_bwd': dict(bound='mfma', flops=2.0 * B * 4 * D * D, bytes=B * D * 4 * 10 + 4 * D * D * 4),
         'k_dense_grad': dict(bound='mfma', flops=2.0 * B * 6 * D * D, bytes=B * D * 4 * 6 + 3 * 6 * D * D * 4),
         # single GPU: dense-gradient tiles + sparse row update share one launch; its HBM-side work is the sparse
         # gather/scatter plus the dense parameters / accumulators read and written once

@@ -43,10 +43,10 @@ void g4r_set_error(const char* fmt, ...) {
     } while (0)
 
 enum { KN_GRU_P1 = 0, KN_GRU_P2, KN_SCORE_FWD, KN_LOSS, KN_SCORE_BWD, KN_BWD_PRE, KN_BWD_A, KN_BWD_B, KN_DENSE, KN_ALLREDUCE,
-       KN_DENSE_APPLY, KN_SPARSE, KN_UPDATE, KN_COUNT };
+       KN_DENSE_APPLY, KN_SPARSE, KN_UPDATE, KN_BWD_FUSED, KN_COUNT };
 static const char* KN_NAMES[KN_COUNT] = {"k_gru_p1", "k_gru_p2", "k_score_fwd", "k_loss_rows", "k_score_bwd", "k_gru_bwd_pre",
                                          "k_gru_bwd_a", "k_gru_bwd_b", "k_dense_grad", "rccl_allreduce", "k_dense_apply",
-                                         "k_sparse_update", "k_update"};
+                                         "k_sparse_update", "k_update", "k_gru_bwd"};
 
 struct EvRec { int kn; hipEvent_t a, b; };
 
@@ -131,6 +131,12 @@ static const size_t SMEM_TN = tile_smem<GT_BM, GT_BN, GT_BK, true, false>();    
 static constexpr auto k_gru_p1_n32 = k_gru_p1<GT_BN, P1_BK>;
 static constexpr auto k_gru_p1_n64 = k_gru_p1<64, 256>;
 static const size_t SMEM_P1_N64 = tile_smem<GT_BM, 64, 256, false, false>() + GT_BM * sizeof(int);
+// GRU backward in one launch (k_gru_bwd_fused) for layers whose operands fit its LDS plan
+static inline bool fused_bwd(const DevModel& d, int l) {
+    static const bool off = getenv("G4R_NO_FUSED_BWD") != nullptr;
+    return !off && d.D[l] <= BF_MAXD && d.D[l] % 4 == 0 && d.IN[l] % 4 == 0 && !(l == 0 && d.embed_mode == G4R_EMBED_ONEHOT);
+}
+static inline size_t smem_fused_bwd(int D) { return (size_t)((((BF_ROWS + 32) * (3 * D + 2) + D * (D + 2) + 32 + 3) & ~3) + 4 * 6 * 64) * sizeof(float); }
 static inline bool wide_layer(int D) { static const bool off = getenv("G4R_NARROW_TILES") != nullptr; return D >= 256 && !off; }
 static const size_t SMEM_P1 = tile_smem<GT_BM, GT_BN, P1_BK, false, false>() + GT_BM * sizeof(int);
 static const size_t SMEM_BB = tile_smem<GT_BM, GT_BN, BB_BK, false, true>() + GT_BM * sizeof(int);
@@ -268,7 +274,9 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     DA(d.st, 1);
     // scoring backward geometry: role A tiles (n x d, one spare d column for dSBy), role B tiles (b x d x k-chunk)
     {
-        d.kch = GT_BK * std::max(1, (cdiv(d.ldSc, GT_BK) + 8) / 17);      // ~17 slabs whatever the number of negatives
+        // k_gru_bwd_fused sums the slabs next to everything else it loads: half as many, twice as deep (k_score_bwd +0.4 us at cfg2)
+        const int slabs_target = getenv("G4R_KSLABS") ? atoi(getenv("G4R_KSLABS")) : (fused_bwd(d, d.n_layers - 1) ? 9 : 17);
+        d.kch = GT_BK * std::max(1, (cdiv(d.ldSc, GT_BK) + slabs_target / 2) / slabs_target);      // ~17 slabs whatever the number of negatives
         d.ksplit = cdiv(d.ldSc, d.kch);
         DA(d.dhpart, (size_t)d.ksplit * B * d.Dtop);
         const int TB = wide_scores(d) ? 64 : 32;      // tile edge of k_score_bwd
@@ -321,6 +329,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_k128, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_k64, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd_n, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd_w, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_a, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_b, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -621,6 +630,12 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     else LK(k_score_bwd_n, dim3(m->nblkA + m->nblkB), dim3(GT_NTH), std::max(SMEM_TN, SMEM_NN) + (size_t)d.kch * sizeof(int), s, dmp, stp, m->nblkA, m->ndtA, m->ndtB, m->nrtB);
     end();
     for (int l = L - 1; l >= 0; --l) {
+        if (fused_bwd(d, l)) {
+            begin(KN_BWD_FUSED);
+            LK(k_gru_bwd_fused, dim3(cdiv(d.IN[l], 32), cdiv(B, BF_ROWS)), dim3(512), smem_fused_bwd(d.D[l]), s, dmp, stp, l);
+            end();
+            continue;
+        }
         begin(KN_BWD_PRE);
         LK(k_gru_bwd_pre, dim3(cdiv((long long)B * d.D[l], 256)), dim3(256), 0, s, dmp, stp, l);
         end();

@@ -719,6 +719,243 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_bwd_b(const DevModel* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// GRU backward of one layer in ONE launch, for layers of up to BF_MAXD units: replaces k_gru_bwd_pre + k_gru_bwd_a +
+// k_gru_bwd_b (two dispatches less per layer and step).  One 8-wave workgroup per 16 x 32 tile of dy; everything it needs
+// is requested up front (one round trip), the three stages then hand their results over through LDS:
+//   stage 0  da = dh z act'(c), dz' = dh (c - H) z (1 - z) for the tile's 16 rows; dh = split-K slabs of k_score_bwd summed
+//            in fixed order (top layer) or the upper layer's dy, through the hidden-dropout mask
+//   stage 1  dr' = (da Wh^T) * H * r (1 - r), 16 rows x all D columns: one 16 x 16 sub-tile per wave (MFMA, Wh in LDS)
+//   stage 2  dy tile = [da | dr' | dz'] Wx^T: two sub-tiles x four quarters of K = 3D over the eight waves (MFMA), partial
+//            sums joined through LDS, epilogue of k_gru_bwd_b
+// dV = [da | dr' | dz'] goes to memory from column tile 0 (the dense-gradient tiles read it).  The column tiles of a row
+// block repeat stages 0 / 1 (a 16 x D x D product): cheaper than a launch boundary.  Thread -> element maps are powers of
+// two (no integer divisions; this kernel is bound by instruction issue on the few CUs it occupies).
+#define BF_MAXD 112
+#define BF_ROWS 16
+#define BF_SLB 10      // split-K slabs summed per batch of loads
+__global__ __launch_bounds__(512) void k_gru_bwd_fused(const DevModel* __restrict__ mp, StepState* st, int l) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevModel& m = *mp;
+    const StepCtx c = load_ctx(st);
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = c.M, B = m.B, D = m.D[l], IN = m.IN[l], D3 = 3 * D, Dq = D >> 2, D3q = D3 >> 2;
+    const int m0 = blockIdx.y * BF_ROWS, n0 = blockIdx.x * 32;
+    if (m0 >= M) return;
+    GAS long long* clk = (m.dbgclk && blockIdx.x == 1 && blockIdx.y == 1) ? m.dbgclk + 16 : nullptr;     // kernel 1 of tools/clk.py
+    if (clk && tid == 0) clk[0] = wall_clock64();
+    const int LDV = D3 + 2, LDW = D + 2;      // row strides with ld / 2 odd: MFMA fragment reads are conflict-free
+    float* sV = smem;                          // [16][LDV]   dV rows of the tile
+    float* sWh = sV + BF_ROWS * LDV;           // [D][LDW]    Wh[n][k]
+    float* sWx = sWh + D * LDW;                // [32][LDV]   Wx[n0 + n][k]
+    int* sRow = reinterpret_cast<int*>(sWx + 32 * LDV);
+    f32x4* sR = reinterpret_cast<f32x4*>(smem + ((BF_ROWS * LDV + D * LDW + 32 * LDV + 32 + 3) & ~3));     // [6][64] partial sums
+    const bool top = (l == m.n_layers - 1), writer = (blockIdx.x == 0);
+    const GAS float* Wh = m.dense_p + m.offWh[l];
+    const GAS float* Wx = m.dense_p + m.offWx[l];
+    const GAS float* Hcur = m.H[l][c.g & 1];
+    const GAS float *zl = m.z[l], *cl = m.c[l], *rl = m.r[l];
+    GAS float* dV = m.dV[l];
+    // ---- requests (clamped addresses, no branches in between)
+    int myrow = m.occ_idx[min(m0 + (tid & 15), M - 1)];
+    if (!(l == 0 && m0 + (tid & 15) < M)) myrow = -1;
+    // Wh: 16 rows per pass, one quad of k per thread (32 quad slots per row, Dq <= 28 used)
+    constexpr int NP_WH = (BF_MAXD + 15) / 16, NP_WX = (3 * BF_MAXD / 4 + 15) / 16;
+    const int wr = tid >> 5, wq = min(tid & 31, Dq - 1);
+    float4 wh[NP_WH], wx[NP_WX];
+#pragma unroll
+    for (int p = 0; p < NP_WH; ++p) wh[p] = ld4(Wh + (size_t)min(wr + 16 * p, D - 1) * D + 4 * wq);
+    // Wx rows of the tile: 32 rows x 16 quad slots per pass
+    const int xr = tid >> 4, xq = tid & 15;
+    const GAS float* wxrow = Wx + (size_t)min(n0 + xr, IN - 1) * D3;
+#pragma unroll
+    for (int p = 0; p < NP_WX; ++p) wx[p] = ld4(wxrow + 4 * min(xq + 16 * p, D3q - 1));
+    // stage-0 operands: 16 rows x 32 quad slots
+    const int r0 = tid >> 5, q0 = tid & 31;
+    const bool act0 = q0 < Dq;
+    const size_t off0 = (size_t)min(m0 + r0, M - 1) * D + 4 * min(q0, Dq - 1);
+    const int ks = top ? m.ksplit : 1;
+    const GAS float* dsrc = (top ? m.dhpart : m.dyl[l]) + off0;
+    const size_t ps = (size_t)B * D;
+    const float4 h4 = ld4(Hcur + off0), z4 = ld4(zl + off0), c4 = ld4(cl + off0);
+    float4 g4[BF_SLB];
+    {
+        const GAS float* pp = dsrc;
+#pragma unroll
+        for (int q = 0; q < BF_SLB; ++q) {      // slots past the last slab re-read it (weight 0 below)
+            g4[q] = ld4(pp);
+            if (q + 1 < ks) pp += ps;
+        }
+    }
+    // stage-1 epilogue operands: r and H at this wave's sub-tile of dr' (columns 16 wid ..)
+    const int NT1 = (D + 15) >> 4;
+    float r1[4], h1[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const int row = m0 + 4 * lg + rg, n = wid * 16 + li;
+        const bool ok = row < M && n < D;
+        r1[rg] = ldf_at(rl, (size_t)row * D + n, ok);
+        h1[rg] = ldf_at(Hcur, (size_t)row * D + n, ok);
+    }
+    if (clk && tid == 0) clk[1] = wall_clock64();
+    // ---- Wh / Wx to LDS (row stride == 2 mod 4: 8-byte stores)
+    if (tid < BF_ROWS) sRow[tid] = myrow;
+#pragma unroll
+    for (int p = 0; p < NP_WH; ++p) {
+        const int n = wr + 16 * p;
+        if (n < D && (tid & 31) < Dq) {
+            float2* d = reinterpret_cast<float2*>(sWh + n * LDW + 4 * wq);
+            d[0] = make_float2(wh[p].x, wh[p].y); d[1] = make_float2(wh[p].z, wh[p].w);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NP_WX; ++p) {
+        const int k4 = xq + 16 * p;
+        if (k4 < D3q) {
+            const bool ok = n0 + xr < IN;
+            float2* d = reinterpret_cast<float2*>(sWx + xr * LDV + 4 * k4);
+            d[0] = ok ? make_float2(wx[p].x, wx[p].y) : make_float2(0.f, 0.f);
+            d[1] = ok ? make_float2(wx[p].z, wx[p].w) : make_float2(0.f, 0.f);
+        }
+    }
+    if (clk && tid == 0) clk[2] = wall_clock64();
+    // ---- stage 0
+    const float drop_h = m.drop_h, hp0 = m.ha_p0, hp1 = m.ha_p1;
+    const int hact = m.hidden_act;
+    const unsigned long long seed = m.seed;
+    {
+        const int row = m0 + r0;
+        float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < BF_SLB; ++q) {      // fixed summation order
+            const float w = (q < ks) ? 1.f : 0.f;
+            dh.x = fmaf(w, g4[q].x, dh.x); dh.y = fmaf(w, g4[q].y, dh.y); dh.z = fmaf(w, g4[q].z, dh.z); dh.w = fmaf(w, g4[q].w, dh.w);
+        }
+        for (int k0 = BF_SLB; k0 < ks; k0 += BF_SLB) {      // more slabs than one batch holds (rare)
+            float4 v[BF_SLB];
+#pragma unroll
+            for (int q = 0; q < BF_SLB; ++q) v[q] = ld4(dsrc + (size_t)min(k0 + q, ks - 1) * ps);
+#pragma unroll
+            for (int q = 0; q < BF_SLB; ++q) {
+                const float w = (k0 + q < ks) ? 1.f : 0.f;
+                dh.x = fmaf(w, v[q].x, dh.x); dh.y = fmaf(w, v[q].y, dh.y); dh.z = fmaf(w, v[q].z, dh.z); dh.w = fmaf(w, v[q].w, dh.w);
+            }
+        }
+        if (act0) {
+            const bool ok = row < M;
+            if (drop_h > 0.f) {
+                const float4 mk = drop_mult4(seed, (unsigned)c.g, G4R_STREAM_DROP_HIDDEN + l, row, q0, 1.0f - drop_h);
+                dh.x *= mk.x; dh.y *= mk.y; dh.z *= mk.z; dh.w *= mk.w;
+            }
+            const float hh[4] = {h4.x, h4.y, h4.z, h4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w};
+            const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, dd[4] = {dh.x, dh.y, dh.z, dh.w};
+            float da[4], dzp[4], ad[4];
+            if (hact == G4R_ACT_TANH) {      // the default, kept out of the per-element switch
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ad[j] = 1.0f - cc[j] * cc[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ad[j] = act_bwd_from_out(hact, hp0, hp1, cc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dz = dd[j] * (cc[j] - hh[j]), dc = dd[j] * zz[j];
+                da[j] = ok ? dc * ad[j] : 0.f;
+                dzp[j] = ok ? dz * zz[j] * (1.f - zz[j]) : 0.f;
+            }
+            float2* pa = reinterpret_cast<float2*>(sV + r0 * LDV + 4 * q0);
+            float2* pz = reinterpret_cast<float2*>(sV + r0 * LDV + 2 * D + 4 * q0);
+            pa[0] = make_float2(da[0], da[1]); pa[1] = make_float2(da[2], da[3]);
+            pz[0] = make_float2(dzp[0], dzp[1]); pz[1] = make_float2(dzp[2], dzp[3]);
+            if (writer && ok) {
+                st4(dV + (size_t)row * D3 + 4 * q0, make_float4(da[0], da[1], da[2], da[3]));
+                st4(dV + (size_t)row * D3 + 2 * D + 4 * q0, make_float4(dzp[0], dzp[1], dzp[2], dzp[3]));
+            }
+        }
+    }
+    if (clk && tid == 0) clk[3] = wall_clock64();
+    __syncthreads();
+    if (clk && tid == 0) clk[4] = wall_clock64();
+    // stage-2 epilogue operands (waves 0, 1): pre-step accumulator of the input item's row, layer 0 (as k_gru_bwd_b)
+    const GAS float* accT = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.accWy : m.accE;
+    const int ns2 = wid & 1, kq = wid >> 1;
+    float a2[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const int item = sRow[4 * lg + rg], n = n0 + ns2 * 16 + li;
+        a2[rg] = ldf_at(accT, (size_t)max(item, 0) * IN + n, item >= 0 && n < IN);
+    }
+    // k-steps in fully unrolled groups of 8 (all fragment reads ahead of the MFMAs); steps past kend read on inside the
+    // workgroup's LDS and are replaced by zeros
+    auto mma = [&](f32x4 acc, const float* pa, const float* pb, int kbeg, int kend) -> f32x4 {
+        for (int k0 = kbeg; k0 < kend; k0 += 32) {
+            float af[8], bf[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 4 * u;
+                const float a = pa[k], b = pb[k];
+                af[u] = (k < kend) ? a : 0.f;
+                bf[u] = (k < kend) ? b : 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = mfma16(af[u], bf[u], acc);
+        }
+        return acc;
+    };
+    // ---- stage 1: dr' for the tile's rows, sub-tile `wid`
+    if (wid < NT1) {      // wave-uniform
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc = mma(acc, sV + li * LDV + lg, sWh + (wid * 16 + li) * LDW + lg, 0, D);
+        const int n = wid * 16 + li;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int r = 4 * lg + rg, row = m0 + r;
+            const float v = acc[rg] * h1[rg] * r1[rg] * (1.f - r1[rg]);
+            if (n < D) {
+                sV[r * LDV + D + n] = (row < M) ? v : 0.f;
+                if (writer && row < M) dV[(size_t)row * D3 + D + n] = v;
+            }
+        }
+    }
+    if (clk && tid == 0) clk[5] = wall_clock64();
+    __syncthreads();
+    if (clk && tid == 0) clk[6] = wall_clock64();
+    // ---- stage 2: the dy tile; wave w: sub-tile (w & 1), quarter (w >> 1) of K = 3D
+    const int kquart = ((D3q + 3) >> 2) << 2;
+    f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc2 = mma(acc2, sV + li * LDV + lg, sWx + (ns2 * 16 + li) * LDV + lg, kq * kquart, min(D3, (kq + 1) * kquart));
+    if (clk && tid == 0) clk[7] = wall_clock64();
+    if (kq) sR[(wid - 2) * 64 + lane] = acc2;
+    __syncthreads();
+    if (kq) return;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {      // quarters 1..3 in order
+        const f32x4 o = sR[(2 * j + ns2) * 64 + lane];
+        acc2[0] += o[0]; acc2[1] += o[1]; acc2[2] += o[2]; acc2[3] += o[3];
+    }
+    const float lr = m.lr, drop_e = m.drop_e;
+    const bool generic = m.generic != 0;
+    GAS float *dSx = m.dSx, *dAx = m.dAx, *dylo = (l > 0) ? m.dyl[l - 1] : nullptr;
+    const int n = n0 + ns2 * 16 + li;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const int row = m0 + 4 * lg + rg;
+        if (row >= M || n >= IN) continue;
+        float v = acc2[rg];
+        if (l == 0) {
+            if (drop_e > 0.f) v *= drop_mult(seed, (unsigned)c.g, G4R_STREAM_DROP_EMBED, row, n, 1.0f - drop_e);
+            const float an = a2[rg] + v * v;
+            dSx[(size_t)row * IN + n] = generic ? v : lr * v * frsq(an + G4R_EPS_ADAGRAD);
+            dAx[(size_t)row * IN + n] = an;
+        } else {
+            dylo[(size_t)row * IN + n] = v;
+        }
+    }
+    if (clk && tid == 0) clk[8] = wall_clock64();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Dense gradients: contractions over the batch, one wave per 16x16 output tile of
 //   dWx = yin^T dV ; dWh = (H r)^T dV[:, :D] ; dWrz = H^T dV[:, D:] ; dBh = colsum(dV)
 // with the dense Adagrad(+momentum) update (gru4rec.py:330-334,390-406) fused into the epilogue when
