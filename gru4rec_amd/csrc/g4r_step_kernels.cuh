@@ -171,9 +171,9 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_p1(const DevModel* __restric
         if (!pub) return;
         constexpr int LDA = TileCfg<GT_BM, TBN, TBK, false, false>::LDA;
         const int kmax = min(kend, IN - kk);          // columns of this chunk that belong to y
-        for (int e = tid; e < GT_BM * kmax; e += GT_NTH_FEW) {
-            const int r = e / kmax, k = e - r * kmax;
-            if (m0 + r < M) yin0[(size_t)(m0 + r) * IN + kk + k] = sA[r * LDA + k];
+        const int r = tid >> 4;                       // 32 rows x 16 column slots per pass (no integer division)
+        if (m0 + r < M) {
+            for (int k = tid & 15; k < kmax; k += 16) yin0[(size_t)(m0 + r) * IN + kk + k] = sA[r * LDA + k];
         }
     };
     gemm_tile<GT_BM, TBN, TBK, false, false, GT_NTH_FEW>(m0, n0, K, aload, bload, pre, epi, smem, clk, hook, afix, bfix);
