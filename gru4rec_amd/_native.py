@@ -163,7 +163,10 @@ def load_events(path, session_col, item_col, time_col=None, threads=0):
                                _i64(off), raw))
     finally:
         L.g4r_events_free(h)
-    blob = raw.raw[:nb].decode('utf-8')
+    try:
+        blob = raw.raw[:nb].decode('utf-8')
+    except UnicodeDecodeError:
+        return None      # item ids in another encoding: pandas' reader decides how to read them
     lo = off.tolist()
     if len(blob) == nb:      # pure ASCII: byte offsets are character offsets
         ids = [blob[lo[i]:lo[i + 1]] for i in range(k)]

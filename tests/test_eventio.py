@@ -170,3 +170,10 @@ def test_prepare_host_products_equal_reference_expressions(tmp_path):
     offs = datatools.compute_offset(data, 'SessionId')
     start_ref = ref.groupby('SessionId')['Time'].min().values                          # gru4rec.py:585
     assert np.array_equal(data['Time'].values[offs[:-1]], start_ref)
+
+
+def test_non_utf8_item_ids_are_left_to_pandas(tmp_path):
+    path = str(tmp_path / 'e.tsv')
+    with open(path, 'wb') as fh:
+        fh.write(b'SessionId\tItemId\tTime\n1\tcaf\xe9\t1\n1\tb\t2\n')
+    assert _native.load_events(path, 'SessionId', 'ItemId', 'Time') is None

@@ -364,6 +364,24 @@ def test_many_negatives_big_batch():
     assert not errs, errs
 
 
+def test_more_split_k_slabs_than_one_batch():
+    """B + n_sample = 1632 -> 13 score chunks of 128 -> 13 split-K slabs of dh: k_gru_bwd_fused sums them in two batches
+    (its first batch holds 10), in the same fixed order."""
+    I, B, ns, T = 900, 32, 1600, 3
+    o, m = make_pair(I, B, ns, store_rows=5, loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(24,),
+                     learning_rate=0.05, momentum=0.1, dropout_p_hidden=0.2)
+    assert int(m.get_debug('ksplit', (1,))[0]) == 13
+    plan = random_plan(I, B, T, seed=31)
+    m.set_plan(plan)
+    want = [o.train_step(plan['in_idx'][t], plan['out_idx'][t], B, plan['reset'][t]) for t in range(T)]
+    m.train_steps(0, T)
+    errs = []
+    report('--- 13 slabs')
+    close('loss curve', m.get_losses(0, T), np.array(want), atol=5e-6, rtol=5e-4, errs=errs)
+    compare_params(o, m, errs, 'slabs13', atol=1e-4, rtol=2e-3)
+    assert not errs, errs
+
+
 @pytest.mark.parametrize('name', ['bprmax_elu', 'xe_softmax_logq', 'top1max_2layer', 'xe_sep_embed', 'xelogit_smooth', 'onehot_bprmax'])
 def test_predict_and_ranks(name):
     kw = CASES[name]
