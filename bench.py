@@ -67,6 +67,8 @@ def algorithmic_cost(cfg):
         'k_loss_rows': dict(bound='hbm', bytes=2 * B * N * 4),
         'k_gru_p1': dict(bound='mfma', flops=2.0 * B * 5 * D * D, bytes=B * D * 4 * 6 + 5 * D * D * 4),
         'k_gru_p2': dict(bound='mfma', flops=2.0 * B * D * D, bytes=B * D * 4 * 6 + D * D * 4),
+        # k_gru_p1 + k_gru_p2 in one launch (r for all D columns is recomputed by the column tiles of a row block: not counted)
+        'k_gru_fwd': dict(bound='mfma', flops=2.0 * B * 6 * D * D, bytes=B * D * 4 * 10 + 6 * D * D * 4),
         'k_gru_bwd_pre': dict(bound='hbm', bytes=B * D * 4 * 6),
         'k_gru_bwd_a': dict(bound='mfma', flops=2.0 * B * D * D, bytes=B * D * 4 * 4 + D * D * 4),
         'k_gru_bwd_b': dict(bound='mfma', flops=2.0 * B * 3 * D * D, bytes=B * D * 4 * 4 + 3 * D * D * 4),

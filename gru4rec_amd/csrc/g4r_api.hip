@@ -43,10 +43,10 @@ void g4r_set_error(const char* fmt, ...) {
     } while (0)
 
 enum { KN_GRU_P1 = 0, KN_GRU_P2, KN_SCORE_FWD, KN_LOSS, KN_SCORE_BWD, KN_BWD_PRE, KN_BWD_A, KN_BWD_B, KN_DENSE, KN_ALLREDUCE,
-       KN_DENSE_APPLY, KN_SPARSE, KN_UPDATE, KN_BWD_FUSED, KN_COUNT };
+       KN_DENSE_APPLY, KN_SPARSE, KN_UPDATE, KN_BWD_FUSED, KN_FWD_FUSED, KN_COUNT };
 static const char* KN_NAMES[KN_COUNT] = {"k_gru_p1", "k_gru_p2", "k_score_fwd", "k_loss_rows", "k_score_bwd", "k_gru_bwd_pre",
                                          "k_gru_bwd_a", "k_gru_bwd_b", "k_dense_grad", "rccl_allreduce", "k_dense_apply",
-                                         "k_sparse_update", "k_update", "k_gru_bwd"};
+                                         "k_sparse_update", "k_update", "k_gru_bwd", "k_gru_fwd"};
 
 struct EvRec { int kn; hipEvent_t a, b; };
 
@@ -135,6 +135,12 @@ static const size_t SMEM_P1_N64 = tile_smem<GT_BM, 64, 256, false, false>() + GT
 static inline bool fused_bwd(const DevModel& d, int l) {
     static const bool off = getenv("G4R_NO_FUSED_BWD") != nullptr;
     return !off && d.D[l] <= BF_MAXD && d.D[l] % 4 == 0 && d.IN[l] % 4 == 0 && !(l == 0 && d.embed_mode == G4R_EMBED_ONEHOT);
+}
+// GRU forward in one launch (k_gru_fwd_fused) for layers whose weights fit its LDS plan (in + D up to ~200)
+static inline bool fused_fwd(const DevModel& d, int l) {
+    static const bool off = getenv("G4R_NO_FUSED_FWD") != nullptr;
+    return !off && d.D[l] <= FF_LDR && d.IN[l] <= FF_LDR && d.D[l] % 4 == 0 && d.IN[l] % 4 == 0 && d.IN[l] >= 4 &&      // its load maps cover 112 rows / columns
+           !(l == 0 && d.embed_mode == G4R_EMBED_ONEHOT) && (size_t)fwd_fused_lds(d.IN[l], d.D[l]).total * sizeof(float) <= 156 * 1024;
 }
 static inline size_t smem_fused_bwd(int D) { return (size_t)((((BF_ROWS + 32) * (3 * D + 2) + D * (D + 2) + 32 + 3) & ~3) + 4 * 6 * 64) * sizeof(float); }
 static inline bool wide_layer(int D) { static const bool off = getenv("G4R_NARROW_TILES") != nullptr; return D >= 256 && !off; }
@@ -330,6 +336,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_k64, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd_n, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gru_fwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd_w, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_a, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_b, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -610,6 +617,12 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     bool merged = false;      // the sparse update already ran inside k_update
     if (part != 2) {
     for (int l = 0; l < L; ++l) {
+        if (fused_fwd(d, l)) {
+            begin(KN_FWD_FUSED);
+            LK(k_gru_fwd_fused, dim3(cdiv(d.D[l], 32), cdiv(B, FF_ROWS)), dim3(512), (size_t)fwd_fused_lds(d.IN[l], d.D[l]).total * sizeof(float), s, dmp, stp, l, l == 0 ? 1 : 0);
+            end();
+            continue;
+        }
         begin(KN_GRU_P1);
         if (wide_layer(d.D[l])) LK(k_gru_p1_n64, dim3(cdiv(3 * d.D[l], 64), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1_N64, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
         else LK(k_gru_p1_n32, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);

@@ -239,6 +239,267 @@ __global__ __launch_bounds__(GT_NTH) void k_gru_p2(const DevModel* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// GRU forward of one layer in ONE launch (training, layers whose operands fit the LDS plan below: in + D <= ~200): replaces
+// k_gru_p1 + k_gru_p2.  One 8-wave workgroup per 16 rows x 32 output columns.  The candidate needs (H * r) Wh over ALL D
+// columns, so every column tile computes r for all D columns of its rows (a 16 x D x (in + D) product, repeated by the four
+// column tiles of a row block: cheaper than a launch boundary), z and the candidate's input part only for its own 32 columns:
+//   stage A1  K = input part (k < in):  V_r (D cols), V_z (32), V_c (32)      operands [y | H] rows, Wx column blocks in LDS
+//   stage A2  K = hidden part:          V_r, V_z += H * Wrz                   (the V_r weight buffer is reused)
+//   epilogue  r = sigmoid, Hr = H r -> LDS (+ memory for the tile's own columns); z, V_c -> LDS
+//   stage B   (H r) Wh for the 32 columns (two sub-tiles x four quarters of K over the eight waves), joined through LDS
+//   epilogue  c = act(.), h = (1 - z) H + z c, hidden dropout, reset switch -> H_next; saves c, hd   (gru4rec.py:471-479)
+// Layer 0 gathers its input rows (+ embedding dropout), publishes them (yin0) and the X part of occ_idx / occ_fl, and copies
+// the step state, exactly as k_gru_p1 does.  B operands are kept [k][n] with row strides == 16 mod 32 (conflict-free reads).
+#define FF_ROWS 16
+#define FF_LDR 112      // row stride of the V_r weight buffer (D <= 112)
+#define FF_LDT 48       // row stride of the 32-column weight tiles
+struct FwdFusedLds {     // float offsets of the LDS plan
+    int sA, sWr, sWz, sWc, sWh, sHr, sZ, sVc, sRow, sJoin, total;
+    int LDA, LDH;
+};
+__host__ __device__ inline FwdFusedLds fwd_fused_lds(int IN, int D) {
+    FwdFusedLds o;
+    const int KA = IN + D, rk = IN > D ? IN : D;
+    o.LDA = KA + 2; o.LDH = D + 2;
+    o.sA = 0;
+    o.sWr = o.sA + FF_ROWS * o.LDA;
+    o.sWz = o.sWr + rk * FF_LDR;
+    o.sWc = o.sWz + KA * FF_LDT;
+    o.sWh = o.sWc + IN * FF_LDT;
+    o.sHr = o.sWh + D * FF_LDT;
+    o.sZ = o.sHr + FF_ROWS * o.LDH;
+    o.sVc = o.sZ + FF_ROWS * 33;
+    o.sRow = o.sVc + FF_ROWS * 33;
+    o.sJoin = (o.sRow + FF_ROWS + 3) & ~3;          // [6][64] f32x4 partial sums of stage B
+    o.total = o.sJoin + 6 * 64 * 4;
+    return o;
+}
+__global__ __launch_bounds__(512) void k_gru_fwd_fused(const DevModel* __restrict__ mp, StepState* st, int l, int first) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevModel& m = *mp;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = m.D[l], IN = m.IN[l], D3 = 3 * D, D2 = 2 * D, KA = IN + D, Dq = D >> 2, INq = IN >> 2;
+    const StepCtx c = first ? load_ctx_first(st) : load_ctx(st);
+    const long long t = c.t, g = c.g;
+    const int M = c.M, B = m.B;
+    const int m0 = blockIdx.y * FF_ROWS, n0 = blockIdx.x * 32;
+    const FwdFusedLds L = fwd_fused_lds(IN, D);
+    float* sA = smem + L.sA;       // [16][LDA]   [y | H] rows
+    float* sWr = smem + L.sWr;     // [max(in, D)][FF_LDR]   Wx[:, D:2D], then Wrz[:, 0:D]
+    float* sWz = smem + L.sWz;     // [in + D][FF_LDT]       [Wx[:, 2D + n0 ..] ; Wrz[:, D + n0 ..]]
+    float* sWc = smem + L.sWc;     // [in][FF_LDT]           Wx[:, n0 ..]
+    float* sWh = smem + L.sWh;     // [D][FF_LDT]            Wh[:, n0 ..]
+    float* sHr = smem + L.sHr;     // [16][LDH]
+    float* sZ = smem + L.sZ;       // [16][33]
+    float* sVc = smem + L.sVc;     // [16][33]
+    int* sRow = reinterpret_cast<int*>(smem + L.sRow);
+    f32x4* sJ = reinterpret_cast<f32x4*>(smem + L.sJoin);
+    const int LDA = L.LDA, LDH = L.LDH;
+    const GAS float* Hcur = m.H[l][g & 1];
+    GAS long long* clk = (m.dbgclk && blockIdx.x == 1 && blockIdx.y == 1) ? m.dbgclk + 0 : nullptr;      // kernel 0 of tools/clk.py
+    if (clk && tid == 0) clk[0] = wall_clock64();
+    // ---- row items first (the gathers wait for them), then everything that does not depend on them
+    const int rrow = m0 + (tid & 15);
+    int item = (l == 0) ? m.in_idx[t * B + min(rrow, B - 1)] : 0;
+    if (!(l == 0 && rrow < M)) item = -1;
+    const GAS float* Wx = m.dense_p + m.offWx[l];
+    const GAS float* Wrz = m.dense_p + m.offWrz[l];
+    const GAS float* Wh = m.dense_p + m.offWh[l];
+    const GAS float* Bh = m.dense_p + m.offBh[l];
+    // V_r weights: 16 rows of k per pass, one quad of n per thread (32 quad slots, Dq <= 28 used)
+    constexpr int NP_R = 7;
+    const int kr = tid >> 5, nq = min(tid & 31, Dq - 1);
+    float4 wr1[NP_R], wr2[NP_R];
+#pragma unroll
+    for (int p = 0; p < NP_R; ++p) {
+        wr1[p] = ld4(Wx + (size_t)min(kr + 16 * p, IN - 1) * D3 + D + 4 * nq);
+        wr2[p] = ld4(Wrz + (size_t)min(kr + 16 * p, D - 1) * D2 + 4 * nq);
+    }
+    // 32-column tiles: 64 rows of k per pass, 8 quads per row; columns past the matrix edge are clamped and zeroed at commit
+    const int kt = tid >> 3, tq = tid & 7;
+    const int nz = min(n0 + 4 * tq, D - 4);
+    float4 wzx[2], wzh[2], wcx[2], whh[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        wzx[p] = ld4(Wx + (size_t)min(kt + 64 * p, IN - 1) * D3 + D2 + nz);
+        wcx[p] = ld4(Wx + (size_t)min(kt + 64 * p, IN - 1) * D3 + nz);
+        wzh[p] = ld4(Wrz + (size_t)min(kt + 64 * p, D - 1) * D2 + D + nz);
+        whh[p] = ld4(Wh + (size_t)min(kt + 64 * p, D - 1) * D + nz);
+    }
+    // hidden part of the A rows: 16 rows x 32 quad slots
+    const int ar = tid >> 5, aq = tid & 31;
+    const int arow = min(m0 + ar, M - 1);
+    const float4 ah = ld4(Hcur + (size_t)max(arow, 0) * D + 4 * min(aq, Dq - 1));
+    // epilogue operands of this wave's sub-tiles: biases of the r columns (16 wid + li), of the tile's z / c columns
+    const int nr = wid * 16 + li;
+    const float b_r = ldf_at(Bh, D + nr, nr < D);
+    const int nt = n0 + (wid & 1) * 16 + li;
+    const float b_z = ldf_at(Bh, D2 + nt, nt < D), b_c = ldf_at(Bh, nt, nt < D);
+    unsigned rst4 = 0;      // reset flags of rows 4 lg .. 4 lg + 3 (stage-B epilogue: waves 0 and 1)
+    if (wid < 2) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) rst4 |= (unsigned)m.reset[t * B + min(m0 + 4 * lg + rg, B - 1)] << (8 * rg);
+    }
+    if (clk && tid == 0) clk[1] = wall_clock64();
+    if (tid < FF_ROWS) {
+        sRow[tid] = item;
+        if (l == 0 && blockIdx.x == 0 && rrow < B) {
+            m.occ_idx[rrow] = item;
+            if (item >= 0) {      // first / last occurrence of the item in this step's gathered-row list (k_update)
+                int* fl = (int*)m.occ_fl + 4 * ((m.embed_mode == G4R_EMBED_CONSTRAINED ? 0 : (size_t)m.n_items) + item);
+                atomicMax(fl, rrow + 1);
+                atomicMax(fl + 1, m.R - rrow);
+                atomicAdd(fl + 2, 1);
+            }
+        }
+    }
+    if (m0 >= M) return;
+    // ---- everything that does not wait for the gather goes to LDS now ([k][n] tiles, 16-byte stores): the hidden-part
+    // weights of V_r (the input part follows into the same buffer after stage A1), the 32-column tiles, the H part of the rows
+#pragma unroll
+    for (int p = 0; p < NP_R; ++p) {
+        const int k = kr + 16 * p;
+        if (k < D && (tid & 31) < Dq) st4(sWr + k * FF_LDR + 4 * nq, wr2[p]);
+    }
+    const bool tz = n0 + 4 * tq < D;      // D % 4 == 0: a quad is inside or outside as a whole
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int k = kt + 64 * p;
+        if (k < IN) {
+            st4(sWz + k * FF_LDT + 4 * tq, tz ? wzx[p] : zero4);
+            st4(sWc + k * FF_LDT + 4 * tq, tz ? wcx[p] : zero4);
+        }
+        if (k < D) {
+            st4(sWz + (IN + k) * FF_LDT + 4 * tq, tz ? wzh[p] : zero4);
+            st4(sWh + k * FF_LDT + 4 * tq, tz ? whh[p] : zero4);
+        }
+    }
+    const bool arow_ok = m0 + ar < M;      // rows past the batch are zero
+    if (aq < Dq) {      // row stride == 2 mod 4: 8-byte stores
+        float2* d = reinterpret_cast<float2*>(sA + ar * LDA + IN + 4 * aq);
+        d[0] = arow_ok ? make_float2(ah.x, ah.y) : make_float2(0.f, 0.f);
+        d[1] = arow_ok ? make_float2(ah.z, ah.w) : make_float2(0.f, 0.f);
+    }
+    if (clk && tid == 0) clk[2] = wall_clock64();
+    __syncthreads();
+    if (clk && tid == 0) clk[3] = wall_clock64();
+    // input part of the A rows: gathered table rows (layer 0) or the lower layer's output; in flight during stage A1
+    const GAS float* table = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.Wy : m.E;
+    const GAS float* ysrc = (l == 0) ? table + (size_t)max(sRow[ar], 0) * IN : m.hd[l - 1] + (size_t)max(arow, 0) * IN;
+    float4 ay = ld4(ysrc + 4 * min(aq, INq - 1));
+    // k-steps in fully unrolled groups of 8 (fragment reads ahead of the MFMAs), single steps for the remainder
+    auto mma = [&](f32x4 acc, const float* pa, const float* pb, int ldb, int nk) -> f32x4 {      // pa[k], pb[k * ldb], k = 0, 4, .. < nk
+        int k0 = 0;
+        for (; k0 + 32 <= nk; k0 += 32) {
+            float af[8], bf[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { af[u] = pa[k0 + 4 * u]; bf[u] = pb[(k0 + 4 * u) * ldb]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = mfma16(af[u], bf[u], acc);
+        }
+        for (; k0 < nk; k0 += 4) acc = mfma16(pa[k0], pb[k0 * ldb], acc);
+        return acc;
+    };
+    // ---- stage A.  Wave w < NT1 owns r sub-tile w; the z / c sub-tiles of the tile go to the waves 7, 6 (z) and 5, 4 (c).
+    // A1: K = hidden part (needs nothing from the gather), A2: K = input part
+    const int NT1 = (D + 15) >> 4;
+    const float* paA = sA + li * LDA + lg;
+    f32x4 accR = (f32x4){0.f, 0.f, 0.f, 0.f}, accT = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool doZ = wid >= 6, doC = (wid == 4 || wid == 5);
+    const int tsub = wid & 1;
+    if (wid < NT1) accR = mma(accR, paA + IN, sWr + lg * FF_LDR + wid * 16 + li, FF_LDR, D);
+    if (doZ) accT = mma(accT, paA + IN, sWz + (IN + lg) * FF_LDT + tsub * 16 + li, FF_LDT, D);
+    if (clk && tid == 0) clk[4] = wall_clock64();
+    __syncthreads();
+    if (clk && tid == 0) clk[5] = wall_clock64();
+#pragma unroll
+    for (int p = 0; p < NP_R; ++p) {      // input part of the V_r weights into the same buffer
+        const int k = kr + 16 * p;
+        if (k < IN && (tid & 31) < Dq) st4(sWr + k * FF_LDR + 4 * nq, wr1[p]);
+    }
+    if (aq < INq) {
+        if (l == 0 && m.drop_e > 0.f) {
+            const float4 mk = drop_mult4(m.seed, (unsigned)g, G4R_STREAM_DROP_EMBED, m0 + ar, aq, 1.0f - m.drop_e);
+            ay.x *= mk.x; ay.y *= mk.y; ay.z *= mk.z; ay.w *= mk.w;
+        }
+        if (!arow_ok) ay = zero4;
+        float2* d = reinterpret_cast<float2*>(sA + ar * LDA + 4 * aq);
+        d[0] = make_float2(ay.x, ay.y); d[1] = make_float2(ay.z, ay.w);
+        // the dense-gradient tiles read the (dropout-masked) layer-0 input rows back (dWx = yin^T dV)
+        if (l == 0 && blockIdx.x == 0 && arow_ok) st4(m.yin0 + (size_t)(m0 + ar) * IN + 4 * aq, ay);
+    }
+    __syncthreads();
+    if (clk && tid == 0) clk[6] = wall_clock64();
+    if (wid < NT1) accR = mma(accR, paA, sWr + lg * FF_LDR + wid * 16 + li, FF_LDR, IN);
+    if (doZ) accT = mma(accT, paA, sWz + lg * FF_LDT + tsub * 16 + li, FF_LDT, IN);
+    if (doC) accT = mma(accT, paA, sWc + lg * FF_LDT + tsub * 16 + li, FF_LDT, IN);
+    if (clk && tid == 0) clk[7] = wall_clock64();
+    // epilogue A
+    GAS float *rb = m.r[l], *Hrb = m.Hr[l], *zb = m.z[l];
+    if (wid < NT1) {
+        const bool mine = (nr >= n0 && nr < n0 + 32);      // this column tile stores its own 32 columns of r / Hr
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int r = 4 * lg + rg, row = m0 + r;
+            if (nr < D) {
+                const float rr = sigmoidf_(accR[rg] + b_r), hr = sA[r * LDA + IN + nr] * rr;
+                sHr[r * LDH + nr] = hr;
+                if (mine && row < M) { rb[(size_t)row * D + nr] = rr; Hrb[(size_t)row * D + nr] = hr; }
+            }
+        }
+    }
+    if (doZ || doC) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int r = 4 * lg + rg, row = m0 + r;
+            if (doZ) {
+                const float zz = sigmoidf_(accT[rg] + b_z);
+                sZ[r * 33 + tsub * 16 + li] = zz;
+                if (nt < D && row < M) zb[(size_t)row * D + nt] = zz;
+            } else {
+                sVc[r * 33 + tsub * 16 + li] = accT[rg] + b_c;
+            }
+        }
+    }
+    __syncthreads();
+    if (clk && tid == 0) clk[8] = wall_clock64();
+    // ---- stage B: (H r) Wh for the tile's columns; wave w: sub-tile (w & 1), quarter (w >> 1) of K = D
+    const int kq = wid >> 1;
+    const int kquart = ((Dq + 3) >> 2) << 2, kb = kq * kquart, ke = min(D, kb + kquart);
+    f32x4 accB = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (kb < ke) accB = mma(accB, sHr + li * LDH + lg + kb, sWh + (kb + lg) * FF_LDT + tsub * 16 + li, FF_LDT, ke - kb);
+    if (clk && tid == 0) clk[9] = wall_clock64();
+    if (kq) sJ[(wid - 2) * 64 + lane] = accB;
+    __syncthreads();
+    if (kq) return;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {      // quarters 1..3 in order
+        const f32x4 o = sJ[(2 * j + tsub) * 64 + lane];
+        accB[0] += o[0]; accB[1] += o[1]; accB[2] += o[2]; accB[3] += o[3];
+    }
+    if (nt >= D) return;
+    GAS float *cl = m.c[l], *hout = m.hd[l], *Hnext = m.H[l][(g + 1) & 1];
+    const float drop_h = m.drop_h;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const int r = 4 * lg + rg, row = m0 + r;
+        if (row >= M) continue;
+        const size_t o = (size_t)row * D + nt;
+        const float cc = act_fwd(m.hidden_act, m.ha_p0, m.ha_p1, accB[rg] + sVc[r * 33 + tsub * 16 + li]);
+        const float zz = sZ[r * 33 + tsub * 16 + li], hprev = sA[r * LDA + IN + nt];
+        float h = (1.0f - zz) * hprev + zz * cc;
+        if (drop_h > 0.f) h *= drop_mult(m.seed, (unsigned)g, G4R_STREAM_DROP_HIDDEN + l, row, nt, 1.0f - drop_h);
+        cl[o] = cc;
+        hout[o] = h;
+        Hnext[o] = ((rst4 >> (8 * rg)) & 0xFF) ? 0.f : h;
+    }
+    if (clk && tid == 0) clk[10] = wall_clock64();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Scoring GEMM: Sc[B, N] = h[B, D] * Wy[items]^T + By[items] - logq * lq[items]    (gru4rec.py:493-495)
 // 64 x 32 tiles; the B provider gathers the TN output-embedding rows of the tile's columns (in-batch targets,
 // then the step's row of the negative-sample store).  Publishes the column -> item map for the later kernels.

@@ -16,14 +16,11 @@ for rep in range(5):
     R = 2 * cfg['batch_size'] + cfg['n_sample']
     raw = m.get_debug('dbgclk', (2 * (64 + 8 * R),)).view(np.int64)
     g = raw[0:6]; s = raw[16:21]
-    print('k_gru_p1 tile(1,1): ctx->idx %.2f  idx->issued %.2f  issued->LDS %.2f  MFMA %.2f  epilogue %.2f us' % (
-        (g[5] - g[4]) / 100., (g[0] - g[5]) / 100., (g[1] - g[0]) / 100., (g[2] - g[1]) / 100., (g[3] - g[2]) / 100.))
+    f = raw[0:11]
+    print('k_gru_fwd_fused tile(1,1) us: requests %.2f  commits %.2f  barrier %.2f  gather issue + A1 %.2f  barrier %.2f  chunk swap + y rows + barrier %.2f  A2 %.2f  epilogue A + barrier %.2f  stage B %.2f  join+epilogue %.2f' % tuple(np.diff(f) / 100.))
     b = raw[16:25]
     print('k_gru_bwd_fused tile(1,1) us: requests %.2f  Wh/Wx->LDS %.2f  stage0 %.2f  barrier %.2f  stage1 %.2f  barrier %.2f  stage2 MFMA %.2f  join+epilogue %.2f' % tuple(np.diff(b) / 100.))
     mx = raw[32]
-    print('gru_fwd phases (us):', np.round(np.diff(g) / 100.0, 2), ' sparse b0w0 (us):', np.round(np.diff(s) / 100.0, 2),
-          '| slowest owner wave: %.2f us with %d dups | owners %d, occurrences %d, max dups %d' % (
-              (mx >> 20) / 100.0, mx & 0xFFFFF, raw[33], raw[34], raw[35]))
     tr = raw[64:].reshape(R, 8)
     tr = tr[(tr[:, 4] > 0) & (tr[:, 6] == 200 + rep)]
     t0 = tr[:, 0].min()
