@@ -275,7 +275,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     DA(d.dAx, (size_t)B * d.Ein); DA(d.dAy, (size_t)d.ldSc * d.Dtop); DA(d.dABy, d.ldSc);
     DA(d.lossrow, B);
     DA(d.occ_idx, ((d.R + 255) & ~255) + 256 + 64);      // k_sparse_update stages it with 16-byte loads up to Rpad
-    DA(d.col_item, d.ldSc);
+    DA(d.col_item, d.ldSc); DA(d.cur_in, B); DA(d.cur_col, d.ldSc);
     DA(d.occ_fl, (size_t)(cfg->embed_mode != G4R_EMBED_CONSTRAINED ? 2 : 1) * I * 4);
     DA(d.st, 1);
     // scoring backward geometry: role A tiles (n x d, one spare d column for dSBy), role B tiles (b x d x k-chunk)
@@ -545,7 +545,8 @@ int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
     const int B = m->dm.B;
     dfree(m, m->d_in); dfree(m, m->d_out); dfree(m, m->d_reset); dfree(m, m->d_M); dfree(m, m->d_cmaps);
     m->d_in = m->d_out = m->d_M = m->d_cmaps = nullptr; m->d_reset = nullptr;
-    if (dalloc(m, &m->d_in, (size_t)T * B, false) || dalloc(m, &m->d_out, (size_t)T * B, false) ||
+    // one trailing row: the bookkeeping of the last step stages "step T" (never run)
+    if (dalloc(m, &m->d_in, (size_t)(T + 1) * B, true) || dalloc(m, &m->d_out, (size_t)(T + 1) * B, true) ||
         dalloc(m, &m->d_reset, (size_t)T * B, false) || dalloc(m, &m->d_M, (size_t)T + 1, true))
         return -1;
     HIPCHK(hipMemcpyAsync(m->d_in, in_idx, (size_t)T * B * sizeof(int), hipMemcpyHostToDevice, m->stream));
@@ -773,7 +774,7 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
     if (t0 < 0 || n_steps < 0 || t0 + n_steps > m->T) return fail("step range outside the plan");
     if (m->dm.ns > 0 && !m->have_pop && !m->store_frozen) return fail("negative sampling needs g4r_set_popularity first");
     HIPCHK(hipSetDevice(m->cfg.device));
-    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(1), 0, m->stream, (StepState*)m->dm.st, (long long)t0, (long long)m->gstep, (const int*)m->d_M);
+    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(512), 0, m->stream, (const DevModel*)m->d_dm, (StepState*)m->dm.st, (long long)t0, (long long)m->gstep);
     const bool use_graph = m->cfg.use_graph && !m->profiling && m->dm.apply_dense_inplace;
     size_t ci = std::lower_bound(m->compact_steps.begin(), m->compact_steps.end(), t0) - m->compact_steps.begin();
     int64_t t = t0;
@@ -783,7 +784,10 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
         // host-scheduled events that sit between steps: batch compaction, sample-store refill
         while (ci < m->compact_steps.size() && m->compact_steps[ci] == t) { if (apply_compaction(m, (int64_t)ci)) return -1; ++ci; }
         if (m->dm.ns > 0 && !m->store_frozen && m->gstep > 0 && m->gstep % m->gl == 0)
+        {
             if (refill_store(m)) return -1;      // gru4rec.py:618-620
+            hipLaunchKernelGGL(k_restage_inputs, dim3(1), dim3(512), 0, m->stream, (const DevModel*)m->d_dm, (StepState*)m->dm.st);
+        }
         // steps until the next event
         int64_t run = tend - t;
         if (ci < m->compact_steps.size()) run = std::min(run, m->compact_steps[ci] - t);

@@ -109,6 +109,10 @@ struct DevModel {
     GP(float) yin0;    // [B][IN0] layer-0 input rows as the GRU saw them (gathered, embedding dropout applied)
     GP(int) occ_idx;   // [R] item of each gathered-row occurrence (X | Y | samples), -1 = inactive
     GP(int) col_item;  // [ldSc] item of each score column, -1 = inactive
+    // inputs of the NEXT step, staged at fixed addresses by the bookkeeping block of the update kernel (and by k_set_state /
+    // after a sample-store refill), so that the first kernels of a step load them next to the step state instead of behind it
+    GP(int) cur_in;    // [B]    in_idx row of the step about to run
+    GP(int) cur_col;   // [ldSc] item of every score column of the step about to run (targets | -1 | samples | -1)
     // [tables][n_items][4]: (last occurrence + 1, R - first occurrence, count, 0) of every item touched this step, written
     // with atomics by the kernels that publish occ_idx and zeroed again by the row's owner in k_sparse_update
     // (table 0: Wy / By rows, table 1: separate input embedding E)

@@ -35,6 +35,23 @@ __device__ __forceinline__ StepCtx load_ctx(StepState* st_) {
     return c;
 }
 
+// Stages the inputs of step (t, g) with M active rows: its in_idx row and its column -> item list (gru4rec.py:436-437: the
+// targets of the active rows, then this step's row of the negative-sample store).  All threads of the calling workgroup.
+__device__ __forceinline__ void stage_step_inputs(const DevModel& m, long long t, long long g, int M, int tid, int nth) {
+    const int B = m.B, N = m.N, ld = m.ldSc;
+    const GAS int* in = m.in_idx + t * B;
+    const GAS int* out = m.out_idx + t * B;
+    const GAS int* smp = m.ST + (size_t)(m.gl > 0 ? g % m.gl : 0) * m.ns;
+    GAS int *ci = m.cur_in, *cc = m.cur_col;
+    for (int b = tid; b < B; b += nth) ci[b] = in[b];
+    for (int n = tid; n < ld; n += nth) {
+        int item = -1;
+        if (n < M) item = out[n];
+        else if (n >= B && n < N) item = smp[n - B];
+        cc[n] = item;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Arguments of the GRU kernels in prediction mode (train = 0; gru4rec.py:433 predict=True): explicit state
 // instead of the device step state, no dropout, no reset switch, nothing saved for a backward pass.
@@ -81,7 +98,7 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_p1(const DevModel* __restric
         const StepCtx c = first ? load_ctx_first(st) : load_ctx(st);
         t = c.t; g = c.g; M = c.M;
         Hcur = m.H[l][g & 1];
-        if (l == 0) gidx = m.in_idx + t * m.B; else ysrc = m.hd[l - 1];
+        if (l == 0) gidx = m.cur_in; else ysrc = m.hd[l - 1];      // staged by the previous step's bookkeeping: no wait for t
         Vc = m.Vc[l]; zb = m.z[l]; Hrb = m.Hr[l]; rb = m.r[l];
     } else {
         M = pa.M; Hcur = pa.Hcur; gidx = pa.in_idx; ysrc = pa.ysrc; Vc = pa.Vc; zb = pa.z; Hrb = pa.Hr;
@@ -301,7 +318,7 @@ __global__ __launch_bounds__(512) void k_gru_fwd_fused(const DevModel* __restric
     if (clk && tid == 0) clk[0] = wall_clock64();
     // ---- row items first (the gathers wait for them), then everything that does not depend on them
     const int rrow = m0 + (tid & 15);
-    int item = (l == 0) ? m.in_idx[t * B + min(rrow, B - 1)] : 0;
+    int item = (l == 0) ? m.cur_in[min(rrow, B - 1)] : 0;      // staged by the previous step's bookkeeping: no wait for t
     if (!(l == 0 && rrow < M)) item = -1;
     const GAS float* Wx = m.dense_p + m.offWx[l];
     const GAS float* Wrz = m.dense_p + m.offWrz[l];
@@ -518,9 +535,8 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
     const int n0 = blockIdx.x * TBN, m0 = blockIdx.y * SF_BM;
     if (tid < TBN) {
         const int n = n0 + tid;
-        int item = -1;
-        if (n < M) item = m.out_idx[c.t * B + n];
-        else if (n >= B && n < N) item = m.ST[(size_t)(c.g % m.gl) * m.ns + (n - B)];
+        int item = m.cur_col[min(n, m.ldSc - 1)];      // targets | samples of this step, staged by the previous step's bookkeeping
+        if (n >= m.ldSc) item = -1;
         sItem[tid] = item;
         if (blockIdx.y == 0 && n < m.ldSc) {
             m.col_item[n] = item;
@@ -1446,6 +1462,7 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     const GAS float *g_dSx = m.dSx, *g_dSy = m.dSy, *g_dAx = m.dAx, *g_dAy = m.dAy, *g_dSBy = m.dSBy, *g_dABy = m.dABy;
     if (blk == nblk_occ) {
         // ---- bookkeeping block: cost = sum_i L_i / batch_size (gru4rec.py:577), NaN flag (:626), advance state
+        const int Mn = m.Mplan[c.t + 1];     // the plan carries one trailing entry (and one trailing row)
         if (wid == 0) {
             float s = 0.f;
             for (int i = lane; i < c.M; i += 64) s += m.lossrow[i];
@@ -1457,9 +1474,10 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
                 if (isnan(cost)) sg->nan_flag = 1;
                 sg->t_a = c.t + 1;
                 sg->g_a = c.g + 1;
-                sg->M_a = m.Mplan[c.t + 1];     // the plan carries one trailing entry
+                sg->M_a = Mn;
             }
         }
+        stage_step_inputs(m, c.t + 1, c.g + 1, Mn, tid, SP_WAVES * 64);
         return;
     }
     const long long t_start = m.dbgclk ? wall_clock64() : 0;
@@ -1775,6 +1793,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
     const StepCtx c = load_ctx(st);
     const int B = m.B, R = m.R;
     if ((int)blockIdx.x == nblk_occ) {       // bookkeeping block, as in k_sparse_update
+        const int Mn = m.Mplan[c.t + 1];
         if (wid == 0) {
             float s = 0.f;
             for (int i = lane; i < c.M; i += 64) s += m.lossrow[i];
@@ -1786,9 +1805,10 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
                 if (isnan(cost)) sg->nan_flag = 1;
                 sg->t_a = c.t + 1;
                 sg->g_a = c.g + 1;
-                sg->M_a = m.Mplan[c.t + 1];
+                sg->M_a = Mn;
             }
         }
+        stage_step_inputs(m, c.t + 1, c.g + 1, Mn, tid, SP_WAVES * 64);
         return;
     }
     const int Rpad = ((R + 255) & ~255) + 256;
@@ -1968,7 +1988,18 @@ __global__ __launch_bounds__(256) void k_gather_rows(float* dst, const float* sr
     dst[e] = s >= 0 ? src[(size_t)s * W + d] : 0.f;
 }
 
-__global__ void k_set_state(StepState* st, long long t, long long g, const int* Mplan) {
-    st->t_a = t; st->t_b = t; st->g_a = g; st->g_b = g;
-    st->M_a = Mplan[t]; st->M_b = Mplan[t];
+// host-side (re)positioning of the step state: plan step t, global step g; stages that step's inputs (one 512-thread workgroup)
+__global__ __launch_bounds__(512) void k_set_state(const DevModel* __restrict__ mp, StepState* st, long long t, long long g) {
+    const DevModel& m = *mp;
+    const int M = m.Mplan[t];
+    if (threadIdx.x == 0) {
+        st->t_a = t; st->t_b = t; st->g_a = g; st->g_b = g;
+        st->M_a = M; st->M_b = M;
+    }
+    stage_step_inputs(m, t, g, M, threadIdx.x, 512);
+}
+// after a sample-store refill between two steps: the staged column list of the step about to run holds the old samples
+__global__ __launch_bounds__(512) void k_restage_inputs(const DevModel* __restrict__ mp, StepState* st) {
+    const GAS StepState* sg = (const GAS StepState*)st;
+    stage_step_inputs(*mp, sg->t_a, sg->g_a, sg->M_a, threadIdx.x, 512);
 }

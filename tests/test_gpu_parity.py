@@ -248,6 +248,40 @@ def test_graph_replay_is_bit_identical_to_eager():
         np.testing.assert_array_equal(a, b)
 
 
+def test_refill_boundaries_one_call_equals_stepwise():
+    """Device-generated sample store of 3 rows: it is refilled every 3 steps (gru4rec.py:618-620).  One call over 20 steps
+    (graph replay, the next step's inputs staged by the previous step's bookkeeping, re-staged after each refill) must equal
+    20 one-step calls (every call stages its own inputs): same costs and weights to the last bit."""
+    I, B, ns, T = 90, 12, 24, 20
+    plan = random_plan(I, B, T, seed=41)
+    rng = np.random.RandomState(5)
+    pop = rng.randint(1, 30, size=I).astype(np.float64) ** 0.75
+    cum = (pop.cumsum() / pop.sum()).astype(np.float32)
+    cum[-1] = 1.0
+    Wy = (rng.randn(I, 16) * 0.2).astype(np.float32)
+    outs = []
+    for mode in ('one_call', 'stepwise'):
+        m = _native.Model(n_items=I, layers=[16], batch_size=B, n_sample=ns, loss=_native.LOSS_IDS['bpr-max'],
+                          final_act=_native.ACT_IDS['elu'], final_act_p0=0.5, hidden_act=_native.ACT_IDS['tanh'], embed_mode=0,
+                          learning_rate=0.1, momentum=0.2, bpreg=1.0, sample_alpha=0.75, dropout_p_hidden=0.1, sample_store=3 * ns,
+                          seed=77, device=0, rank=0, nranks=1, use_graph=1 if mode == 'one_call' else 0)
+        m.set_param('Wy', Wy)
+        m.set_popularity(cum)
+        assert m.sample_store_rows() == 3
+        m.set_plan(plan)
+        m.reset_hidden()
+        if mode == 'one_call':
+            m.train_steps(0, T)
+        else:
+            for t in range(T):
+                m.train_steps(t, 1)
+        outs.append((m.get_losses(0, T), m.get_param('Wy', (I, 16)), m.get_param('Wx', (16, 48), 0), m.get_sample_store(ns)))
+        m.close()
+    assert len(np.unique(outs[0][0])) == T          # every step saw different samples / inputs
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_multirank_data_path_on_one_gpu(monkeypatch):
     """The N > 1 step (dense gradients staged -> RCCL all-reduce on the side stream -> k_dense_apply, next to the
     sparse update) with a one-rank communicator must reproduce the fused single-GPU step."""
