@@ -537,6 +537,9 @@ int64_t g4r_build_plan(const int32_t* off, int64_t n_sessions, const int64_t* or
     return T;
 }
 
+static int ensure_graph(g4r_model* m);
+static int ensure_head_graph(g4r_model* m);
+
 int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, const uint8_t* reset, const int32_t* M,
                  int64_t T, const int64_t* compact_steps, const int32_t* compact_maps, int64_t n_compact) {
     if (!m || !in_idx || !out_idx || !reset || !M || T < 1) return fail("null / empty plan");
@@ -571,7 +574,15 @@ int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
     m->dm.in_idx = m->d_in; m->dm.out_idx = m->d_out; m->dm.reset = m->d_reset; m->dm.Mplan = m->d_M;
     m->dm.loss_steps = m->d_loss;
     // the captured graph stays valid: kernels read the plan pointers from the device descriptor
-    return sync_dm(m);
+    if (sync_dm(m)) return -1;
+    // capture + instantiate the step graph now (capturing executes nothing): the first timed steps of a short run must not
+    // pay the ~10 ms of graph construction
+    if (m->cfg.use_graph && !m->profiling && !getenv("G4R_TRACE")) {
+        if (m->dm.apply_dense_inplace ? ensure_graph(m) : ensure_head_graph(m)) return -1;
+        hipGraphExec_t ge = m->dm.apply_dense_inplace ? m->gexec : m->gexec_head;
+        if (ge) (void)hipGraphUpload(ge, m->stream);
+    }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ the step
