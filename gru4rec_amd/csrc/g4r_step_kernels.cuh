@@ -44,11 +44,20 @@ __device__ __forceinline__ void stage_step_inputs(const DevModel& m, long long t
     const GAS int* smp = m.ST + (size_t)(m.gl > 0 ? g % m.gl : 0) * m.ns;
     GAS int *ci = m.cur_in, *cc = m.cur_col;
     for (int b = tid; b < B; b += nth) ci[b] = in[b];
-    for (int n = tid; n < ld; n += nth) {
-        int item = -1;
-        if (n < M) item = out[n];
-        else if (n >= B && n < N) item = smp[n - B];
-        cc[n] = item;
+    // 8 columns per thread and pass, all loads of a pass in flight together (clamped addresses, selects afterwards)
+    for (int base = 0; base < ld; base += 8 * nth) {
+        int vo[8], vs[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int n = base + q * nth + tid;
+            vo[q] = out[min(n, B - 1)];
+            vs[q] = (m.ns > 0) ? smp[min(max(n - B, 0), m.ns - 1)] : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int n = base + q * nth + tid;
+            if (n < ld) cc[n] = (n < M) ? vo[q] : (n >= B && n < N) ? vs[q] : -1;
+        }
     }
 }
 
@@ -1763,7 +1772,8 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
 template <int MAXCH>
 __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevModel* __restrict__ mp, StepState* st, int nblk_occ) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    sparse_update_block<MAXCH>(mp, st, nblk_occ, (int)blockIdx.x, smem);
+    // workgroup 0 does the step bookkeeping (it depends on nothing the other workgroups produce; dispatched first, it is off the tail)
+    sparse_update_block<MAXCH>(mp, st, nblk_occ, blockIdx.x == 0 ? nblk_occ : (int)blockIdx.x - 1, smem);
 }
 
 // Single GPU: the dense-gradient tiles (+ fused dense Adagrad) and the sparse row update are independent of each other
@@ -1774,8 +1784,11 @@ template <int MAXCH>
 __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_update(const DevModel* __restrict__ mp, StepState* st, const DenseTile* __restrict__ tiles_,
                                                              int ntiles, int nblk_occ) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if ((int)blockIdx.x < ntiles) dense_grad_tile(*mp, st, tiles_, (int)blockIdx.x, smem);
-    else sparse_update_block<MAXCH>(mp, st, nblk_occ, (int)blockIdx.x - ntiles, smem);
+    // workgroup 0: step bookkeeping (dispatched first: off the tail), then the dense tiles, then the sparse-update workgroups
+    const int b = (int)blockIdx.x - 1;
+    if (b < 0) sparse_update_block<MAXCH>(mp, st, nblk_occ, nblk_occ, smem);
+    else if (b < ntiles) dense_grad_tile(*mp, st, tiles_, b, smem);
+    else sparse_update_block<MAXCH>(mp, st, nblk_occ, b - ntiles, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
