@@ -1,17 +1,16 @@
-// Training / prediction step kernels (gfx950), second generation: every GEMM of the step is an LDS-staged
-// fp32 MFMA tile GEMM (g4r_gemm.cuh) split over >= 100 workgroups, with gathers, dropout, gates and optimizer
-// updates fused into the operand providers / epilogues.  One training step (reference: the Theano function built
-// at gru4rec.py:572-584 and called at :623) for one GRU layer is 10 launches:
-//   k_gru_p1      V = [y | H] [Wx ; Wrz] + Bh, gates r z, H*r        gather + embedding dropout fused  gru4rec.py:438-473
-//   k_gru_p2      c = act((H*r) Wh + V_c), h, hidden dropout, reset                                     gru4rec.py:474-479
-//   k_score_fwd   Sc = h Wy[Y | samples]^T + By - logq lq            gathered rows through LDS          gru4rec.py:480-495
-//   k_loss_rows   final activation + loss + d cost / d s per row                                        gru4rec.py:193-248,496
-//   k_score_bwd   dSy = ds^T h, dSBy ; split-K slabs of dh = ds Sy                                      (T.grad, :383-384)
-//   k_gru_bwd_pre dh = sum of slabs, dropout mask, da, dz'  (element-wise)
-//   k_gru_bwd_a   dr' = (da Wh^T) H r (1 - r)
-//   k_gru_bwd_b   dy = dV Wx^T  -> dSx (embedding-row gradient) or the lower layer's dh
-//   k_dense_grad  dWx / dWh / dWrz / dBh over the batch + fused dense Adagrad(+momentum)                gru4rec.py:390-406
-//   k_sparse_update  per-occurrence Adagrad on the touched Wy / By / E rows + step bookkeeping          gru4rec.py:407-431
+// Training / prediction step kernels (gfx950).  Every GEMM of the step is an LDS-staged fp32 MFMA tile GEMM, with gathers,
+// dropout, gates and optimizer updates fused into the operand providers / epilogues.  One training step (reference: the
+// Theano function built at gru4rec.py:572-584 and called at :623) for one GRU layer of up to 112 units is 6 launches:
+//   k_gru_fwd_fused  [y | H] rows -> r, z, candidate, h, next H in one launch (gather + dropout fused)     gru4rec.py:438-479
+//   k_score_fwd      Sc = h Wy[Y | samples]^T + By - logq lq            gathered rows through LDS          gru4rec.py:480-495
+//   k_loss_rows      final activation + loss + d cost / d s per row                                        gru4rec.py:193-248,496
+//   k_score_bwd      dSy = ds^T h, dSBy ; split-K slabs of dh = ds Sy                                      (T.grad, :383-384)
+//   k_gru_bwd_fused  slab sum + gate derivatives, dr' GEMM, dy GEMM -> dSx / the lower layer's dh          (T.grad)
+//   k_update         dense-gradient tiles (dWx / dWh / dWrz / dBh + dense Adagrad, gru4rec.py:390-406), per-occurrence sparse
+//                    Adagrad on the touched Wy / By / E rows (:407-431), step bookkeeping + staging of the next step's inputs
+// Wider layers, one-hot input and prediction use the unfused kernels (g4r_gemm.cuh tiles over >= 100 workgroups):
+//   k_gru_p1 (V = [y | H] [Wx ; Wrz] + Bh, r, z, H*r), k_gru_p2 (candidate, h), k_gru_bwd_pre / _a / _b, k_onehot_step;
+// N > 1 and the generic optimizers: k_dense_grad / k_dense_apply, k_sparse_update(_generic), k_grad_sqsum / k_grad_clip.
 #pragma once
 #include <type_traits>
 
