@@ -821,7 +821,7 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
                     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { m->kn_ms[r.kn] += ms; m->kn_n[r.kn]++; }
                 }
             } else if (m->cfg.use_graph && !m->dm.apply_dense_inplace && !getenv("G4R_TRACE")) {
-                // N > 1: the step's 9 compute kernels replay from a graph; the RCCL all-reduce, the dense apply and the
+                // N > 1: the step's compute kernels replay from a graph; the RCCL all-reduce, the dense apply and the
                 // sparse update (two streams, fork/join events) are launched eagerly behind it
                 if (ensure_head_graph(m)) return -1;
                 HIPCHK(hipGraphLaunch(m->gexec_head, m->stream));
