@@ -104,7 +104,8 @@ int64_t g4r_build_plan(const int32_t* offset_sessions, int64_t n_sessions, const
                        int32_t* in_idx, int32_t* out_idx, uint8_t* reset, int32_t* M,
                        int64_t* compact_steps, int32_t* compact_maps, int64_t max_steps, int64_t max_compact,
                        int64_t* n_compact);
-/* upload a plan: in_idx/out_idx [T,B] int32, reset [T,B] uint8, M [T] */
+/* upload a plan: in_idx/out_idx [T,B] int32, reset [T,B] uint8, M [T].  Also captures and instantiates the step graph
+ * (nothing executes), so that the first g4r_train_steps call does not pay for it. */
 int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, const uint8_t* reset,
                  const int32_t* M, int64_t T, const int64_t* compact_steps, const int32_t* compact_maps,
                  int64_t n_compact);
