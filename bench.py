@@ -112,7 +112,7 @@ def make_plan(cfg, n_steps, rank, nranks, seed=42):
     return plan, support
 
 
-def create_model(cfg, support, rank, nranks, device, unique_id, use_graph=True, seed=12345):
+def create_model(cfg, support, rank, nranks, device, unique_id, use_graph=True, seed=12345, sample_store=10000000):
     from gru4rec_amd import _native
     from gru4rec_amd.gru4rec import _parse_act
     fa = _parse_act(cfg['final_act'], True)
@@ -122,7 +122,7 @@ def create_model(cfg, support, rank, nranks, device, unique_id, use_graph=True, 
         hidden_act=_native.ACT_IDS['tanh'], embed_mode=_native.EMBED_CONSTRAINED, embedding=0,
         learning_rate=cfg['learning_rate'], momentum=cfg['momentum'], lmbd=0.0, bpreg=cfg['bpreg'], logq=cfg['logq'],
         sample_alpha=cfg['sample_alpha'], dropout_p_hidden=cfg['dropout_p_hidden'],
-        dropout_p_embed=cfg['dropout_p_embed'], sample_store=10000000, seed=seed + 7919 * rank, device=device,
+        dropout_p_embed=cfg['dropout_p_embed'], sample_store=sample_store, seed=seed + 7919 * rank, device=device,
         rank=rank, nranks=nranks, use_graph=1 if use_graph else 0)
     if nranks > 1:
         m.comm_init(unique_id, nranks, rank)

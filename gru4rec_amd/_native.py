@@ -15,7 +15,7 @@ G4R_MAX_LAYERS = 8
 LOSS_IDS = {'cross-entropy': 0, 'bpr-max': 1, 'top1-max': 2, 'bpr': 3, 'top1': 4, 'xe_logit': 5}
 ACT_IDS = {'linear': 0, 'relu': 1, 'tanh': 2, 'leaky': 3, 'elu': 4, 'selu': 5, 'softmax': 6, 'softmax_logit': 7}
 ADAPT_IDS = {'adagrad': 0, 'rmsprop': 1, 'adadelta': 2, 'adam': 3, None: 4}
-RANK_MODES = {'standard': 0, 'conservative': 1, 'median': 2}
+RANK_MODES = {'standard': 0, 'conservative': 1, 'median': 2, 'tiebreaking': 3}
 EMBED_CONSTRAINED, EMBED_SEPARATE, EMBED_ONEHOT = 0, 1, 2
 
 
@@ -91,7 +91,7 @@ def lib():
     L.g4r_profile.argtypes = [vp, i32]
     L.g4r_reset_hidden.argtypes = [vp]
     L.g4r_predict_begin.argtypes = [vp, i32]
-    L.g4r_predict_hidden.argtypes = [vp, u8p, i32p, i32]
+    L.g4r_predict_hidden.argtypes = [vp, u8p, i32, i32p, i32]
     L.g4r_predict_step.argtypes = [vp, i32p, i32, i32p, i64, f32p]
     L.g4r_rank_targets.argtypes = [vp, i32p, i32, i64, i32, f32p]
     L.g4r_evaluate.argtypes = [vp, i32p, i32p, u8p, i32p, i64, i32, i64p, i32p, i64, i32p, i64, i32p, i32, i32,
@@ -327,7 +327,7 @@ class Model:
     def predict_hidden(self, zero_mask=None, keep_rows=None):
         z = None if zero_mask is None else np.ascontiguousarray(zero_mask, dtype=np.uint8)
         k = None if keep_rows is None else np.ascontiguousarray(keep_rows, dtype=np.int32)
-        _chk(lib().g4r_predict_hidden(self.h, None if z is None else _u8(z), None if k is None else _i32(k),
+        _chk(lib().g4r_predict_hidden(self.h, None if z is None else _u8(z), 0 if z is None else len(z), None if k is None else _i32(k),
                                       0 if k is None else len(k)))
 
     def predict_step(self, in_idx, item_idx=None, want_scores=True):

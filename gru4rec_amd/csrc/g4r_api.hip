@@ -95,6 +95,7 @@ struct g4r_model {
     float *p_scores = nullptr, *p_ranks = nullptr;
     int* p_cnt = nullptr;                        // [pbatch][2] streamed (greater, equal) counts of the evaluation
     int64_t p_scores_cap = 0, p_items_cap = 0, p_nsel = 0, p_ldo = 0;
+    unsigned tie_ctr = 0;                        // evaluation step counter of the 'tiebreaking' noise stream
     // rccl
     ncclComm_t comm = nullptr;
     bool comm_ready = false;
@@ -209,10 +210,11 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     memset(&d, 0, sizeof(d));
     const int L = cfg->n_layers, B = cfg->batch_size;
     d.n_items = cfg->n_items; d.n_layers = L; d.B = B;
-    // negatives: generate_length = sample_store // n_sample ; a store of <= 1 rows means "no store" (gru4rec.py:546-550)
-    int ns = cfg->n_sample;
+    // negatives: generate_length = sample_store // n_sample ; a store of <= 1 rows means "no store" (gru4rec.py:546-550), i.e. a
+    // fresh row of negatives for every step (:614-615): a one-row store that is refilled before every step
+    const int ns = std::max(cfg->n_sample, 0);
     int64_t gl = (ns > 0 && cfg->sample_store > 0) ? cfg->sample_store / ns : 0;
-    if (gl <= 1) { ns = 0; gl = 0; }
+    if (ns > 0 && gl <= 1) gl = 1;
     m->gl = gl;
     d.ns = ns; d.N = B + ns; d.R = 2 * B + ns; d.ldSc = (d.N + 15) & ~15;
     d.gl = (int)std::max<int64_t>(gl, 1);
@@ -901,17 +903,22 @@ int g4r_predict_begin(g4r_model* m, int32_t batch) {
             for (int q = 0; q < 2; ++q) HIPCHK(hipMemsetAsync(m->pH[l][q], 0, (size_t)batch * d.D[l] * sizeof(float), m->stream));
     }
     m->ppar = 0;
+    m->tie_ctr = 0;
     HIPCHK(hipStreamSynchronize(m->stream));
     return 0;
 }
 
-int g4r_predict_hidden(g4r_model* m, const uint8_t* zero_mask, const int32_t* keep_rows, int32_t n_keep) {
+int g4r_predict_hidden(g4r_model* m, const uint8_t* zero_mask, int32_t n_mask, const int32_t* keep_rows, int32_t n_keep) {
     if (!m || !m->pbatch) return fail("g4r_predict_begin first");
     HIPCHK(hipSetDevice(m->cfg.device));
     DevModel& d = m->dm;
     const int PB = m->pbatch;
     if (zero_mask) {
-        HIPCHK(hipMemcpyAsync(m->p_zero, zero_mask, PB, hipMemcpyHostToDevice, m->stream));
+        if (n_mask < 0 || n_mask > PB) return fail("zero_mask is longer than the prediction batch (g4r_predict_begin)");
+        std::vector<unsigned char> zm(PB, 0);      // rows past the mask keep their state
+        memcpy(zm.data(), zero_mask, (size_t)n_mask);
+        HIPCHK(hipMemcpyAsync(m->p_zero, zm.data(), PB, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
         for (int l = 0; l < d.n_layers; ++l)
             hipLaunchKernelGGL(k_zero_rows, dim3(cdiv((long long)PB * d.D[l], 256)), dim3(256), 0, m->stream, m->pH[l][m->ppar],
                                (const unsigned char*)m->p_zero, PB, d.D[l]);
@@ -970,13 +977,14 @@ int g4r_predict_step(g4r_model* m, const int32_t* in_idx, int32_t mrows, const i
 int g4r_rank_targets(g4r_model* m, const int32_t* target_col, int32_t mrows, int64_t col_begin, int32_t mode, float* ranks) {
     if (!m || !target_col || !ranks) return fail("null argument");
     if (!m->p_scores || mrows < 1 || mrows > m->pbatch) return fail("no scores / mrows out of range");
-    if (mode < 0 || mode > G4R_RANK_MEDIAN) return fail("unknown rank mode");
+    if (mode < 0 || mode > G4R_RANK_TIEBREAKING) return fail("unknown rank mode");
     for (int i = 0; i < mrows; ++i)
         if (target_col[i] < 0 || target_col[i] >= m->p_nsel) return fail("target column out of range");
     HIPCHK(hipSetDevice(m->cfg.device));
     HIPCHK(hipMemcpyAsync(m->p_tgt, target_col, mrows * sizeof(int), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(k_rank_rows, dim3(mrows), dim3(256), 0, m->stream, (const float*)m->p_scores, (long long)m->p_nsel,
-                       (long long)m->p_ldo, (const int*)m->p_tgt, (long long)col_begin, (int)mode, m->p_ranks);
+                       (long long)m->p_ldo, (const int*)m->p_tgt, (long long)col_begin, (int)mode, m->p_ranks,
+                       (unsigned long long)m->cfg.seed, m->tie_ctr++);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ranks, m->p_ranks, mrows * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
@@ -988,7 +996,7 @@ int g4r_rank_targets(g4r_model* m, const int32_t* target_col, int32_t mrows, int
 // element-wise final activation) nothing is materialised: stream->tgt lists the target item of every row; their scores are
 // computed first (mrows x mrows tile, diagonal used), then every candidate tile is compared with them on the fly and
 // p_ranks receives the ranks (stream->mode, candidates from column stream->col_begin on).
-struct StreamRank { const int* tgt; long long col_begin; int mode; };
+struct StreamRank { const int* tgt; long long col_begin; int mode; const int* tie_col; unsigned tie_ctr; };
 static int predict_forward(g4r_model* m, const int* d_in_idx, int mrows, const int* d_items, int64_t n_sel, const StreamRank* stream) {
     DevModel& d = m->dm;
     const int64_t ldo = stream ? ((mrows + 3) & ~3) : ((n_sel + 3) & ~3LL);
@@ -1023,16 +1031,17 @@ static int predict_forward(g4r_model* m, const int* d_in_idx, int mrows, const i
     if (stream) {
         if (sm) return fail("internal: streaming ranks need an element-wise final activation");
         hipLaunchKernelGGL(k_score_store, dim3(cdiv(mrows, 32), cdiv(mrows, SC_BM)), dim3(256), m->smem_score, m->stream, (const DevModel*)m->d_dm,
-                           hsrc, (int)mrows, stream->tgt, (long long)mrows, m->p_scores, (long long)ldo, 1, (int*)nullptr, 0LL);
+                           hsrc, (int)mrows, stream->tgt, (long long)mrows, m->p_scores, (long long)ldo, 1, (int*)nullptr, 0LL, (const int*)nullptr, 0u);
         hipLaunchKernelGGL(k_score_count, dim3(cdiv(n_sel, 32), cdiv(mrows, SC_BM)), dim3(256), m->smem_score, m->stream, (const DevModel*)m->d_dm,
-                           hsrc, (int)mrows, d_items, (long long)n_sel, m->p_scores, (long long)ldo, 1, m->p_cnt, stream->col_begin);
+                           hsrc, (int)mrows, d_items, (long long)n_sel, m->p_scores, (long long)ldo, 1, m->p_cnt, stream->col_begin,
+                           stream->mode == G4R_RANK_TIEBREAKING ? stream->tie_col : (const int*)nullptr, stream->tie_ctr);
         hipLaunchKernelGGL(k_rank_counts, dim3(cdiv(mrows, 256)), dim3(256), 0, m->stream, m->p_cnt, (int)mrows, stream->mode, m->p_ranks);
         HIPCHK(hipGetLastError());
         m->p_nsel = 0; m->p_ldo = ldo;        // no score matrix to read back
         return 0;
     }
     hipLaunchKernelGGL(k_score_store, dim3(cdiv(n_sel, 32), cdiv(mrows, SC_BM)), dim3(256), m->smem_score, m->stream, (const DevModel*)m->d_dm,
-                       hsrc, (int)mrows, d_items, (long long)n_sel, m->p_scores, (long long)ldo, sm ? 0 : 1, (int*)nullptr, 0LL);
+                       hsrc, (int)mrows, d_items, (long long)n_sel, m->p_scores, (long long)ldo, sm ? 0 : 1, (int*)nullptr, 0LL, (const int*)nullptr, 0u);
     if (sm) hipLaunchKernelGGL(k_softmax_rows, dim3(mrows), dim3(256), 0, m->stream, m->p_scores, (long long)n_sel, (long long)ldo);
     HIPCHK(hipGetLastError());
     m->p_nsel = n_sel; m->p_ldo = ldo;
@@ -1045,7 +1054,7 @@ int g4r_evaluate(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
                  double* recall_sum, double* mrr_sum, int64_t* n_events) {
     if (!m || !in_idx || !out_idx || !reset || !M || !cutoffs || !recall_sum || !mrr_sum || !n_events) return fail("null argument");
     if (T < 0 || batch < 1 || n_cut < 1 || n_cut > 64) return fail("bad evaluation sizes");
-    if (mode < 0 || mode > G4R_RANK_MEDIAN) return fail("unknown rank mode");
+    if (mode < 0 || mode > G4R_RANK_TIEBREAKING) return fail("unknown rank mode");
     if (n_compact > 0 && (!compact_steps || !compact_maps)) return fail("compaction arrays missing");
     DevModel& d = m->dm;
     const int B = batch;
@@ -1106,13 +1115,15 @@ int g4r_evaluate(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
         }
         if (streaming) {
             // element-wise final activation: candidate tiles are ranked against the target score as they are produced
-            const StreamRank sr = {tgt, items ? (long long)Mt : 0LL, (int)mode};
+            // column of row i's target in the candidate list: i when [targets | items] are scored, the target item otherwise
+            const StreamRank sr = {tgt, items ? (long long)Mt : 0LL, (int)mode, items ? (const int*)e_iota : tgt, (unsigned)t};
             if (predict_forward(m, e_in + t * B, Mt, cand, n_sel, &sr)) { cleanup(); return -1; }
         } else {
             // softmax needs the whole row first (max, sum): scores are materialised, then ranked
             if (predict_forward(m, e_in + t * B, Mt, cand, n_sel, nullptr)) { cleanup(); return -1; }
             hipLaunchKernelGGL(k_rank_rows, dim3(Mt), dim3(256), 0, s, (const float*)m->p_scores, (long long)m->p_nsel, (long long)m->p_ldo,
-                               items ? (const int*)e_iota : tgt, items ? (long long)Mt : 0LL, (int)mode, m->p_ranks);
+                               items ? (const int*)e_iota : tgt, items ? (long long)Mt : 0LL, (int)mode, m->p_ranks,
+                               (unsigned long long)m->cfg.seed, (unsigned)t);
         }
         hipLaunchKernelGGL(k_eval_accum, dim3(1), dim3(256), 0, s, (const float*)m->p_ranks, Mt, (const int*)e_cut, (int)n_cut, e_acc,
                            e_acc + n_cut, e_n);

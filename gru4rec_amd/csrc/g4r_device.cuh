@@ -15,6 +15,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define G4R_STREAM_SAMPLE 0x53414D50u
 #define G4R_STREAM_DROP_EMBED 0x44454D42u
 #define G4R_STREAM_DROP_HIDDEN 0x44484944u
+#define G4R_STREAM_TIEBREAK 0x54494542u
 
 // ---------------------------------------------------------------------------------------------
 // Pointers that the kernels read out of device-resident descriptors (DevModel, DenseTile) would be generic
@@ -210,6 +211,14 @@ __device__ __forceinline__ float drop_mult(unsigned long long seed, unsigned g, 
     const int e = col & 3;
     const unsigned x = e == 0 ? p.x : (e == 1 ? p.y : (e == 2 ? p.z : p.w));
     return u32_to_unit(x) < retain ? 1.0f / retain : 0.0f;
+}
+// evaluation mode 'tiebreaking' (evaluation.py:55): uniform * 1e-10 for score (row, col) of evaluation step `ctr`;
+// twin of oracle.philox.uniform_rows(..., STREAM_TIEBREAK)
+__device__ __forceinline__ float tie_noise(unsigned long long seed, unsigned ctr, int row, long long col) {
+    const Philox4 p = philox4x32_10((unsigned)(col >> 2), (unsigned)row, ctr, G4R_STREAM_TIEBREAK, (unsigned)seed, (unsigned)(seed >> 32));
+    const int e = (int)(col & 3);
+    const unsigned x = e == 0 ? p.x : (e == 1 ? p.y : (e == 2 ? p.z : p.w));
+    return u32_to_unit(x) * 1e-10f;
 }
 __device__ __forceinline__ float4 drop_mult4(unsigned long long seed, unsigned g, unsigned stream, int row, int col4,
                                              float retain) {

@@ -14,10 +14,13 @@
 // every row (out[row * ldo + row], produced by a COUNT = false launch over the target items, i.e. by the very same
 // k-ordered MFMA chain, so equal scores compare equal); the tile's scores are compared with it and the number of
 // candidates in columns >= col_begin that are greater / equal is added to cnt[2 * row], cnt[2 * row + 1] (integer atomics).
+// tie_col != nullptr (mode 'tiebreaking'): score (row, column n) is moved by tie_noise(row, n) before the comparison and the
+// row's target score by tie_noise(row, tie_col[row]) -- tie_col[row] is the column the target occupies in the candidate list.
 template <int TN, bool COUNT = false>
 __global__ __launch_bounds__(256) void k_score_all(const DevModel* __restrict__ mp, const float* h, int mrows, const int* item_idx,
                                                    long long n_sel, float* out, long long ldo, int apply_act,
-                                                   int* cnt = nullptr, long long col_begin = 0) {
+                                                   int* cnt = nullptr, long long col_begin = 0, const int* tie_col = nullptr,
+                                                   unsigned tie_ctr = 0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lg = lane >> 4;
@@ -99,13 +102,15 @@ __global__ __launch_bounds__(256) void k_score_all(const DevModel* __restrict__ 
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int row = rbase + 32 * wid + 16 * ri + 4 * lg + rg;
-                const float t = out[(size_t)min(row, mrows - 1) * ldo + min(row, mrows - 1)];
+                float t = out[(size_t)min(row, mrows - 1) * ldo + min(row, mrows - 1)];
+                if (tie_col) t += tie_noise(m.seed, tie_ctr, row, tie_col[min(row, mrows - 1)]);
                 float gt = 0.f, eq = 0.f;
 #pragma unroll
                 for (int cj = 0; cj < CT; ++cj) {
                     const long long n = n0 + 16 * cj + li;
                     float v = acc[ri][cj][rg] + add[cj];
                     if (apply_act) v = act_fwd(m.final_act, m.fa_p0, m.fa_p1, v);
+                    if (tie_col) v += tie_noise(m.seed, tie_ctr, row, n);
                     const bool in = n < n_sel && n >= col_begin;
                     gt += (in && v > t) ? 1.f : 0.f;
                     eq += (in && v == t) ? 1.f : 0.f;
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void k_rank_counts(int* cnt, int mrows, int mo
     float r;
     if (mode == G4R_RANK_CONSERVATIVE) r = gt + eq;
     else if (mode == G4R_RANK_MEDIAN) r = gt + 0.5f * (eq - 1.f) + 1.f;
-    else r = gt + 1.f;
+    else r = gt + 1.f;      // STANDARD, TIEBREAKING
     ranks[i] = r;
 }
 
@@ -149,13 +154,16 @@ __global__ __launch_bounds__(256) void k_softmax_rows(float* sc, long long n_sel
 
 // ranks (evaluation.py:62-65): others = columns [col_begin, n_sel); target = column target_col[row]
 __global__ __launch_bounds__(256) void k_rank_rows(const float* sc, long long n_sel, long long ldo, const int* target_col,
-                                                   long long col_begin, int mode, float* ranks) {
+                                                   long long col_begin, int mode, float* ranks, unsigned long long seed, unsigned tie_ctr) {
     __shared__ float red[8];
     const float* row = sc + (size_t)blockIdx.x * ldo;
-    const float t = row[target_col[blockIdx.x]];
+    const bool tie = mode == G4R_RANK_TIEBREAKING;      // evaluation.py:55: yhat += uniform * 1e-10 (fp32), then as STANDARD
+    float t = row[target_col[blockIdx.x]];
+    if (tie) t += tie_noise(seed, tie_ctr, blockIdx.x, target_col[blockIdx.x]);
     float gt = 0.f, eq = 0.f;
     for (long long j = col_begin + threadIdx.x; j < n_sel; j += 256) {
-        const float v = row[j];
+        float v = row[j];
+        if (tie) v += tie_noise(seed, tie_ctr, blockIdx.x, j);
         gt += (v > t) ? 1.f : 0.f;
         eq += (v == t) ? 1.f : 0.f;
     }
@@ -237,5 +245,5 @@ template __global__ void k_score_bwd<32, GT_BK>(const DevModel*, StepState*, int
 template __global__ void k_score_bwd<64, 64>(const DevModel*, StepState*, int, int, int, int);
 template __global__ void k_gru_p1<GT_BN, P1_BK>(const DevModel*, StepState*, int, int, int, GruFwdPredict);
 template __global__ void k_gru_p1<64, 256>(const DevModel*, StepState*, int, int, int, GruFwdPredict);
-template __global__ void k_score_all<32, false>(const DevModel*, const float*, int, const int*, long long, float*, long long, int, int*, long long);
-template __global__ void k_score_all<32, true>(const DevModel*, const float*, int, const int*, long long, float*, long long, int, int*, long long);
+template __global__ void k_score_all<32, false>(const DevModel*, const float*, int, const int*, long long, float*, long long, int, int*, long long, const int*, unsigned);
+template __global__ void k_score_all<32, true>(const DevModel*, const float*, int, const int*, long long, float*, long long, int, int*, long long, const int*, unsigned);

@@ -4,7 +4,8 @@
 `evaluate_gpu` hands the whole test loop to the device in ONE call (`g4r_evaluate`): the session-parallel schedule
 of evaluation.py:96-139 is the schedule of `fit` (same author, same loop), so the C++ plan builder produces it; every
 step runs the GRU forward, scores all / the given items (final activation applied in fp32 as the reference does), ranks
-the targets with the > / >= / == counts of :62-65 and adds the hits and reciprocal ranks of every cut-off into device
+the targets with the > / >= / == counts of :62-65 (mode 'tiebreaking': scores + uniform * 1e-10 in fp32 first, :55, from a Philox
+stream keyed by the model seed, evaluation step, row and candidate column) and adds the hits and reciprocal ranks of every cut-off into device
 accumulators; hidden rows of finished sessions are zeroed / dropped on the device.  `evaluate_gpu_stepwise` is the
 host-driven variant (one `g4r_predict_step` + `g4r_rank_targets` per step), kept as a cross-check.
 """
@@ -60,10 +61,6 @@ def evaluate_gpu(gru, test_data, items=None, session_key='SessionId', item_key='
     multi = isinstance(cut_off, (list, tuple))
     cuts = list(cut_off) if multi else [cut_off]
     print('Measuring Recall@{} and MRR@{}'.format(','.join(str(c) for c in cuts), ','.join(str(c) for c in cuts)))
-    if mode == 'tiebreaking':
-        # the reference adds uniform*1e-10 to the scores (evaluation.py:55) and then ranks as 'standard'; the
-        # perturbation is below fp32 resolution for scores of ordinary magnitude, so ranks equal 'standard'
-        mode = 'standard'
     model = gru._ensure_model()
     titems, item_idxs, offs = _prepare(gru, test_data, items, session_key, item_key, time_key)
     n_sessions = len(offs) - 1
@@ -72,6 +69,9 @@ def evaluate_gpu(gru, test_data, items=None, session_key='SessionId', item_key='
     # sessions in id order (evaluation.py:90-95); n_sample = 1 selects "run until no session is left" (:124-127)
     plan = _native.build_plan(offs.astype(np.int32), np.arange(n_sessions), titems, batch_size, 1)
     rec, mrr, n = model.evaluate(plan, batch_size, item_idxs, cuts, mode)
+    # the evaluation used the model's prediction state; predict_next_batch starts afresh afterwards (the reference's
+    # evaluate_gpu keeps an H of its own, evaluation.py:54)
+    gru.predict = None
     return (rec / n).tolist(), (mrr / n).tolist()
 
 
@@ -85,10 +85,6 @@ def evaluate_gpu_stepwise(gru, test_data, items=None, session_key='SessionId', i
     multi = isinstance(cut_off, (list, tuple))
     cuts = list(cut_off) if multi else [cut_off]
     print('Measuring Recall@{} and MRR@{}'.format(','.join(str(c) for c in cuts), ','.join(str(c) for c in cuts)))
-    if mode == 'tiebreaking':
-        # the reference adds uniform*1e-10 to the scores (evaluation.py:55) and then ranks as 'standard'; the
-        # perturbation is below fp32 resolution for scores of ordinary magnitude, so ranks equal 'standard'
-        mode = 'standard'
     model = gru._ensure_model()
     lookup = pd.DataFrame({'ItemIdx': gru.itemidmap.values, item_key: gru.itemidmap.index})
     test_data = pd.merge(test_data, lookup, on=item_key, how='inner')
@@ -143,6 +139,7 @@ def evaluate_gpu_stepwise(gru, test_data, items=None, session_key='SessionId', i
                              np.pad(refill.astype(np.uint8), (0, batch_size - len(refill))),
                              keep_rows=keep if len(keep) < len(valid) else None)
         slot, first, last = slot[valid], first[valid], last[valid]
+    gru.predict = None      # see evaluate_gpu
     rec = (rec / n).tolist()
     mrr = (mrr / n).tolist()
     return rec, mrr

@@ -234,8 +234,6 @@ class GRU4Rec:
 
     # ------------------------------------------------------------------ native model management
     def _check_supported(self):
-        if self.adapt not in _native.ADAPT_IDS:
-            raise NotImplementedError('adapt={}'.format(self.adapt))
         need = {'rmsprop': 1, 'adadelta': 1, 'adam': 2}.get(self.adapt, 0)
         if len(self.adapt_params) < need:
             raise IndexError('adapt={} needs {} value(s) in adapt_params'.format(self.adapt, need))     # the reference indexes adapt_params[0..1]
@@ -261,7 +259,8 @@ class GRU4Rec:
                 _native.EMBED_SEPARATE if self.embedding else _native.EMBED_ONEHOT),
             embedding=int(self.embedding or 0), learning_rate=self.learning_rate, momentum=self.momentum,
             lmbd=self.lmbd, bpreg=self.bpreg, logq=self.logq, sample_alpha=self.sample_alpha, smoothing=float(self.smoothing),
-            adapt=_native.ADAPT_IDS[self.adapt], adapt_p0=float(self.adapt_params[0]) if len(self.adapt_params) > 0 else 0.0,
+            adapt=_native.ADAPT_IDS.get(self.adapt, _native.ADAPT_IDS[None]),      # any other value: plain SGD (gru4rec.py:392-399 fall through)
+            adapt_p0=float(self.adapt_params[0]) if len(self.adapt_params) > 0 else 0.0,
             adapt_p1=float(self.adapt_params[1]) if len(self.adapt_params) > 1 else 0.0, grad_cap=float(self.grad_cap),
             dropout_p_hidden=self.dropout_p_hidden, dropout_p_embed=self.dropout_p_embed,
             sample_store=int(sample_store), seed=int(self.seed) + 7919 * rank, device=int(self.device),
@@ -333,8 +332,8 @@ class GRU4Rec:
         self._model = self._create_model(sample_store)
         m = self._model
         self._upload_weights(m)
-        if self.n_sample and m.sample_store_rows() == 0:
-            print('No example store was used')
+        if self.n_sample and m.sample_store_rows() <= 1:
+            print('No example store was used')      # negatives are then drawn anew for every step (gru4rec.py:548-550,614-615)
         lq_t = lq_s = None
         if self.logq:
             p0 = support.astype(np.float32)
@@ -344,7 +343,7 @@ class GRU4Rec:
         pop = pop.cumsum() / pop.sum()
         pop[-1] = 1
         m.set_popularity(pop.astype(np.float32), lq_t, lq_s)
-        if self.n_sample and m.sample_store_rows() > 0:
+        if self.n_sample and m.sample_store_rows() > 1:
             print('Created sample store with {} batches of samples (type=GPU)'.format(m.sample_store_rows()))
         if self.time_sort:
             # data is ordered by (session, time): a session's first row holds its minimum time (the groupby().min() of

@@ -1,7 +1,8 @@
 """Deterministic RSC15-*shaped* synthetic click-stream generator (no datasets ship with this repo).
 
 Shape targets: I = 37,483 items, session length 2 + Geometric(p=0.34) clipped at
-200 (mean ~3.9), Zipf-like item popularity, and a first-order Markov structure (every item has a handful
+200 (mean ~3.9), Zipf-Mandelbrot item popularity p(rank) ~ (rank + 27)^-1 (the most popular item holds ~0.5 % of the
+events, as in RSC15; a pure Zipf(1.0) head would give it 9 %), and a first-order Markov structure (every item has a handful
 of preferred successors) so that Recall@20 is learnable and sensitive to bugs.  Session start times
 increase with the session id; events inside a session are 1..60 s apart.
 """
@@ -10,13 +11,13 @@ import pandas as pd
 
 
 def make_sessions(n_sessions, n_items=37483, seed=42, p_len=0.34, max_len=200, n_succ=10, p_follow=0.75,
-                  zipf_s=1.0):
+                  zipf_s=1.0, zipf_q=27.0):
     """Return a DataFrame with columns SessionId (int32), ItemId (int64), Time (int64), sorted by session, time."""
     rng = np.random.RandomState(seed)
     lens = np.minimum(2 + rng.geometric(p_len, size=n_sessions) - 1, max_len).astype(np.int64)
     n_events = int(lens.sum())
     ranks = np.arange(1, n_items + 1, dtype=np.float64)
-    pop = ranks ** (-zipf_s)
+    pop = (ranks + zipf_q) ** (-zipf_s)
     pop /= pop.sum()
     cum = np.cumsum(pop)
     cum[-1] = 1.0

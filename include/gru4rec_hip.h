@@ -39,7 +39,9 @@ enum { G4R_EMBED_CONSTRAINED = 0 /* Wy shared, :438-448 */, G4R_EMBED_SEPARATE =
 /* gru4rec.py:392-399,411-418: learning-rate adaptation (`adapt`); NONE = plain SGD */
 enum { G4R_ADAPT_ADAGRAD = 0, G4R_ADAPT_RMSPROP = 1, G4R_ADAPT_ADADELTA = 2, G4R_ADAPT_ADAM = 3, G4R_ADAPT_NONE = 4 };
 /* evaluation.py:62-65 */
-enum { G4R_RANK_STANDARD = 0, G4R_RANK_CONSERVATIVE = 1, G4R_RANK_MEDIAN = 2 };
+enum { G4R_RANK_STANDARD = 0, G4R_RANK_CONSERVATIVE = 1, G4R_RANK_MEDIAN = 2,
+       G4R_RANK_TIEBREAKING = 3 /* :55: scores + uniform * 1e-10 in fp32 (Philox stream keyed by the model seed, the evaluation step,
+       row and candidate column instead of the reference's MRG stream), then ranked as STANDARD */ };
 
 /* Constructor arguments of the reference's GRU4Rec (gru4rec.py:97-135) that the hot path needs. */
 typedef struct g4r_config {
@@ -127,9 +129,9 @@ int g4r_reset_hidden(g4r_model* m);
 /* ---- prediction: replaces the compiled `self.predict` / evaluate functions --------------------- */
 /* gru4rec.py:691-711 (+ symbolic_predict :729-741): allocate prediction state for `batch` rows */
 int g4r_predict_begin(g4r_model* m, int32_t batch);
-/* zero rows where zero_mask != 0, then keep rows in `keep_rows` order (NULL = identity), evaluation.py:134-139,
- * gru4rec.py:712-717 */
-int g4r_predict_hidden(g4r_model* m, const uint8_t* zero_mask, const int32_t* keep_rows, int32_t n_keep);
+/* zero rows where zero_mask[0..n_mask) != 0 (n_mask <= batch of g4r_predict_begin; later rows keep their state), then keep
+ * rows in `keep_rows` order (NULL = identity), evaluation.py:134-139, gru4rec.py:712-717 */
+int g4r_predict_hidden(g4r_model* m, const uint8_t* zero_mask, int32_t n_mask, const int32_t* keep_rows, int32_t n_keep);
 /* forward only; scores[m, n_sel] = final_act(h Wy[item_idx]^T + By) (all items if item_idx NULL); out may be NULL */
 int g4r_predict_step(g4r_model* m, const int32_t* in_idx, int32_t mrows, const int32_t* item_idx, int64_t n_sel,
                      float* out_scores);

@@ -98,11 +98,13 @@ def oracle_evaluate(model, itemidmap, test_data, cut_off=(20,), batch_size=100, 
     rec = np.zeros(len(cut_off))
     mrr = np.zeros(len(cut_off))
     n = 0
+    step = 0
     for ev in eval_schedule(offs, titems, batch_size):
         if ev[0] == 'step':
             _, cur_in, cur_out, M = ev
             yhat, H = model.predict_step(H, cur_in)
-            ranks = ranks_from_scores(yhat, cur_out, mode)
+            ranks = ranks_from_scores(yhat, cur_out, mode, tie=(model.seed, step))
+            step += 1
             for j, c in enumerate(cut_off):
                 hit = ranks <= c
                 rec[j] += hit.sum()

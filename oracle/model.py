@@ -302,10 +302,13 @@ class OracleGRU4Rec:
         return out
 
     def make_sample_store(self, sample_store):
-        """gru4rec.py:546-566: ST[generate_length, n_sample]; uniforms from Philox instead of MRG."""
+        """gru4rec.py:546-566: ST[generate_length, n_sample]; uniforms from Philox instead of MRG.  A store that cannot hold
+        two rows means "no store": a fresh row of negatives is drawn for every step (gru4rec.py:548-550,614-615), which is a
+        one-row store refilled before every step."""
         self.generate_length = sample_store // self.n_sample if self.n_sample else 0
         self.n_refills = 0
-        if self.n_sample and self.generate_length > 1:
+        if self.n_sample:
+            self.generate_length = max(self.generate_length, 1)
             self._refill()
         else:
             self.ST = None
@@ -601,8 +604,15 @@ class OracleGRU4Rec:
         return yhat, newH
 
 
-def ranks_from_scores(yhat, target_cols, mode='standard'):
-    """evaluation.py:56-65 for the all-items case: yhat[M, I], target_cols[M]."""
+def ranks_from_scores(yhat, target_cols, mode='standard', tie=None):
+    """evaluation.py:55-65 for the all-items case: yhat[M, I], target_cols[M].  mode 'tiebreaking' adds uniform * 1e-10 to
+    every score in float32 (:55) and ranks as 'standard'; `tie` = (seed, step counter) of the Philox stream that stands in
+    for the reference's MRG stream (only scores below ~2e-3 in magnitude are moved by it at all)."""
+    if mode == 'tiebreaking':
+        seed, ctr = tie
+        u = philox.uniform_rows(yhat.shape[0], yhat.shape[1], seed, ctr, philox.STREAM_TIEBREAK)
+        yhat = (yhat.astype(np.float32) + u * np.float32(1e-10)).astype(np.float32)
+        mode = 'standard'
     t = yhat[np.arange(len(target_cols)), target_cols][:, None]
     gt = (yhat > t).sum(axis=1)
     if mode == 'standard':

@@ -22,6 +22,7 @@ _MASK = np.uint64(0xFFFFFFFF)
 STREAM_SAMPLE = 0x53414D50   # 'SAMP'
 STREAM_DROP_EMBED = 0x44454D42  # 'DEMB'
 STREAM_DROP_HIDDEN = 0x44484944  # 'DHID' (+ layer index)
+STREAM_TIEBREAK = 0x54494542  # 'TIEB': evaluation mode 'tiebreaking' (evaluation.py:55)
 
 
 def philox4x32_10(c0, c1, c2, c3, k0, k1):
@@ -66,6 +67,17 @@ def uniform_block(n, seed, c1, c2, stream):
                       seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     out = np.stack(r, axis=1).reshape(-1)[:n]
     return u32_to_unit_float(out)
+
+
+def uniform_rows(rows, cols, seed, step, stream):
+    """float32 uniforms of shape (rows, cols): element (row, col) comes from Philox call
+    (c0 = col>>2, c1 = row, c2 = step, c3 = stream), lane col&3."""
+    ncall = (cols + 3) // 4
+    c0 = np.arange(ncall, dtype=np.uint32)[None, :]
+    c1 = np.arange(rows, dtype=np.uint32)[:, None]
+    r = philox4x32_10(c0, c1, np.uint32(step & 0xFFFFFFFF), np.uint32(stream & 0xFFFFFFFF),
+                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    return u32_to_unit_float(np.stack(r, axis=2).reshape(rows, ncall * 4)[:, :cols])
 
 
 def dropout_mask(rows, cols, retain, seed, step, stream):

@@ -68,7 +68,7 @@ def read_events(fname, opts, model_cls=None):
         present = set(table.columns)
     else:
         with open(fname, 'rt') as fh:
-            present = set(fh.readline().rstrip('\n').split('\t'))
+            present = set(fh.readline().rstrip('\r\n').split('\t'))
     for what, column, default in wanted:
         if column not in present:
             fail_missing_column(what, column, default, fname)

@@ -30,7 +30,7 @@ def trained_elementwise(request):
     return gru, test
 
 
-@pytest.mark.parametrize('mode', ['standard', 'conservative', 'median'])
+@pytest.mark.parametrize('mode', ['standard', 'conservative', 'median', 'tiebreaking'])
 @pytest.mark.parametrize('batch', [5, 130])
 def test_streaming_ranks_equal_materialised_ranks(trained_elementwise, mode, batch):
     gru, test = trained_elementwise
@@ -45,7 +45,7 @@ def test_streaming_ranks_equal_materialised_ranks(trained_elementwise, mode, bat
     np.testing.assert_allclose(a[1], b[1], rtol=1e-6, atol=1e-9)
 
 
-@pytest.mark.parametrize('mode', ['standard', 'conservative', 'median'])
+@pytest.mark.parametrize('mode', ['standard', 'conservative', 'median', 'tiebreaking'])
 @pytest.mark.parametrize('batch', [7, 50])
 def test_one_call_equals_stepwise_all_items(trained, mode, batch):
     gru, test = trained

@@ -61,14 +61,20 @@ def test_reference_paramfiles_load(tmp_path):
 
 def test_out_of_scope_options_fail_loudly_at_fit():
     data = synth.make_sessions(50, n_items=30, seed=1)
-    for kw in (dict(adapt='nadam', constrained_embedding=True),
-               dict(smoothing=0.1, loss='bpr-max', constrained_embedding=True),
+    for kw in (dict(smoothing=0.1, loss='bpr-max', constrained_embedding=True),
                dict(layers=[256])):   # last: one-hot input wider than the 512-float row limit
         kw.setdefault('layers', [8])
         g = GRU4Rec(batch_size=4, **kw)
         g.n_items = 30
         with pytest.raises(NotImplementedError):
             g._check_supported()
+
+
+def test_unknown_adapt_means_plain_sgd_like_the_reference():
+    """gru4rec.py:392-399,411-418: any `adapt` other than the four known names falls through to the unscaled gradient."""
+    g = GRU4Rec(layers=[8], batch_size=4, adapt='sgd', constrained_embedding=True)
+    g._check_supported()
+    assert _native.ADAPT_IDS.get(g.adapt, _native.ADAPT_IDS[None]) == _native.ADAPT_IDS[None]
 
 
 def test_fit_without_gpu_raises_not_falls_back():
