@@ -185,6 +185,29 @@ def cpu_baseline(cfg, plan, support, budget_s=15.0):
                 events_per_s=ev / dt, host_cpus=os.cpu_count())
 
 
+def spawn_ranks(n):
+    """One process per GPU on this node (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, rendezvous on 127.0.0.1);
+    rank 0's JSON line is this process's output.  Returns the exit code (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for r, p in enumerate(procs):
+        code = p.wait()
+        if code != 0:
+            sys.stderr.write('bench.py: rank %d exited with code %d\n' % (r, code))
+            rc = rc or code or 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -196,14 +219,19 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one process per GPU, as torch.distributed.run would)
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit('WORLD_SIZE (%d) != --gpus (%d)' % (world, args.gpus))
     from gru4rec_amd import _native
     if _native.device_count() <= 0:
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    if world > 1 and _native.device_count() <= local_rank:
+        raise SystemExit('rank %d: LOCAL_RANK %d but only %d GPU(s) visible' % (rank, local_rank, _native.device_count()))
     dist = None
     unique_id = None
     if world > 1:
@@ -221,6 +249,9 @@ def main():
     assert plan['T'] >= total_steps, 'synthetic plan too short: %d < %d' % (plan['T'], total_steps)
     assert (plan['M'][:total_steps] == cfg['batch_size']).all()
     m = create_model(cfg, support, rank, world, local_rank if world > 1 else 0, unique_id, use_graph=not args.no_graph)
+    n_ranks = m.comm_nranks()      # what RCCL reports for the communicator (1 without one): n_gpus in the output is THIS number
+    if n_ranks != world:
+        raise SystemExit('RCCL communicator has %d rank(s), expected %d' % (n_ranks, world))
     for k in ('in_idx', 'out_idx', 'reset', 'M'):
         plan[k] = plan[k][:total_steps]
     plan['T'] = total_steps
@@ -247,7 +278,7 @@ def main():
     out = {
         'metric': 'mini-batches/sec (gru4rec.py:661), RSC15-shaped batch=128 n_sample=2048 BPR-max' if args.config == 'cfg2'
         else 'mini-batches/sec (gru4rec.py:661), %s: batch=%d n_sample=%d %s' % (args.config, cfg['batch_size'], cfg['n_sample'], cfg['loss']),
-        'value': args.steps * world / dt, 'unit': 'mini-batches/s', 'n_gpus': world, 'steps': args.steps,
+        'value': args.steps * world / dt, 'unit': 'mini-batches/s', 'n_gpus': n_ranks, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': (args.steps * world / dt) / A30_PUBLISHED_MBS if args.config == 'cfg2' else None,
         'baseline_note': 'BASELINE.md: ~1240 mb/s, Theano on an NVIDIA A30 (closest published point; no MI355X number exists)',

@@ -41,9 +41,9 @@ SYMBOLS = [
     'g4r_device_count', 'g4r_last_error', 'g4r_version', 'g4r_sizeof_config', 'g4r_create', 'g4r_destroy', 'g4r_set_param',
     'g4r_get_param', 'g4r_set_popularity', 'g4r_set_sample_store', 'g4r_get_sample_store',
     'g4r_sample_store_rows', 'g4r_build_plan', 'g4r_set_plan', 'g4r_train_steps', 'g4r_get_losses',
-    'g4r_synchronize', 'g4r_global_step', 'g4r_kernel_time', 'g4r_profile', 'g4r_reset_hidden',
+    'g4r_synchronize', 'g4r_global_step', 'g4r_refills', 'g4r_set_step_counters', 'g4r_kernel_time', 'g4r_profile', 'g4r_reset_hidden',
     'g4r_predict_begin', 'g4r_predict_hidden', 'g4r_predict_step', 'g4r_rank_targets', 'g4r_evaluate', 'g4r_comm_unique_id',
-    'g4r_comm_init', 'g4r_comm_sync_sparse', 'g4r_comm_min_i64', 'g4r_get_debug', 'g4r_selftest_mfma',
+    'g4r_comm_init', 'g4r_comm_sync_sparse', 'g4r_comm_min_i64', 'g4r_comm_max_i64', 'g4r_comm_nranks', 'g4r_sync_enable', 'g4r_sync_row_floats', 'g4r_sync_export', 'g4r_sync_import', 'g4r_get_debug', 'g4r_selftest_mfma',
     'g4r_events_load', 'g4r_events_rows', 'g4r_events_items', 'g4r_events_item_bytes', 'g4r_events_time_kind',
     'g4r_events_copy', 'g4r_events_free',
 ]
@@ -87,6 +87,8 @@ def lib():
     L.g4r_synchronize.argtypes = [vp]
     L.g4r_global_step.argtypes = [vp]
     L.g4r_global_step.restype = i64
+    L.g4r_refills.argtypes, L.g4r_refills.restype = [vp], i64
+    L.g4r_set_step_counters.argtypes = [vp, i64, i64]
     L.g4r_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), i64p]
     L.g4r_profile.argtypes = [vp, i32]
     L.g4r_reset_hidden.argtypes = [vp]
@@ -100,6 +102,12 @@ def lib():
     L.g4r_comm_init.argtypes = [vp, C.c_char_p, i32, i32]
     L.g4r_comm_sync_sparse.argtypes = [vp]
     L.g4r_comm_min_i64.argtypes = [vp, i64p]
+    L.g4r_comm_max_i64.argtypes = [vp, i64p]
+    L.g4r_comm_nranks.argtypes = [vp]
+    L.g4r_sync_enable.argtypes = [vp]
+    L.g4r_sync_row_floats.argtypes, L.g4r_sync_row_floats.restype = [vp, i32], i64
+    L.g4r_sync_export.argtypes, L.g4r_sync_export.restype = [vp, i32, i32p, f32p, i64], i64
+    L.g4r_sync_import.argtypes = [vp, i32, i32, i64p, C.POINTER(i32p), C.POINTER(f32p)]
     L.g4r_get_debug.argtypes = [vp, C.c_char_p, f32p, i64]
     L.g4r_selftest_mfma.argtypes = [f32p]
     L.g4r_events_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, i32, C.POINTER(vp)]
@@ -303,6 +311,12 @@ class Model:
     def global_step(self):
         return int(lib().g4r_global_step(self.h))
 
+    def refills(self):
+        return int(lib().g4r_refills(self.h))
+
+    def set_step_counters(self, global_step, refills):
+        _chk(lib().g4r_set_step_counters(self.h, int(global_step), int(refills)))
+
     def profile(self, enable):
         _chk(lib().g4r_profile(self.h, 1 if enable else 0))
 
@@ -370,10 +384,46 @@ class Model:
     def comm_sync_sparse(self):
         _chk(lib().g4r_comm_sync_sparse(self.h))
 
+    def sync_enable(self):
+        _chk(lib().g4r_sync_enable(self.h))
+
+    def sync_export(self, group=0):
+        """(sorted ids int32[n], delta rows float32[n * row_floats] plane after plane) of the rows touched since the last sync."""
+        n = int(lib().g4r_sync_export(self.h, group, None, None, 0))
+        if n < 0:
+            raise NativeError(lib().g4r_last_error().decode())
+        w = int(lib().g4r_sync_row_floats(self.h, group))
+        ids = np.empty(n, dtype=np.int32)
+        rows = np.empty(n * w, dtype=np.float32)
+        if lib().g4r_sync_export(self.h, group, _i32(ids), _f32(rows), n) != n:
+            raise NativeError(lib().g4r_last_error().decode())
+        return ids, rows
+
+    def sync_import(self, parts, group=0):
+        """parts: [(ids, rows)] of ALL ranks in rank order."""
+        n = len(parts)
+        counts = np.array([len(p[0]) for p in parts], dtype=np.int64)
+        ids = [np.ascontiguousarray(p[0], dtype=np.int32) for p in parts]
+        rows = [np.ascontiguousarray(p[1], dtype=np.float32) for p in parts]
+        pi = (C.POINTER(C.c_int32) * n)(*[_i32(a) for a in ids])
+        pr = (C.POINTER(C.c_float) * n)(*[_f32(a) for a in rows])
+        _chk(lib().g4r_sync_import(self.h, group, n, _i64(counts), pi, pr))
+
     def comm_min(self, value):
         v = C.c_int64(int(value))
         _chk(lib().g4r_comm_min_i64(self.h, C.byref(v)))
         return int(v.value)
+
+    def comm_max(self, value):
+        v = C.c_int64(int(value))
+        _chk(lib().g4r_comm_max_i64(self.h, C.byref(v)))
+        return int(v.value)
+
+    def comm_nranks(self):
+        n = int(lib().g4r_comm_nranks(self.h))
+        if n < 0:
+            raise NativeError(lib().g4r_last_error().decode())
+        return n
 
 
 def comm_unique_id():

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "g4r_eval_kernels.cuh"
+#include "g4r_sync_kernels.cuh"
 
 // Host code below is compiled in the host pass only: on the device pass the descriptor pointer fields are
 // address-space qualified (g4r_device.cuh) and the template kernels are instantiated explicitly.
@@ -78,8 +79,9 @@ struct g4r_model {
     float* d_tmpH = nullptr;
     // graph
     hipGraphExec_t gexec = nullptr;
-    hipGraphExec_t gexec_head = nullptr;         // N > 1: one step's kernels up to the dense gradients (RCCL stays eager)
+    hipGraphExec_t gexec_head = nullptr;         // N > 1 fallback: one step's kernels up to the dense gradients, RCCL eager behind it
     int graph_steps = 0;
+    bool dist_graph_failed = false;              // capturing the step with its RCCL all-reduce did not work: head graph + eager tail
     // profiling
     bool profiling = false;
     double kn_ms[KN_COUNT] = {0};
@@ -99,6 +101,12 @@ struct g4r_model {
     // rccl
     ncclComm_t comm = nullptr;
     bool comm_ready = false;
+    // reconciliation of the GPU-local item tables (g4r_sync_kernels.cuh): per table group (0: Wy / By rows, 1: E rows) the
+    // planes (current values, common base, row width) and scratch
+    struct SyncPlane { float* cur; float* base; int W; };
+    std::vector<SyncPlane> planes[2];
+    unsigned char* d_touched = nullptr;
+    bool sync_on = false;
 };
 
 template <class T>
@@ -416,6 +424,9 @@ int g4r_set_param(g4r_model* m, const char* name, int32_t layer, const float* ho
     if (locate(m, name, layer, &p, &n)) return -1;
     if (n != count) return fail(std::string("size mismatch for ") + name);
     HIPCHK(hipMemcpyAsync(p, host, n * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    for (int g = 0; g < 2; ++g)      // a table set from the host is the new common base of its rows
+        for (auto& pl : m->planes[g])
+            if (pl.cur == p) HIPCHK(hipMemcpyAsync(pl.base, host, n * sizeof(float), hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     return 0;
 }
@@ -541,6 +552,7 @@ int64_t g4r_build_plan(const int32_t* off, int64_t n_sessions, const int64_t* or
 
 static int ensure_graph(g4r_model* m);
 static int ensure_head_graph(g4r_model* m);
+static int ensure_step_graph(g4r_model* m, bool* whole);
 
 int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, const uint8_t* reset, const int32_t* M,
                  int64_t T, const int64_t* compact_steps, const int32_t* compact_maps, int64_t n_compact) {
@@ -571,7 +583,7 @@ int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
         m->loss_cap = T;
     }
     for (int64_t t = 0; t < T; ++t)
-        if (M[t] < 1 || M[t] > B) return fail("plan M out of range");
+        if (M[t] < 0 || M[t] > B) return fail("plan M out of range");      // 0 = padding step (multi-rank plans of unequal length)
     m->T = T;
     m->dm.in_idx = m->d_in; m->dm.out_idx = m->d_out; m->dm.reset = m->d_reset; m->dm.Mplan = m->d_M;
     m->dm.loss_steps = m->d_loss;
@@ -579,9 +591,10 @@ int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
     if (sync_dm(m)) return -1;
     // capture + instantiate the step graph now (capturing executes nothing): the first timed steps of a short run must not
     // pay the ~10 ms of graph construction
-    if (m->cfg.use_graph && !m->profiling && !getenv("G4R_TRACE")) {
-        if (m->dm.apply_dense_inplace ? ensure_graph(m) : ensure_head_graph(m)) return -1;
-        hipGraphExec_t ge = m->dm.apply_dense_inplace ? m->gexec : m->gexec_head;
+    if (m->cfg.use_graph && !m->profiling && !getenv("G4R_TRACE") && (m->dm.apply_dense_inplace || m->comm_ready)) {
+        bool whole = false;
+        if (ensure_step_graph(m, &whole)) return -1;
+        hipGraphExec_t ge = whole ? m->gexec : m->gexec_head;
         if (ge) (void)hipGraphUpload(ge, m->stream);
     }
     return 0;
@@ -757,17 +770,49 @@ static int apply_compaction(g4r_model* m, int64_t ci) {
 }
 
 #define G4R_GRAPH_STEPS 16
+// N > 1 (or the one-rank staged mode): the all-reduce is captured with the step, so that a replay covers 16 whole steps
+// (kernels, RCCL all-reduce, dense apply) with no host work in between; G4R_RCCL_EAGER=1 keeps RCCL out of the graph
+static inline bool dist_graph_wanted(const g4r_model* m) {
+    static const bool eager = getenv("G4R_RCCL_EAGER") != nullptr;
+    return !m->dm.apply_dense_inplace && !eager && !m->dist_graph_failed && m->comm_ready && !getenv("G4R_OVERLAP");
+}
 static int ensure_graph(g4r_model* m) {
     if (m->gexec) return 0;
-    hipGraph_t graph;
-    HIPCHK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < G4R_GRAPH_STEPS; ++i)
-        if (launch_step(m, nullptr)) { hipGraph_t g2; (void)hipStreamEndCapture(m->stream, &g2); return -1; }
-    HIPCHK(hipStreamEndCapture(m->stream, &graph));
-    HIPCHK(hipGraphInstantiate(&m->gexec, graph, nullptr, nullptr, 0));
+    const bool dist = !m->dm.apply_dense_inplace;
+    if (dist) {
+        // RCCL sets its channels up on first use: that must not happen inside a capture (dense_g is scratch between steps)
+        NCCLCHK(ncclAllReduce(m->dm.dense_g, m->dm.dense_g, m->dm.dense_count, ncclFloat, ncclSum, m->comm, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+    }
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(m->stream, dist ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
+    int rc = 0;
+    for (int i = 0; i < G4R_GRAPH_STEPS && !rc; ++i) rc = launch_step(m, nullptr);
+    hipError_t e = hipStreamEndCapture(m->stream, &graph);
+    if (rc || e != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        if (!rc) fail(std::string("graph capture: ") + hipGetErrorString(e));
+        return -1;
+    }
+    e = hipGraphInstantiate(&m->gexec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { m->gexec = nullptr; (void)hipGetLastError(); return fail(std::string("graph instantiate: ") + hipGetErrorString(e)); }
     m->graph_steps = G4R_GRAPH_STEPS;
     return 0;
+}
+// the step graph for this model: the whole step (single GPU; N > 1 with RCCL captured), or -- if RCCL cannot be captured on this
+// runtime -- the head graph with an eager tail.  Returns 0 / -1; *whole tells which one is ready.
+static int ensure_head_graph(g4r_model* m);
+static int ensure_step_graph(g4r_model* m, bool* whole) {
+    if (m->dm.apply_dense_inplace) { *whole = true; return ensure_graph(m); }
+    if (dist_graph_wanted(m)) {
+        if (ensure_graph(m) == 0) { *whole = true; return 0; }
+        m->dist_graph_failed = true;
+        fprintf(stderr, "[g4r] RCCL all-reduce could not be captured into the step graph (%s); launching it eagerly\n", g_err.c_str());
+    }
+    *whole = false;
+    return ensure_head_graph(m);
 }
 
 static int ensure_head_graph(g4r_model* m) {
@@ -788,7 +833,12 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
     if (m->dm.ns > 0 && !m->have_pop && !m->store_frozen) return fail("negative sampling needs g4r_set_popularity first");
     HIPCHK(hipSetDevice(m->cfg.device));
     hipLaunchKernelGGL(k_set_state, dim3(1), dim3(512), 0, m->stream, (const DevModel*)m->d_dm, (StepState*)m->dm.st, (long long)t0, (long long)m->gstep);
-    const bool use_graph = m->cfg.use_graph && !m->profiling && m->dm.apply_dense_inplace;
+    bool use_graph = m->cfg.use_graph && !m->profiling && !getenv("G4R_TRACE") && (m->dm.apply_dense_inplace || dist_graph_wanted(m));
+    if (use_graph && !m->dm.apply_dense_inplace) {
+        bool whole = false;
+        if (ensure_step_graph(m, &whole)) return -1;
+        use_graph = whole;
+    }
     size_t ci = std::lower_bound(m->compact_steps.begin(), m->compact_steps.end(), t0) - m->compact_steps.begin();
     int64_t t = t0;
     const int64_t tend = t0 + n_steps;
@@ -852,6 +902,25 @@ int g4r_synchronize(g4r_model* m) {
     return 0;
 }
 int64_t g4r_global_step(g4r_model* m) { return m ? m->gstep : -1; }
+int64_t g4r_refills(g4r_model* m) { return m ? (int64_t)m->refills : -1; }
+// resume: continue the counter-based random streams (dropout masks are keyed by the global step, the sample store by its refill
+// number) where a checkpointed run stopped; the store is regenerated as that run's last refill left it
+int g4r_set_step_counters(g4r_model* m, int64_t global_step, int64_t refills) {
+    if (!m) return fail("null model");
+    if (global_step < 0 || refills < 0) return fail("negative counter");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    m->gstep = global_step;
+    if (m->dm.ns > 0 && !m->store_frozen) {
+        if (!m->have_pop) return fail("g4r_set_popularity first");
+        if (refills < 1) return fail("a model with negative sampling has filled its store at least once");
+        m->refills = (unsigned)(refills - 1);
+        if (refill_store(m)) return -1;
+        HIPCHK(hipStreamSynchronize(m->stream));
+    } else {
+        m->refills = (unsigned)refills;
+    }
+    return 0;
+}
 int g4r_profile(g4r_model* m, int32_t enable) {
     if (!m) return fail("null model");
     m->profiling = enable != 0;
@@ -1165,14 +1234,9 @@ int g4r_comm_init(g4r_model* m, const char* id128, int32_t nranks, int32_t rank)
     NCCLCHK(ncclCommInitRank(&m->comm, nranks, id, rank));
     fflush(stdout);      // RCCL's version banner must not surface after the caller's own output at exit
     m->comm_ready = true;
-    return 0;
+    return g4r_sync_enable(m);      // base snapshot of the item tables as they are now (g4r_set_param keeps it in step)
 }
-static int allreduce_avg(g4r_model* m, float* p, long long n) {
-    NCCLCHK(ncclAllReduce(p, p, n, ncclFloat, ncclSum, m->comm, m->stream));
-    hipLaunchKernelGGL(k_scale, dim3(cdiv(n, 256)), dim3(256), 0, m->stream, p, n, 1.0f / (float)m->cfg.nranks);
-    return 0;
-}
-int g4r_comm_min_i64(g4r_model* m, int64_t* value) {
+static int comm_reduce_i64(g4r_model* m, int64_t* value, ncclRedOp_t op) {
     if (!m || !value) return fail("null argument");
     if (m->cfg.nranks <= 1 && !m->comm_ready) return 0;
     if (!m->comm_ready) return fail("g4r_comm_init first");
@@ -1180,25 +1244,245 @@ int g4r_comm_min_i64(g4r_model* m, int64_t* value) {
     long long* d = nullptr;
     HIPCHK(hipMalloc((void**)&d, sizeof(long long)));
     HIPCHK(hipMemcpyAsync(d, value, sizeof(long long), hipMemcpyHostToDevice, m->stream));
-    ncclResult_t r = ncclAllReduce(d, d, 1, ncclInt64, ncclMin, m->comm, m->stream);
+    ncclResult_t r = ncclAllReduce(d, d, 1, ncclInt64, op, m->comm, m->stream);
     if (r != ncclSuccess) { (void)hipFree(d); return fail(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); }
     HIPCHK(hipMemcpyAsync(value, d, sizeof(long long), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     (void)hipFree(d);
     return 0;
 }
+int g4r_comm_min_i64(g4r_model* m, int64_t* value) { return comm_reduce_i64(m, value, ncclMin); }
+int g4r_comm_max_i64(g4r_model* m, int64_t* value) { return comm_reduce_i64(m, value, ncclMax); }
+int g4r_comm_nranks(g4r_model* m) {
+    if (!m) { fail("null model"); return -1; }
+    if (!m->comm_ready) return 1;
+    int n = 0;
+    if (ncclCommCount(m->comm, &n) != ncclSuccess) { fail("ncclCommCount failed"); return -1; }
+    return n;
+}
+// ---- reconciliation of the GPU-local item tables ------------------------------------------------------------
+static inline int nblk256(long long n) { return (int)((n + 255) / 256); }
+
+int g4r_sync_enable(g4r_model* m) {
+    if (!m) return fail("null model");
+    if (m->sync_on) return 0;
+    HIPCHK(hipSetDevice(m->cfg.device));
+    DevModel& d = m->dm;
+    const size_t I = d.n_items;
+    const int tables = d.E ? 2 : 1;
+    auto add = [&](int g, float* cur, int W) -> int {
+        if (!cur) return 0;
+        float* base = nullptr;
+        if (dalloc(m, &base, I * (size_t)W, false)) return -1;
+        if (hipMemcpyAsync(base, cur, I * (size_t)W * sizeof(float), hipMemcpyDeviceToDevice, m->stream) != hipSuccess) return fail("base snapshot");
+        m->planes[g].push_back({cur, base, W});
+        return 0;
+    };
+    if (add(0, d.Wy, d.Dtop) || add(0, d.accWy, d.Dtop) || add(0, d.velWy, d.Dtop) || add(0, d.acc2Wy, d.Dtop) || add(0, d.cntWy, d.Dtop) ||
+        add(0, d.By, 1) || add(0, d.accBy, 1) || add(0, d.velBy, 1) || add(0, d.acc2By, 1) || add(0, d.cntBy, 1))
+        return -1;
+    if (d.E && (add(1, d.E, d.Ein) || add(1, d.accE, d.Ein) || add(1, d.velE, d.Ein) || add(1, d.acc2E, d.Ein) || add(1, d.cntE, d.Ein))) return -1;
+    if (dalloc(m, &m->d_touched, (size_t)tables * I, true)) return -1;
+    d.touched = m->d_touched;
+    m->sync_on = true;
+    return sync_dm(m);
+}
+
+// sorted ids of the rows of `group` this rank rewrote since the last reconciliation
+static int sync_local_ids(g4r_model* m, int group, std::vector<int>& ids) {
+    const size_t I = m->dm.n_items;
+    std::vector<unsigned char> t(I);
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipMemcpy(t.data(), m->d_touched + (size_t)group * I, I, hipMemcpyDeviceToHost));
+    ids.clear();
+    for (size_t i = 0; i < I; ++i) if (t[i]) ids.push_back((int)i);
+    return 0;
+}
+int64_t g4r_sync_row_floats(g4r_model* m, int32_t group) {
+    if (!m || group < 0 || group > 1) { fail("bad argument"); return -1; }
+    int64_t w = 0;
+    for (auto& pl : m->planes[group]) w += pl.W;
+    return w;
+}
+// test hook / building block: this rank's part = (sorted ids, per plane the delta rows [n][W_p], planes back to back)
+int64_t g4r_sync_export(g4r_model* m, int32_t group, int32_t* ids_out, float* rows_out, int64_t cap_rows) {
+    if (!m || group < 0 || group > 1) { fail("bad argument"); return -1; }
+    if (!m->sync_on) { fail("g4r_sync_enable first"); return -1; }
+    if (hipSetDevice(m->cfg.device) != hipSuccess) { fail("hipSetDevice"); return -1; }
+    std::vector<int> ids;
+    if (sync_local_ids(m, group, ids)) return -1;
+    const int64_t n = (int64_t)ids.size();
+    if (!ids_out && !rows_out) return n;
+    if (n > cap_rows) { fail("export buffers too small"); return -1; }
+    if (ids_out) memcpy(ids_out, ids.data(), n * sizeof(int));
+    if (rows_out && n > 0) {
+        int* d_ids = nullptr; float* d_out = nullptr;
+        int wmax = 1;
+        for (auto& pl : m->planes[group]) wmax = std::max(wmax, pl.W);
+        if (hipMalloc((void**)&d_ids, n * sizeof(int)) != hipSuccess || hipMalloc((void**)&d_out, (size_t)n * wmax * sizeof(float)) != hipSuccess) {
+            (void)hipFree(d_ids); fail("export scratch"); return -1;
+        }
+        (void)hipMemcpyAsync(d_ids, ids.data(), n * sizeof(int), hipMemcpyHostToDevice, m->stream);
+        float* dst = rows_out;
+        for (auto& pl : m->planes[group]) {
+            hipLaunchKernelGGL(k_sync_pack, dim3(nblk256(n * pl.W)), dim3(256), 0, m->stream, (const float*)pl.cur, (const float*)pl.base, pl.W,
+                               (const int*)d_ids, (long long)n, d_out);
+            (void)hipMemcpyAsync(dst, d_out, (size_t)n * pl.W * sizeof(float), hipMemcpyDeviceToHost, m->stream);
+            (void)hipStreamSynchronize(m->stream);
+            dst += (size_t)n * pl.W;
+        }
+        (void)hipFree(d_ids); (void)hipFree(d_out);
+        if (hipGetLastError() != hipSuccess) { fail("export kernels"); return -1; }
+    }
+    return n;
+}
+// rows of this rank in [lo, hi) of its own sorted list `d_loc` go back to the base, then every part (rank order) is added and
+// the rows of every part become the new base.  All pointers are device pointers; part q has cnt[q] rows.
+static void sync_apply(g4r_model* m, const g4r_model::SyncPlane& pl, const int* d_loc, long long n_loc, int nparts,
+                       const int* const* d_ids, const long long* cnt, const float* const* d_delta) {
+    hipStream_t s = m->stream;
+    if (n_loc > 0) hipLaunchKernelGGL(k_sync_reset, dim3(nblk256(n_loc * pl.W)), dim3(256), 0, s, pl.cur, (const float*)pl.base, pl.W, d_loc, n_loc);
+    for (int q = 0; q < nparts; ++q)
+        if (cnt[q] > 0) hipLaunchKernelGGL(k_sync_add, dim3(nblk256(cnt[q] * pl.W)), dim3(256), 0, s, pl.cur, pl.W, d_ids[q], cnt[q], d_delta[q]);
+    for (int q = 0; q < nparts; ++q)
+        if (cnt[q] > 0) hipLaunchKernelGGL(k_sync_rebase, dim3(nblk256(cnt[q] * pl.W)), dim3(256), 0, s, (const float*)pl.cur, pl.base, pl.W, d_ids[q], cnt[q]);
+}
+// test hook: apply the parts of all ranks (in rank order; this rank's own part included) as g4r_comm_sync_sparse does after its
+// all-gather.  ids[q]: counts[q] sorted item ids; rows[q]: g4r_sync_export layout.
+int g4r_sync_import(g4r_model* m, int32_t group, int32_t nparts, const int64_t* counts, const int32_t* const* ids, const float* const* rows) {
+    if (!m || group < 0 || group > 1 || nparts < 1 || !counts || !ids || !rows) return fail("bad argument");
+    if (!m->sync_on) return fail("g4r_sync_enable first");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    std::vector<int> loc;
+    if (sync_local_ids(m, group, loc)) return -1;
+    const size_t I = m->dm.n_items;
+    std::vector<int*> d_ids(nparts, nullptr);
+    std::vector<float*> d_rows(nparts, nullptr);
+    std::vector<long long> cnt(nparts);
+    int* d_loc = nullptr;
+    const int64_t wsum = g4r_sync_row_floats(m, group);
+    auto cleanup = [&]() { for (auto p : d_ids) (void)hipFree(p); for (auto p : d_rows) (void)hipFree(p); (void)hipFree(d_loc); };
+    if (!loc.empty()) {
+        if (hipMalloc((void**)&d_loc, loc.size() * sizeof(int)) != hipSuccess) { cleanup(); return fail("import scratch"); }
+        (void)hipMemcpyAsync(d_loc, loc.data(), loc.size() * sizeof(int), hipMemcpyHostToDevice, m->stream);
+    }
+    for (int q = 0; q < nparts; ++q) {
+        cnt[q] = counts[q];
+        if (cnt[q] <= 0) continue;
+        for (int64_t j = 0; j < cnt[q]; ++j)
+            if (ids[q][j] < 0 || (size_t)ids[q][j] >= I || (j > 0 && ids[q][j] <= ids[q][j - 1])) { cleanup(); return fail("part ids must be sorted, distinct and in range"); }
+        if (hipMalloc((void**)&d_ids[q], cnt[q] * sizeof(int)) != hipSuccess || hipMalloc((void**)&d_rows[q], (size_t)cnt[q] * wsum * sizeof(float)) != hipSuccess) {
+            cleanup(); return fail("import scratch");
+        }
+        (void)hipMemcpyAsync(d_ids[q], ids[q], cnt[q] * sizeof(int), hipMemcpyHostToDevice, m->stream);
+        (void)hipMemcpyAsync(d_rows[q], rows[q], (size_t)cnt[q] * wsum * sizeof(float), hipMemcpyHostToDevice, m->stream);
+    }
+    std::vector<const float*> dl(nparts);
+    std::vector<size_t> off(nparts, 0);
+    for (auto& pl : m->planes[group]) {
+        for (int q = 0; q < nparts; ++q) dl[q] = d_rows[q] ? d_rows[q] + off[q] : nullptr;
+        sync_apply(m, pl, d_loc, (long long)loc.size(), nparts, (const int* const*)d_ids.data(), cnt.data(), dl.data());
+        for (int q = 0; q < nparts; ++q) off[q] += (size_t)std::max<long long>(cnt[q], 0) * pl.W;
+    }
+    (void)hipMemsetAsync(m->d_touched + (size_t)group * I, 0, I, m->stream);
+    hipError_t e = hipStreamSynchronize(m->stream);
+    cleanup();
+    if (e != hipSuccess || hipGetLastError() != hipSuccess) return fail("import kernels");
+    return 0;
+}
+
+// RCCL path: id lists all-gathered once per group, then the table is walked in item-id ranges; per range every rank packs its
+// delta rows, one all-gather (padded to the largest part of the range) brings all parts, sync_apply adds them in rank order.
+// The traffic follows the number of touched rows, not the table size.
 int g4r_comm_sync_sparse(g4r_model* m) {
     if (!m) return fail("null model");
     if (m->cfg.nranks <= 1 && !m->comm_ready) return 0;
     if (!m->comm_ready) return fail("g4r_comm_init first");
+    if (!m->sync_on) return fail("g4r_sync_enable first");
     HIPCHK(hipSetDevice(m->cfg.device));
     DevModel& d = m->dm;
-    const long long I = d.n_items;
-    if (allreduce_avg(m, d.Wy, I * d.Dtop) || allreduce_avg(m, d.accWy, I * d.Dtop) || allreduce_avg(m, d.By, I) ||
-        allreduce_avg(m, d.accBy, I))
-        return -1;
-    if (d.E && (allreduce_avg(m, d.E, I * d.Ein) || allreduce_avg(m, d.accE, I * d.Ein))) return -1;
-    HIPCHK(hipStreamSynchronize(m->stream));
+    int nr = 1;
+    NCCLCHK(ncclCommCount(m->comm, &nr));
+    const int me = m->cfg.rank;
+    const size_t I = d.n_items;
+    hipStream_t s = m->stream;
+    for (int group = 0; group < 2; ++group) {
+        if (m->planes[group].empty()) continue;
+        std::vector<int> loc;
+        if (sync_local_ids(m, group, loc)) return -1;
+        // counts
+        std::vector<long long> cnt(nr, 0);
+        long long* d_cnt = nullptr;
+        HIPCHK(hipMalloc((void**)&d_cnt, (size_t)(nr + 1) * sizeof(long long)));
+        long long mine = (long long)loc.size();
+        HIPCHK(hipMemcpyAsync(d_cnt + nr, &mine, sizeof(long long), hipMemcpyHostToDevice, s));
+        ncclResult_t r = ncclAllGather(d_cnt + nr, d_cnt, 1, ncclInt64, m->comm, s);
+        if (r != ncclSuccess) { (void)hipFree(d_cnt); return fail(std::string("ncclAllGather: ") + ncclGetErrorString(r)); }
+        HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)nr * sizeof(long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        (void)hipFree(d_cnt);
+        const long long maxn = *std::max_element(cnt.begin(), cnt.end());
+        if (maxn == 0) continue;
+        // id lists: [nr][maxn], padded with INT_MAX so that every list stays sorted
+        int *d_all = nullptr, *d_send = nullptr;
+        HIPCHK(hipMalloc((void**)&d_all, (size_t)nr * maxn * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&d_send, (size_t)maxn * sizeof(int)));
+        std::vector<int> pad(maxn, 0x7fffffff);
+        std::copy(loc.begin(), loc.end(), pad.begin());
+        HIPCHK(hipMemcpyAsync(d_send, pad.data(), (size_t)maxn * sizeof(int), hipMemcpyHostToDevice, s));
+        r = ncclAllGather(d_send, d_all, (size_t)maxn, ncclInt32, m->comm, s);
+        std::vector<int> all((size_t)nr * maxn);
+        if (r == ncclSuccess && hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess &&
+            hipStreamSynchronize(s) == hipSuccess) {
+        } else { (void)hipFree(d_all); (void)hipFree(d_send); return fail("id list all-gather failed"); }
+        (void)hipFree(d_send);
+        int wmax = 1;
+        for (auto& pl : m->planes[group]) wmax = std::max(wmax, pl.W);
+        // item-id ranges: at most `cap` rows per rank and range (bounds the scratch: nr * cap * wmax floats <= ~1 GiB)
+        const long long cap = std::max<long long>(1024, (1LL << 28) / ((long long)nr * wmax));
+        float *d_pack = nullptr, *d_recv = nullptr;
+        const long long rows_cap = std::min<long long>(cap, maxn);
+        if (hipMalloc((void**)&d_pack, (size_t)rows_cap * wmax * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&d_recv, (size_t)nr * rows_cap * wmax * sizeof(float)) != hipSuccess) {
+            (void)hipFree(d_all); (void)hipFree(d_pack); return fail("sync scratch");
+        }
+        std::vector<long long> lo(nr, 0), hi(nr, 0), c(nr);
+        std::vector<const int*> pid(nr);
+        std::vector<const float*> pdl(nr);
+        bool ok = true;
+        for (long long i0 = 0; i0 < (long long)I && ok;) {
+            // the largest id range [i0, i1) in which no rank has more than `cap` rows
+            long long i1 = (long long)I;
+            for (int q = 0; q < nr; ++q)
+                if (lo[q] + cap < cnt[q]) i1 = std::min<long long>(i1, all[(size_t)q * maxn + lo[q] + cap]);
+            long long cmax = 0;
+            for (int q = 0; q < nr; ++q) {
+                const int* b = all.data() + (size_t)q * maxn;
+                hi[q] = std::lower_bound(b + lo[q], b + cnt[q], (int)std::min<long long>(i1, 0x7fffffffLL)) - b;
+                if (i1 >= (long long)I) hi[q] = cnt[q];
+                c[q] = hi[q] - lo[q];
+                cmax = std::max(cmax, c[q]);
+                pid[q] = d_all + (size_t)q * maxn + lo[q];
+            }
+            if (cmax > 0) {
+                for (auto& pl : m->planes[group]) {
+                    if (c[me] > 0)
+                        hipLaunchKernelGGL(k_sync_pack, dim3(nblk256(c[me] * pl.W)), dim3(256), 0, s, (const float*)pl.cur, (const float*)pl.base, pl.W,
+                                           pid[me], c[me], d_pack);
+                    if (ncclAllGather(d_pack, d_recv, (size_t)cmax * pl.W, ncclFloat, m->comm, s) != ncclSuccess) { ok = false; break; }
+                    for (int q = 0; q < nr; ++q) pdl[q] = d_recv + (size_t)q * cmax * pl.W;
+                    sync_apply(m, pl, pid[me], c[me], nr, pid.data(), c.data(), pdl.data());
+                }
+                if (hipStreamSynchronize(s) != hipSuccess) ok = false;
+            }
+            for (int q = 0; q < nr; ++q) lo[q] = hi[q];
+            i0 = i1;
+        }
+        (void)hipFree(d_all); (void)hipFree(d_pack); (void)hipFree(d_recv);
+        if (!ok || hipGetLastError() != hipSuccess) return fail("sparse reconciliation failed");
+        HIPCHK(hipMemsetAsync(m->d_touched + (size_t)group * I, 0, I, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
     return 0;
 }
 
@@ -1231,6 +1515,11 @@ int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
     else if (s == "dbgclk") { if (!d.dbgclk) return fail("G4R_CLK not set"); p = (const float*)d.dbgclk; n = 2 * (64 + 8 * (int64_t)d.R); }
     else if (s == "ldSc") { if (count < 1) return fail("count"); host[0] = (float)d.ldSc; return 0; }
     else if (s == "ksplit") { if (count < 1) return fail("count"); host[0] = (float)d.ksplit; return 0; }
+    else if (s == "graph_mode") {      // 0: no graph yet, 1: whole steps replayed (RCCL captured when N > 1), 2: head graph + eager tail
+        if (count < 1) return fail("count");
+        host[0] = m->gexec ? 1.f : (m->gexec_head ? 2.f : 0.f);
+        return 0;
+    }
     else return fail(std::string("unknown debug buffer ") + name);
     if (count != n) return fail(std::string("size mismatch for debug buffer ") + name + " expected " + std::to_string(n));
     HIPCHK(hipStreamSynchronize(m->stream));

@@ -118,6 +118,9 @@ struct DevModel {
     // with atomics by the kernels that publish occ_idx and zeroed again by the row's owner in k_sparse_update
     // (table 0: Wy / By rows, table 1: separate input embedding E)
     GP(int) occ_fl;
+    // multi-rank runs: [tables][n_items] bytes, set to 1 by the wave that rewrites a row of the item tables (the rows to
+    // reconcile at the next g4r_comm_sync_sparse); null on a single GPU
+    GP(unsigned char) touched;
     // ---- plan + samples
     GP(const int) in_idx; GP(const int) out_idx; GP(const int) Mplan;
     GP(const unsigned char) reset;
@@ -243,25 +246,32 @@ __device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x)
 __device__ __forceinline__ float sigmoidf_(float x) { return frcp(1.0f + fexp(-x)); }
 __device__ __forceinline__ float ftanh(float x) { return 1.0f - 2.0f * frcp(fexp(2.0f * x) + 1.0f); }
 
-// element-wise activations, gru4rec.py:189-223
+// element-wise activations, gru4rec.py:189-223.  The piecewise ones (leaky / elu / selu) have a derivative that jumps at 0, and the
+// reference's T.grad decides on the INPUT (switch on X >= 0).  The backward kernels only have the output, so the forward encodes
+// the branch in the sign bit of a zero result: x < 0 always yields a value with the sign bit set (exp(x) - 1 rounds to +0 for
+// |x| < 6e-8: returned as -0.0), x >= 0 never does.  -0.0 behaves as 0 in every later use; act_bwd_from_out reads the sign bit.
+// (One score in ~2e5 lands in that window at the first step of an RSC15-sized run; deciding on the output there put a factor
+// 1/alpha on one element of d cost / d s, which the training dynamics amplified to 1e-2 relative cost differences 300 steps later.)
+__device__ __forceinline__ float neg_branch(float v) { return v == 0.0f ? -0.0f : v; }
 __device__ __forceinline__ float act_fwd(int kind, float p0, float p1, float x) {
     switch (kind) {
         case G4R_ACT_RELU: return fmaxf(x, 0.0f);
         case G4R_ACT_TANH: return ftanh(x);
-        case G4R_ACT_LEAKY: return x >= 0.0f ? x : p0 * x;
-        case G4R_ACT_ELU: return x >= 0.0f ? x : p0 * (fexp(x) - 1.0f);
-        case G4R_ACT_SELU: return p0 * (x >= 0.0f ? x : p1 * (fexp(x) - 1.0f));
+        case G4R_ACT_LEAKY: return x >= 0.0f ? fabsf(x) : neg_branch(p0 * x);
+        case G4R_ACT_ELU: return x >= 0.0f ? fabsf(x) : neg_branch(p0 * (fexp(x) - 1.0f));
+        case G4R_ACT_SELU: return x >= 0.0f ? p0 * fabsf(x) : neg_branch(p0 * (p1 * (fexp(x) - 1.0f)));
         default: return x;
     }
 }
-// derivative expressed through the OUTPUT y (sign(y) == sign(x) for all of these)
+// derivative expressed through the OUTPUT y (for the piecewise activations the sign BIT of y tells the branch, see above)
 __device__ __forceinline__ float act_bwd_from_out(int kind, float p0, float p1, float y) {
+    const bool pos = !(__builtin_bit_cast(unsigned, y) >> 31);
     switch (kind) {
         case G4R_ACT_RELU: return y > 0.0f ? 1.0f : 0.0f;
         case G4R_ACT_TANH: return 1.0f - y * y;
-        case G4R_ACT_LEAKY: return y >= 0.0f ? 1.0f : p0;
-        case G4R_ACT_ELU: return y >= 0.0f ? 1.0f : y + p0;
-        case G4R_ACT_SELU: return y >= 0.0f ? p0 : y + p0 * p1;
+        case G4R_ACT_LEAKY: return pos ? 1.0f : p0;
+        case G4R_ACT_ELU: return pos ? 1.0f : y + p0;
+        case G4R_ACT_SELU: return pos ? p0 : y + p0 * p1;
         default: return 1.0f;
     }
 }

@@ -36,6 +36,8 @@ __device__ __forceinline__ StepCtx load_ctx(StepState* st_) {
 
 // Stages the inputs of step (t, g) with M active rows: its in_idx row and its column -> item list (gru4rec.py:436-437: the
 // targets of the active rows, then this step's row of the negative-sample store).  All threads of the calling workgroup.
+// M = 0 marks a padding step (ranks of a data-parallel run have plans of different lengths): no column is active, so the step
+// computes zero dense gradients and touches no item row, but still takes part in the all-reduce.
 __device__ __forceinline__ void stage_step_inputs(const DevModel& m, long long t, long long g, int M, int tid, int nth) {
     const int B = m.B, N = m.N, ld = m.ldSc;
     const GAS int* in = m.in_idx + t * B;
@@ -55,7 +57,7 @@ __device__ __forceinline__ void stage_step_inputs(const DevModel& m, long long t
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int n = base + q * nth + tid;
-            if (n < ld) cc[n] = (n < M) ? vo[q] : (n >= B && n < N) ? vs[q] : -1;
+            if (n < ld) cc[n] = (n < M) ? vo[q] : (n >= B && n < N && M > 0) ? vs[q] : -1;      // M = 0: padding step of a multi-rank plan, nothing is touched
         }
     }
 }
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_p1(const DevModel* __restric
     auto aload = [&](int kk, int r, int c) -> float4 {
         const int k = min(kk + c, K - 4);
         const bool isy = k < IN;
-        const int rowc = min(m0 + r, M - 1);      // rows past the batch must not even form an out-of-range address
+        const int rowc = min(m0 + r, max(M - 1, 0));      // rows past the batch must not even form an out-of-range address
         const GAS float* src = isy ? ((l == 0) ? table + (size_t)max(sRow[r], 0) * IN : ysrc + (size_t)rowc * IN)
                                    : Hcur + (size_t)rowc * D;
         return ld4(src + (isy ? k : k - IN));
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(512) void k_gru_fwd_fused(const DevModel* __restric
     }
     // hidden part of the A rows: 16 rows x 32 quad slots
     const int ar = tid >> 5, aq = tid & 31;
-    const int arow = min(m0 + ar, M - 1);
+    const int arow = min(m0 + ar, max(M - 1, 0));
     const float4 ah = ld4(Hcur + (size_t)max(arow, 0) * D + 4 * min(aq, Dq - 1));
     // epilogue operands of this wave's sub-tiles: biases of the r columns (16 wid + li), of the tile's z / c columns
     const int nr = wid * 16 + li;
@@ -1042,7 +1044,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd_fused(const DevModel* __restric
     const GAS float *zl = m.z[l], *cl = m.c[l], *rl = m.r[l];
     GAS float* dV = m.dV[l];
     // ---- requests (clamped addresses, no branches in between)
-    int myrow = m.occ_idx[min(m0 + (tid & 15), M - 1)];
+    int myrow = m.occ_idx[min(m0 + (tid & 15), max(M - 1, 0))];
     if (!(l == 0 && m0 + (tid & 15) < M)) myrow = -1;
     // Wh: 16 rows per pass, one quad of k per thread (32 quad slots per row, Dq <= 28 used)
     constexpr int NP_WH = (BF_MAXD + 15) / 16, NP_WX = (3 * BF_MAXD / 4 + 15) / 16;
@@ -1058,7 +1060,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd_fused(const DevModel* __restric
     // stage-0 operands: 16 rows x 32 quad slots
     const int r0 = tid >> 5, q0 = tid & 31;
     const bool act0 = q0 < Dq;
-    const size_t off0 = (size_t)min(m0 + r0, M - 1) * D + 4 * min(q0, Dq - 1);
+    const size_t off0 = (size_t)min(m0 + r0, max(M - 1, 0)) * D + 4 * min(q0, Dq - 1);
     const int ks = top ? m.ksplit : 1;
     const GAS float* dsrc = (top ? m.dhpart : m.dyl[l]) + off0;
     const size_t ps = (size_t)B * D;
@@ -1553,7 +1555,10 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     const int first_j = max(lo, R - fl.y);
     const bool dup = owner && fl.z > 1;
     const bool hot = owner && fl.z - 1 > UB;
-    if (owner && lane == 0) *(GAS int4*)flp = make_int4(0, 0, 0, 0);
+    if (owner && lane == 0) {
+        *(GAS int4*)flp = make_int4(0, 0, 0, 0);
+        if (m.touched) m.touched[(tableE ? (size_t)nI : 0) + item] = 1;
+    }
     const long long t_own = m.dbgclk ? wall_clock64() : 0;
 
     // scan of sOcc[a, b) for `it`: match number i (ascending) goes to myList[i - 64 * pass]; returns the
@@ -1837,7 +1842,10 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
     GAS int* flp = m.occ_fl + 4 * ((tableE ? (size_t)m.n_items : 0) + item);
     const int4 fl = ldi4(flp);
     if (fl.x != k + 1) return;               // not the last occurrence of the item
-    if (lane == 0) *(GAS int4*)flp = make_int4(0, 0, 0, 0);
+    if (lane == 0) {
+        *(GAS int4*)flp = make_int4(0, 0, 0, 0);
+        if (m.touched) m.touched[(tableE ? (size_t)m.n_items : 0) + item] = 1;
+    }
     const int lo = (constrained || k < B) ? 0 : B;
     const int first_j = max(lo, R - fl.y);
     GAS float *P = tableE ? m.E : m.Wy, *A = tableE ? m.accE : m.accWy, *A2 = tableE ? m.acc2E : m.acc2Wy,

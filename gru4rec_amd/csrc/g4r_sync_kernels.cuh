@@ -1,0 +1,43 @@
+// Multi-rank reconciliation of the GPU-local item tables (Wy / By / E and their optimizer state).  New: the reference is
+// single-GPU; north_star keeps the sparse rows GPU-local between synchronisation points.  Rule: every replica of a table ends at
+//     base + sum over ranks q (in rank order) of (value_q - base)
+// for the rows some rank touched since the last synchronisation (`base` = the common value at that point), i.e. every rank's
+// updates are kept in full (a row only one rank trained receives exactly that rank's update; averaging the replicas would
+// keep 1/nranks of it).  Rows are exchanged as packed (id list, delta rows) parts; the kernels below are shared by the RCCL
+// path (g4r_comm_sync_sparse) and by the host-driven test hooks (g4r_sync_export / g4r_sync_import).
+#pragma once
+#include "g4r_device.cuh"
+
+// out[j][c] = cur[ids[j]][c] - base[ids[j]][c]
+__global__ __launch_bounds__(256) void k_sync_pack(const float* cur, const float* base, int W, const int* ids, long long n, float* out) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * W) return;
+    const long long j = e / W;
+    const int c = (int)(e - j * W);
+    const size_t o = (size_t)ids[j] * W + c;
+    out[e] = cur[o] - base[o];
+}
+// cur[ids[j]] = base[ids[j]]
+__global__ __launch_bounds__(256) void k_sync_reset(float* cur, const float* base, int W, const int* ids, long long n) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * W) return;
+    const long long j = e / W;
+    const size_t o = (size_t)ids[j] * W + (int)(e - j * W);
+    cur[o] = base[o];
+}
+// cur[ids[j]] += delta[j]   (ids of one part are distinct: no two threads meet on an element)
+__global__ __launch_bounds__(256) void k_sync_add(float* cur, int W, const int* ids, long long n, const float* delta) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * W) return;
+    const long long j = e / W;
+    const size_t o = (size_t)ids[j] * W + (int)(e - j * W);
+    cur[o] += delta[e];
+}
+// base[ids[j]] = cur[ids[j]]
+__global__ __launch_bounds__(256) void k_sync_rebase(const float* cur, float* base, int W, const int* ids, long long n) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * W) return;
+    const long long j = e / W;
+    const size_t o = (size_t)ids[j] * W + (int)(e - j * W);
+    base[o] = cur[o];
+}

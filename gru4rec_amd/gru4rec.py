@@ -17,7 +17,7 @@ import numpy as np
 import pandas as pd
 
 from . import _native, datatools, eventio
-from .plan import build_rank_plan
+from .plan import build_rank_plan, pad_plan
 
 _PLAIN_ACTS = ('linear', 'relu', 'tanh', 'softmax')
 
@@ -101,6 +101,8 @@ class GRU4Rec:
         self._model = None
         self._dist = None
         self.loss_history = []
+        self.optimizer_state = None   # filled by savemodel(fname, optimizer_state=True); read by fit(resume=True)
+        self.epochs_done = 0
 
     # ------------------------------------------------------------------ validation of names
     # The reference keeps its loss / activation as bound methods (`self.loss_function = self.bpr_max`, gru4rec.py:136-161)
@@ -295,16 +297,51 @@ class GRU4Rec:
         if not self.constrained_embedding and self.embedding:
             self.E = m.get_param('E', (self.n_items, self.embedding))
 
+    # ---- optimizer state ("plus new optimizer-state save"; the reference's pickles hold the weights only)
+    def _opt_tables(self):
+        """(name, layer, shape) of every optimizer-state array the device keeps for this configuration."""
+        pre = ['acc_']
+        if self.momentum > 0:
+            pre.append('vel_')
+        if self.adapt in ('adadelta', 'adam'):
+            pre.append('acc2_')
+        if self.adapt == 'adam':
+            pre.append('cnt_')
+        if self.adapt not in ('adagrad', 'rmsprop', 'adadelta', 'adam'):
+            pre = [p for p in pre if p == 'vel_']      # plain SGD keeps no statistics
+        out = []
+        L = self.layers
+        for p in pre:
+            for i, D in enumerate(L):
+                out += [(p + 'Wx', i, (self.Wx[i].shape[0], 3 * D)), (p + 'Wh', i, (D, D)), (p + 'Wrz', i, (D, 2 * D)), (p + 'Bh', i, (3 * D,))]
+            out += [(p + 'Wy', 0, (self.n_items, L[-1])), (p + 'By', 0, (self.n_items,))]
+            if not self.constrained_embedding and self.embedding:
+                out.append((p + 'E', 0, (self.n_items, self.embedding)))
+        return out
+
+    def _download_optimizer_state(self):
+        m = self._model
+        st = {'arrays': {}, 'global_step': m.global_step(), 'refills': m.refills()}
+        for name, layer, shape in self._opt_tables():
+            st['arrays'][(name, layer)] = m.get_param(name, shape, layer)
+        return st
+
+    def _upload_optimizer_state(self, m, st):
+        for name, layer, shape in self._opt_tables():
+            m.set_param(name, st['arrays'][(name, layer)], layer)
+        m.set_step_counters(st['global_step'], st['refills'])
+
     def set_distributed(self, rank, nranks, unique_id):
         """One process per GPU: sessions are sharded round-robin over ranks, dense GRU gradients are
         all-reduced with RCCL every step, embedding rows stay GPU-local."""
         self._dist = dict(rank=int(rank), nranks=int(nranks), unique_id=unique_id) if nranks > 1 else None
 
     # ------------------------------------------------------------------ training (gru4rec.py:515-664)
-    def prepare(self, data, sample_store=10000000, store_type='gpu'):
+    def prepare(self, data, sample_store=10000000, store_type='gpu', resume=False):
         """Everything fit() does before its epoch loop: item map, sort, offsets, weights, popularity tables,
         device model.  Split out so that benchmarks can time the epoch loop alone (the reference's own
-        mb/s excludes these as well)."""
+        mb/s excludes these as well).  resume=True keeps the weights on this object (a loaded checkpoint) instead of
+        initialising them, and restores the optimizer state / step counters saved next to them."""
         if store_type not in ('gpu', 'cpu'):
             print('Invalid store type {}'.format(store_type))
             raise NotImplementedError
@@ -314,17 +351,25 @@ class GRU4Rec:
         if eventio.is_categorical(item_col):
             # table from eventio.read_events: the category codes already are the indices (no hash join over the events)
             itemids, item_idx = eventio.first_appearance_index(item_col)
-            self.n_items = len(itemids)
-            self.itemidmap = pd.Series(data=np.arange(self.n_items), index=itemids, name='ItemIdx')
+            itemidmap = pd.Series(data=np.arange(len(itemids)), index=itemids, name='ItemIdx')
             data['ItemIdx'] = item_idx
         else:
             itemids = item_col.unique()
-            self.n_items = len(itemids)
-            self.itemidmap = pd.Series(data=np.arange(self.n_items), index=itemids, name='ItemIdx')
-            data['ItemIdx'] = self.itemidmap[item_col.values].values
+            itemidmap = pd.Series(data=np.arange(len(itemids)), index=itemids, name='ItemIdx')
+            data['ItemIdx'] = itemidmap[item_col.values].values
+        if resume:
+            if not hasattr(self, 'Wy') or getattr(self, 'optimizer_state', None) is None:
+                raise ValueError('resume=True needs a model saved with savemodel(fname, optimizer_state=True)')
+            if len(itemids) != self.n_items or not np.array_equal(np.asarray(itemidmap.index), np.asarray(self.itemidmap.index)):
+                raise ValueError('resume=True: the training data does not produce the item map of the checkpoint')
+        self.n_items = len(itemids)
+        self.itemidmap = itemidmap
         datatools.sort_if_needed(data, [self.session_key, self.time_key])
         self._offsets = datatools.compute_offset(data, self.session_key)
-        self._init_host_weights()
+        if not resume:
+            self._init_host_weights()
+            self.optimizer_state = None
+            self.epochs_done = 0
         # events per item in itemidmap order: data.groupby(item_key).size()[itemidmap.index] of gru4rec.py:540-541
         support = np.bincount(data['ItemIdx'].values, minlength=self.n_items)
         if self._model is not None:
@@ -345,6 +390,8 @@ class GRU4Rec:
         m.set_popularity(pop.astype(np.float32), lq_t, lq_s)
         if self.n_sample and m.sample_store_rows() > 1:
             print('Created sample store with {} batches of samples (type=GPU)'.format(m.sample_store_rows()))
+        if resume:
+            self._upload_optimizer_state(m, self.optimizer_state)
         if self.time_sort:
             # data is ordered by (session, time): a session's first row holds its minimum time (the groupby().min() of
             # gru4rec.py:585-586, sessions in ascending id order)
@@ -353,7 +400,8 @@ class GRU4Rec:
             self._base_order = np.arange(len(self._offsets) - 1)
         self._data_items = data.ItemIdx.values.astype(np.int32)
         self._plan_key = None
-        self.loss_history = []
+        if not resume:
+            self.loss_history = []
         self.step_costs = []          # per-epoch arrays of the per-mini-batch cost (gru4rec.py:623)
 
     def _epoch_plan(self):
@@ -365,13 +413,8 @@ class GRU4Rec:
         if self._dist:
             plan = build_rank_plan(self._offsets, order_all, self._data_items, self.batch_size, self.n_sample,
                                    self._dist['rank'], self._dist['nranks'])
-            # every rank must issue the same number of all-reduces: truncate to the shortest plan
-            T = self._model.comm_min(plan['T'])
-            for k in ('in_idx', 'out_idx', 'reset', 'M'):
-                plan[k] = plan[k][:T]
-            keep = plan['compact_steps'] < T
-            plan['compact_steps'], plan['compact_maps'] = plan['compact_steps'][keep], plan['compact_maps'][keep]
-            plan['T'], plan['n_compact'] = int(T), int(keep.sum())
+            # every rank must issue the same number of all-reduces: the shorter plans are padded with M = 0 steps
+            plan = pad_plan(plan, self._model.comm_max(plan['T']))
         else:
             plan = build_rank_plan(self._offsets, order_all, self._data_items, self.batch_size, self.n_sample)
         self._model.set_plan(plan)
@@ -393,14 +436,16 @@ class GRU4Rec:
             m.train_steps(done, n)
             c = m.get_losses(done, n)
             costs[done:done + n] = c
-            bad = np.isnan(c)
-            if bad.any():
+            bad = bool(np.isnan(c).any())
+            if self._dist:
+                bad = bool(m.comm_max(int(bad)))      # all ranks leave together: a lone return would hang the others' all-reduce
+            if bad:
                 print(str(epoch) + ': NaN error!')
                 self.error_during_train = True
                 return None
             done += n
         cc = plan['M'][:T]
-        avgc = np.sum(costs * cc) / np.sum(cc)
+        avgc = np.sum(costs * cc) / max(np.sum(cc), 1)
         if np.isnan(avgc):
             print('Epoch {}: NaN error!'.format(str(epoch)))
             self.error_during_train = True
@@ -412,15 +457,18 @@ class GRU4Rec:
         self.last_epoch_stats = dict(steps=int(T), events=int(np.sum(cc)), seconds=dt, loss=float(avgc))
         return costs, cc
 
-    def fit(self, data, sample_store=10000000, store_type='gpu'):
+    def fit(self, data, sample_store=10000000, store_type='gpu', resume=False):
         """Trains the network; same contract as the reference's fit (gru4rec.py:515-664): mutates `data`
-        (adds ItemIdx, may sort in place), sets n_items / itemidmap / error_during_train."""
-        self.prepare(data, sample_store=sample_store, store_type=store_type)
-        for epoch in range(self.n_epochs):
+        (adds ItemIdx, may sort in place), sets n_items / itemidmap / error_during_train.
+        resume=True (not in the reference): continue a model loaded from savemodel(fname, optimizer_state=True) on the same
+        training data from the epoch it stopped at, up to n_epochs -- bit-identical to the uninterrupted run."""
+        self.prepare(data, sample_store=sample_store, store_type=store_type, resume=resume)
+        for epoch in range(self.epochs_done if resume else 0, self.n_epochs):
             if self.run_epoch(epoch) is None:
                 return
             if self._dist:
                 self._model.comm_sync_sparse()
+            self.epochs_done = epoch + 1
         self._download_weights()
 
     def close(self):
@@ -480,6 +528,8 @@ class GRU4Rec:
         for k, v in self._EXTRAS.items():
             self.__dict__.setdefault(k, v)
         self.__dict__.setdefault('loss_history', [])
+        self.__dict__.setdefault('optimizer_state', None)
+        self.__dict__.setdefault('epochs_done', 0)
         self.__dict__.setdefault('error_during_train', False)
         self.set_loss_function(self.loss)
         self.set_final_activation(self.final_act)
@@ -490,13 +540,27 @@ class GRU4Rec:
         self._dist = None
         self.predict = None
 
-    def savemodel(self, fname):
+    def savemodel(self, fname, optimizer_state=False):
         """Pickle with the reference's attribute names / array layouts (Wx[i] (in,3D)=[cand|r|z], Wrz[i] (D,2D)=[r|z],
-        Wh[i], Bh[i], H[i], Wy (n_items,D), By (n_items,1), E, itemidmap)."""
+        Wh[i], Bh[i], H[i], Wy (n_items,D), By (n_items,1), E, itemidmap).  optimizer_state=True adds, under attributes the
+        reference's loadmodel never looks at (`optimizer_state`, `epochs_done`), what fit(resume=True) needs to continue: the
+        accumulator / velocity arrays, the global step and the sample-store refill count.  The file stays loadable by the
+        reference (gru4rec.py:768-781 touches the weight attributes only)."""
         if self._model is not None and not self.error_during_train:
             self._download_weights()
-        with open(fname, 'wb') as f:
-            pickle.dump(self, f)
+        keep = getattr(self, 'optimizer_state', None)
+        if optimizer_state:
+            if self._model is None:
+                raise ValueError('optimizer_state=True needs the trained device model (call savemodel before close())')
+            self.optimizer_state = self._download_optimizer_state()
+        else:
+            self.optimizer_state = None
+        try:
+            with open(fname, 'wb') as f:
+                pickle.dump(self, f)
+        finally:
+            if not optimizer_state:
+                self.optimizer_state = keep
 
     @classmethod
     def loadmodel(cls, fname):

@@ -29,3 +29,23 @@ def build_rank_plan(offsets, order, data_items, batch_size, n_sample, rank=0, nr
         return _native.build_plan(offsets, order, data_items, batch_size, n_sample)
     sub_off, items = shard_sessions(offsets, order, data_items, rank, nranks)
     return _native.build_plan(sub_off, np.arange(len(sub_off) - 1), items, batch_size, n_sample)
+
+
+def pad_plan(plan, T):
+    """Append M = 0 steps up to T steps.  Ranks of a data-parallel run hold plans of different lengths (their session shards differ);
+    every rank has to issue the same number of dense-gradient all-reduces, so the shorter plans end with no-op steps: no row is
+    active, the rank contributes a zero gradient and still applies the reduced one.  No event is dropped (the alternative, cutting
+    every plan to the shortest, would drop the tail sessions of the longer ones)."""
+    n = int(T) - int(plan['T'])
+    if n < 0:
+        raise ValueError('cannot pad a plan of %d steps to %d' % (plan['T'], T))
+    if n == 0:
+        return plan
+    B = plan['in_idx'].shape[1]
+    out = dict(plan)
+    out['in_idx'] = np.concatenate([plan['in_idx'], np.zeros((n, B), dtype=np.int32)])
+    out['out_idx'] = np.concatenate([plan['out_idx'], np.zeros((n, B), dtype=np.int32)])
+    out['reset'] = np.concatenate([plan['reset'], np.zeros((n, B), dtype=np.uint8)])
+    out['M'] = np.concatenate([plan['M'], np.zeros(n, dtype=np.int32)])
+    out['T'] = int(T)
+    return out

@@ -119,6 +119,10 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps);
 int g4r_get_losses(g4r_model* m, int64_t t0, int64_t n, float* out);     /* cost of :623 per step */
 int g4r_synchronize(g4r_model* m);
 int64_t g4r_global_step(g4r_model* m);
+/* checkpoint resume ("optimizer-state save"): the number of sample-store refills so far, and the setter that
+ * puts a fresh handle where a saved run stopped (global step: dropout counters, store row pointer; refills: store contents) */
+int64_t g4r_refills(g4r_model* m);
+int g4r_set_step_counters(g4r_model* m, int64_t global_step, int64_t refills);
 /* average HIP-event time (ms) per launch of each step kernel since the last reset; names via index */
 int g4r_kernel_time(g4r_model* m, int32_t which, const char** name, double* total_ms, int64_t* launches);
 int g4r_profile(g4r_model* m, int32_t enable);
@@ -174,8 +178,28 @@ void g4r_events_free(g4r_events* ev);
 /* ---- multi-GPU (new: the reference is single-GPU).  RCCL all-reduce of dense GRU gradients ---- */
 int g4r_comm_unique_id(char* out128);                         /* rank 0: ncclGetUniqueId */
 int g4r_comm_init(g4r_model* m, const char* id128, int32_t nranks, int32_t rank);
-int g4r_comm_sync_sparse(g4r_model* m);                        /* average GPU-local embedding replicas */
-int g4r_comm_min_i64(g4r_model* m, int64_t* value);            /* in-place min over ranks (plan lengths must agree) */
+/* Reconciliation of the GPU-local item tables (Wy / By / E and their optimizer state; north_star: "sparse embedding rows stay
+ * GPU-local").  For every row some rank rewrote since the last call, every replica ends at
+ *     base + sum over ranks q, in rank order, of (value on rank q - base),      base = the common value at the last call,
+ * so each rank's updates are kept in full (a row one rank alone trained ends at that rank's value up to fp32 rounding) and the
+ * replicas are bit-identical afterwards.  Packed (id list, delta rows) parts are
+ * all-gathered in item-id ranges: the traffic follows the number of touched rows.  Called by fit() at the end of an epoch. */
+int g4r_comm_sync_sparse(g4r_model* m);
+/* allocates the touched-row bitmap and the base copies, base = the tables as they are now (g4r_comm_init calls it;
+ * g4r_set_param of an item table afterwards also sets its base) */
+int g4r_sync_enable(g4r_model* m);
+/* The two halves of g4r_comm_sync_sparse without RCCL, for tests that emulate ranks with several handles on one GPU.
+ * group 0: Wy / By rows, 1: E rows.  export: sorted ids of the touched rows and, plane after plane (Wy, acc_Wy, [vel ...], By,
+ * acc_By, ...), their delta rows [n][W]; returns n (pass NULL pointers to size the buffers; g4r_sync_row_floats = sum of the plane
+ * widths).  import: the parts of ALL ranks in rank order (this handle's own included) -> reset, add, new base, bitmap cleared. */
+int64_t g4r_sync_row_floats(g4r_model* m, int32_t group);
+int64_t g4r_sync_export(g4r_model* m, int32_t group, int32_t* ids, float* rows, int64_t cap_rows);
+int g4r_sync_import(g4r_model* m, int32_t group, int32_t nparts, const int64_t* counts, const int32_t* const* ids,
+                    const float* const* rows);
+int g4r_comm_min_i64(g4r_model* m, int64_t* value);            /* in-place min over ranks */
+int g4r_comm_max_i64(g4r_model* m, int64_t* value);            /* in-place max over ranks: the common plan length (shorter plans are
+                                                                  padded with M = 0 steps so that every rank issues the same all-reduces) */
+int g4r_comm_nranks(g4r_model* m);                             /* ranks RCCL reports for the communicator (1 without one) */
 
 /* ---- debugging / tests ---------------------------------------------------------------------- */
 /* copy a named intermediate of the most recent step (e.g. "scores", "dS", "dV0", "hd0") */

@@ -350,6 +350,22 @@ class OracleGRU4Rec:
         dt = self.dtype.type
         B = self.batch_size
         L = self.layers
+        if M == 0:
+            # padding step of a data-parallel plan (NOT in the reference: DESIGN.md section 7): nothing is active on this rank, it
+            # contributes zero dense gradients to the all-reduce, applies the reduced ones and consumes its row of negatives
+            self.next_samples()
+            zeros = [(i, None if (self.onehot and i == 0) else np.zeros_like(self.Wx[i]), np.zeros_like(self.Wh[i]),
+                      np.zeros_like(self.Wrz[i]), np.zeros_like(self.Bh[i])) for i in reversed(range(len(L)))]
+            if getattr(self, 'dense_grad_hook', None) is not None:
+                zeros = self.dense_grad_hook(zeros)
+            for (i, dWx, dWh, dWrz, dBh) in zeros:
+                if dWx is not None:
+                    self._dense_update('Wx', i, dWx)
+                self._dense_update('Wh', i, dWh)
+                self._dense_update('Wrz', i, dWrz)
+                self._dense_update('Bh', i, dBh)
+            self.global_step += 1
+            return dt(0)
         in_idx = np.asarray(in_idx, dtype=np.int64)[:M]
         out_idx = np.asarray(out_idx, dtype=np.int64)[:M]
         reset = np.asarray(reset).astype(bool).reshape(-1)[:M]

@@ -80,3 +80,66 @@ def test_reference_checkpoint_predicts_on_the_gpu():
     p2 = g.predict_next_batch(np.array([1, 2, 9, 4]), ids[[2, 3, 1, 6]], None, batch=4)
     np.testing.assert_allclose(p1.values, want['pred1'], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(p2.values, want['pred2'], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kw', [dict(momentum=0.2, dropout_p_hidden=0.2, dropout_p_embed=0.1),
+                                dict(adapt='adam', adapt_params=[0.9, 0.999], learning_rate=0.01, constrained_embedding=False, embedding=16),
+                                dict(constrained_embedding=False, layers=[24])],
+                         ids=['adagrad_momentum_dropout', 'adam_separate_embedding', 'onehot'])
+def test_resume_continues_bit_identically(tmp_path, kw):
+    """SURVEY 8f rank 2, second half: 2 epochs == 1 epoch + savemodel(optimizer_state=True) + loadmodel + fit(resume=True).
+    The sample store wraps around inside the epochs (its refill counter is part of the saved state), dropout masks are keyed by
+    the global step."""
+    from gru4rec_amd import synth
+    data = synth.make_sessions(1500, n_items=300, seed=4)
+    P = dict(loss='bpr-max', final_act='elu-0.5', layers=[32], batch_size=32, n_sample=64, constrained_embedding=True, learning_rate=0.1)
+    P.update(kw)
+    a = GRU4Rec(n_epochs=2, **P)
+    a.fit(data.copy(), sample_store=64 * 50)
+    b = GRU4Rec(n_epochs=1, **P)
+    b.fit(data.copy(), sample_store=64 * 50)
+    f = str(tmp_path / 'ckpt.pickle')
+    b.savemodel(f, optimizer_state=True)
+    b.close()
+    c = GRU4Rec.loadmodel(f)
+    assert c.epochs_done == 1 and c.optimizer_state['global_step'] == len(a.step_costs[0])
+    c.n_epochs = 2
+    c.fit(data.copy(), sample_store=64 * 50, resume=True)
+    np.testing.assert_array_equal(c.step_costs[0], a.step_costs[1])
+    np.testing.assert_array_equal(c.Wy, a.Wy)
+    np.testing.assert_array_equal(c.By, a.By)
+    for i in range(len(a.layers)):
+        np.testing.assert_array_equal(c.Wx[i], a.Wx[i])
+        np.testing.assert_array_equal(c.Wh[i], a.Wh[i])
+    assert c.loss_history == a.loss_history
+    # a checkpoint without optimizer state refuses to resume instead of silently restarting the accumulators
+    b2 = GRU4Rec.loadmodel(f)
+    b2.optimizer_state = None
+    with pytest.raises(ValueError):
+        b2.fit(data.copy(), sample_store=64 * 50, resume=True)
+
+
+def test_checkpoint_with_optimizer_state_keeps_the_reference_layout(tmp_path):
+    """The extra attributes ride along; everything the reference's loadmodel reads is unchanged."""
+    g = GRU4Rec.loadmodel(PICKLE)
+    g.optimizer_state = {'arrays': {('acc_Wy', 0): np.ones((g.n_items, 12), dtype=np.float32)}, 'global_step': 7, 'refills': 1}
+    g.epochs_done = 3
+    f = str(tmp_path / 'm.pickle')
+    with open(f, 'wb') as fh:
+        pickle.dump(g, fh)
+    h = GRU4Rec.loadmodel(f)
+    assert h.epochs_done == 3 and h.optimizer_state['global_step'] == 7
+    np.testing.assert_array_equal(h.Wy, g.Wy)
+    from oracle import ref_loader
+    if ref_loader.available():
+        import sys
+        saved = sys.modules.get('gru4rec')
+        try:
+            _, ref, _ = ref_loader.load()
+            back = ref.GRU4Rec.loadmodel(f)      # the reference's own loader accepts the file
+            assert back.epochs_done == 3
+        finally:
+            ref_loader.unload()
+            if saved is not None:
+                sys.modules['gru4rec'] = saved

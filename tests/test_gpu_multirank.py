@@ -1,0 +1,119 @@
+"""The multi-rank machinery that can be exercised on ONE MI355X: M = 0 padding steps, the staged dense path with the RCCL
+all-reduce captured into the step graph (one-rank communicator), and the reconciliation of the GPU-local item tables with two
+model handles standing in for two ranks (g4r_sync_export / g4r_sync_import: the kernels g4r_comm_sync_sparse runs around its
+all-gather)."""
+import numpy as np
+import pytest
+
+from gru4rec_amd import _native
+from gru4rec_amd.plan import pad_plan
+
+from test_gpu_parity import CASES, make_pair, random_plan
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('staged', [0, 1])
+def test_padding_steps_touch_nothing(monkeypatch, staged):
+    """A plan padded with M = 0 steps (ranks with fewer sessions) ends with exactly the parameters of the unpadded plan, and the
+    padding steps cost 0."""
+    if staged:
+        monkeypatch.setenv('G4R_FORCE_STAGED', '1')
+    kw = dict(CASES['bprmax_elu'])
+    I, B, ns, T = 80, 12, 24, 40
+    outs = []
+    for pad in (0, 5):
+        _, m = make_pair(I, B, ns, store_rows=200, use_graph=1, **dict(kw))
+        if staged:
+            m.comm_init(_native.comm_unique_id(), 1, 0)
+        plan = pad_plan(random_plan(I, B, T, seed=13), T + pad)
+        m.set_plan(plan)
+        m.train_steps(0, T + pad)
+        losses = m.get_losses(0, T + pad)
+        assert (losses[T:] == 0).all()
+        outs.append((losses[:T], m.get_param('Wy', (I, 12)), m.get_param('By', (I,)), m.get_param('acc_Wy', (I, 12)),
+                     m.get_param('Wx', (12, 36), 0), m.get_param('Wh', (12, 12), 0), m.get_param('acc_Wh', (12, 12), 0)))
+        m.close()
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_staged_path_replays_from_a_graph_that_holds_the_allreduce(monkeypatch):
+    """N > 1 data path with a one-rank communicator: gradient staging -> RCCL all-reduce -> k_dense_apply, 16 whole steps per
+    graph replay (the all-reduce is captured), against the fused single-GPU step."""
+    kw = CASES['bprmax_mom_drop']
+    I, B, ns, T = 80, 12, 24, 70
+    plan = random_plan(I, B, T, seed=17)
+    outs = []
+    for staged in (0, 1):
+        if staged:
+            monkeypatch.setenv('G4R_FORCE_STAGED', '1')
+        _, m = make_pair(I, B, ns, store_rows=200, use_graph=1, **dict(kw))
+        if staged:
+            m.comm_init(_native.comm_unique_id(), 1, 0)
+            assert m.comm_nranks() == 1
+        m.set_plan(plan)
+        m.train_steps(0, T)
+        if staged:
+            assert m.get_debug('graph_mode', (1,))[0] == 1.0, 'RCCL was not captured into the step graph'
+            m.comm_sync_sparse()
+        outs.append((m.get_losses(0, T), m.get_param('Wy', (I, 16)), m.get_param('Wx', (16, 48), 0),
+                     m.get_param('Bh', (48,), 0), m.get_param('acc_Wh', (16, 16), 0)))
+        m.close()
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('name', ['bprmax_mom_drop', 'xe_sep_embed'])
+def test_item_table_reconciliation_with_two_handles(name):
+    """Two handles = two ranks.  After training on different shards, exporting both parts and importing [part0, part1] on both:
+    replicas are bit-identical, every row equals base + delta0 + delta1 (fp32, in that order), a row only one rank trained keeps
+    that rank's value (up to the fp32 rounding of base + (value - base)), optimizer state follows the same rule, untouched rows keep their bits; a second round starts
+    from the new base."""
+    kw = dict(CASES[name])
+    I, B, ns, T = 120, 12, 24, 30
+    D = kw['layers'][-1]
+    ms, bases = [], []
+    for r in range(2):
+        _, m = make_pair(I, B, ns, store_rows=200, use_graph=1, **dict(kw))      # identical initial weights on both
+        m.sync_enable()
+        ms.append(m)
+    names = [('Wy', (I, D)), ('acc_Wy', (I, D)), ('By', (I,)), ('acc_By', (I,))]
+    if kw.get('momentum', 0) > 0:
+        names += [('vel_Wy', (I, D))]
+    groups = [0]
+    if not kw.get('constrained_embedding', False):
+        names += [('E', (I, kw['embedding'])), ('acc_E', (I, kw['embedding']))]
+        groups = [0, 1]
+    for rnd in range(2):
+        base = {n: ms[0].get_param(n, sh) for n, sh in names}
+        for n, sh in names:
+            np.testing.assert_array_equal(base[n], ms[1].get_param(n, sh))
+        local = []
+        for r, m in enumerate(ms):
+            plan = random_plan(I // 2, B, T, seed=100 + 10 * rnd + r)      # items 0..59 only: the upper half is touched by samples alone
+            if r == 1:
+                plan['in_idx'] += I // 3
+                plan['out_idx'] += I // 3
+            m.set_plan(plan)
+            m.train_steps(0, T)
+            local.append({n: m.get_param(n, sh) for n, sh in names})
+        for g in groups:
+            parts = [m.sync_export(g) for m in ms]
+            assert all(len(p[0]) > 0 and (np.diff(p[0]) > 0).all() for p in parts)
+            for m in ms:
+                m.sync_import(parts, g)
+        for n, sh in names:
+            a, b = ms[0].get_param(n, sh), ms[1].get_param(n, sh)
+            np.testing.assert_array_equal(a, b)
+            d0, d1 = local[0][n] - base[n], local[1][n] - base[n]
+            np.testing.assert_array_equal(a, (base[n] + d0) + d1)
+            rows = lambda x: np.abs(x.reshape(I, -1)).max(axis=1)
+            only0 = (rows(d0) > 0) & (rows(d1) == 0)
+            if n in ('Wy', 'E'):
+                assert only0.any()
+            np.testing.assert_allclose(a.reshape(I, -1)[only0], local[0][n].reshape(I, -1)[only0], rtol=2e-6, atol=1e-9)
+        for g in groups:      # everything reconciled: nothing left to export
+            assert all(len(m.sync_export(g)[0]) == 0 for m in ms)
+    for m in ms:
+        m.close()

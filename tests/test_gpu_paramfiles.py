@@ -42,7 +42,11 @@ def test_paramfile_trains_through_the_public_class(name):
     gru.fit(data, sample_store=2048 * 64)
     assert not gru.error_during_train
     h = gru.loss_history
-    assert len(h) == 2 and np.isfinite(h).all() and h[1] < h[0], h
+    assert len(h) == 2 and np.isfinite(h).all(), h
+    # rsc15_xe (learning rate 0.2, momentum 0.2, batch 32) is unstable on this small synthetic set: the fp32 and the fp64
+    # oracle end its second epoch at 11.35 and 14.16; "the loss went down" says something for the other five only
+    if name != 'rsc15_xe_shared_100_best':
+        assert h[1] < h[0], h
 
 
 @pytest.mark.parametrize('name', sorted(PARAMFILES))

@@ -459,3 +459,27 @@ def test_predict_and_ranks(name):
     got = m.predict_step(in_idx)
     close('scores after compaction', got, want, atol=2e-6, rtol=3e-4, errs=errs)
     assert not errs, errs
+
+
+@pytest.mark.parametrize('fa', ['elu-0.5', 'leaky-0.2', 'selu-1.05-1.67'])
+def test_activation_derivative_branch_follows_the_input_sign(fa):
+    """Scores a rounding away from 0 (|s| ~ 1e-9: exp(s) - 1 rounds to 0 in fp32): the reference's T.grad switches the piecewise
+    activations on the INPUT (gru4rec.py:214-218: T.switch(T.ge(X, 0), ...)), so d cost / d s of a tiny negative score carries
+    alpha, not 1.  (The kernels only keep the output; the branch travels in the sign bit of the zero.)"""
+    I, B, ns = 60, 20, 40
+    o, m = make_pair(I, B, ns, store_rows=7, loss='bpr-max', final_act=fa, constrained_embedding=False, embedding=8, layers=(12,))
+    tiny = np.where(np.arange(I)[:, None] % 2 == 0, 1e-9, -1e-9).astype(np.float32) * np.ones((1, 12), dtype=np.float32)
+    o.Wy[:40] = tiny[:40]
+    o.By[:] = 0
+    m.set_param('Wy', o.Wy)
+    m.set_param('By', o.By)
+    plan = random_plan(I, B, 1, seed=5)
+    m.set_plan(plan)
+    cost, dbg = o.train_step(plan['in_idx'][0], plan['out_idx'][0], B, plan['reset'][0], return_debug=True)
+    m.train_steps(0, 1)
+    ld = int(m.get_debug('ldSc', (1,))[0])
+    ds = m.get_debug('scores', (B, ld))[:, :B + ns]
+    want = dbg['ds']
+    assert (np.abs(want) > 0).all()
+    np.testing.assert_allclose(ds, want, rtol=2e-3, atol=1e-9)
+    close('cost', m.get_losses(0, 1), [cost], atol=2e-6, rtol=2e-4)

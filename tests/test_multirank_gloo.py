@@ -1,10 +1,12 @@
-"""The N > 1 path on CPU: two processes (gloo), session sharding as the product does it
-(gru4rec_amd.plan), dense GRU gradients all-reduced (averaged) every step, embedding rows rank-local and averaged at
-the end of the epoch -- the semantics of DESIGN.md section 7 -- executed with the oracle as the per-rank engine.
+"""The N > 1 path on CPU: two processes (gloo) run the PRODUCT's host code for a data-parallel epoch -- session sharding and plan
+building (gru4rec_amd.plan.build_rank_plan: the C++ scheduler), the common plan length (max over ranks) and the M = 0 padding
+steps (pad_plan) -- with the device calls stood in for by the oracle: dense GRU gradients all-reduced (averaged) every step,
+embedding rows rank-local and reconciled at the end of the epoch as base + sum of every rank's deltas.
 
-Checks: (1) the shards partition the sessions and preserve time order; (2) dense parameters stay bit-identical across
-ranks; (3) embedding replicas diverge during the epoch and agree after the epoch-end averaging; (4) the
-two-process run equals a single-process emulation of the same algorithm (so the collective placement is right)."""
+Checks: (1) the shards partition the sessions and preserve time order, and no event is lost: the events of all rank plans add
+up to the events of the single-rank plan; (2) dense parameters stay bit-identical across ranks; (3) embedding replicas diverge
+during the epoch and agree after the reconciliation, which keeps a row only one rank trained at exactly that rank's value;
+(4) the two-process run equals a single-process emulation of the same algorithm (so the collective placement is right)."""
 import os
 import tempfile
 
@@ -14,7 +16,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from gru4rec_amd.plan import build_rank_plan, shard_sessions
+from gru4rec_amd import _native
+from gru4rec_amd.plan import build_rank_plan, pad_plan, shard_sessions
 from oracle.model import OracleGRU4Rec
 
 I, B, NS, D = 60, 4, 8, 8
@@ -54,8 +57,9 @@ def worker(rank, world, store_path, out_path):
     off, order, items = make_sessions()
     plan = build_rank_plan(off, order, items, B, NS, rank, world)
     tt = torch.tensor([plan['T']])
-    dist.all_reduce(tt, op=dist.ReduceOp.MIN)          # g4r_comm_min_i64
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)          # g4r_comm_max_i64
     T = int(tt[0])
+    plan = pad_plan(plan, T)                           # what GRU4Rec._epoch_plan does
 
     def allreduce_avg(grads):
         out = []
@@ -68,11 +72,13 @@ def worker(rank, world, store_path, out_path):
             out.append((i, *red))
         return out
     o = make_rank_model(rank)
+    base = o.Wy.copy()                                   # identical on every rank (same initialisation)
     run_rank_steps(o, plan, T, allreduce_avg)
     wy_local = o.Wy.copy()
-    t = torch.from_numpy(o.Wy.copy())
-    dist.all_reduce(t)                                   # g4r_comm_sync_sparse
-    np.savez(out_path % rank, dense=flat_dense(o), wy_local=wy_local, wy_sync=t.numpy() / world, T=T)
+    t = torch.from_numpy(o.Wy - base)
+    dist.all_reduce(t)                                   # g4r_comm_sync_sparse: base + sum of every rank's deltas
+    np.savez(out_path % rank, dense=flat_dense(o), wy_local=wy_local, wy_sync=base + t.numpy(), T=T, base=base,
+             events=int(plan['M'].sum()))
     dist.destroy_process_group()
 
 
@@ -86,12 +92,19 @@ def test_two_ranks_gloo_match_single_process_emulation():
         r = [np.load(out % k) for k in range(world)]
     np.testing.assert_array_equal(r[0]['dense'], r[1]['dense'])          # (2) dense replicas identical
     assert np.abs(r[0]['wy_local'] - r[1]['wy_local']).max() > 1e-6      # (3) embeddings are rank-local ...
-    np.testing.assert_array_equal(r[0]['wy_sync'], r[1]['wy_sync'])      # ... and agree after the epoch-end average
-    # (4) single-process emulation of the same algorithm
+    np.testing.assert_array_equal(r[0]['wy_sync'], r[1]['wy_sync'])      # ... and agree after the reconciliation
+    only0 = (np.abs(r[0]['wy_local'] - r[0]['base']).max(axis=1) > 0) & (np.abs(r[1]['wy_local'] - r[1]['base']).max(axis=1) == 0)
+    assert only0.any()                                                   # rows only rank 0 trained keep rank 0's full update
+    np.testing.assert_allclose(r[0]['wy_sync'][only0], r[0]['wy_local'][only0], rtol=0, atol=1e-15)
+    # (1) no event is lost: all rank plans together hold the events of the single-rank plan
     off, order, items = make_sessions()
+    single = _native.build_plan(off, order, items, B, NS)
+    assert int(r[0]['events']) + int(r[1]['events']) == int(single['M'].sum()) == int((np.diff(off) - 1).sum())
+    # (4) single-process emulation of the same algorithm
     plans = [build_rank_plan(off, order, items, B, NS, k, world) for k in range(world)]
-    T = min(p['T'] for p in plans)
-    assert T == int(r[0]['T'])
+    T = max(p['T'] for p in plans)
+    assert T == int(r[0]['T']) and min(p['T'] for p in plans) < T        # the padding is exercised
+    plans = [pad_plan(p, T) for p in plans]
     models = [make_rank_model(k) for k in range(world)]
     for t in range(T):
         grads = []
