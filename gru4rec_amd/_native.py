@@ -43,7 +43,7 @@ SYMBOLS = [
     'g4r_sample_store_rows', 'g4r_build_plan', 'g4r_set_plan', 'g4r_train_steps', 'g4r_get_losses',
     'g4r_synchronize', 'g4r_global_step', 'g4r_refills', 'g4r_set_step_counters', 'g4r_kernel_time', 'g4r_profile', 'g4r_reset_hidden',
     'g4r_predict_begin', 'g4r_predict_hidden', 'g4r_predict_step', 'g4r_rank_targets', 'g4r_evaluate', 'g4r_comm_unique_id',
-    'g4r_comm_init', 'g4r_comm_sync_sparse', 'g4r_comm_min_i64', 'g4r_comm_max_i64', 'g4r_comm_nranks', 'g4r_sync_enable', 'g4r_sync_row_floats', 'g4r_sync_export', 'g4r_sync_import', 'g4r_get_debug', 'g4r_selftest_mfma',
+    'g4r_comm_init', 'g4r_comm_sync_sparse', 'g4r_comm_min_i64', 'g4r_comm_max_i64', 'g4r_comm_nranks', 'g4r_sync_enable', 'g4r_sync_row_floats', 'g4r_sync_export', 'g4r_sync_import', 'g4r_get_debug', 'g4r_selftest_mfma', 'g4r_bench_rows',
     'g4r_events_load', 'g4r_events_rows', 'g4r_events_items', 'g4r_events_item_bytes', 'g4r_events_time_kind',
     'g4r_events_copy', 'g4r_events_free',
 ]
@@ -110,6 +110,7 @@ def lib():
     L.g4r_sync_import.argtypes = [vp, i32, i32, i64p, C.POINTER(i32p), C.POINTER(f32p)]
     L.g4r_get_debug.argtypes = [vp, C.c_char_p, f32p, i64]
     L.g4r_selftest_mfma.argtypes = [f32p]
+    L.g4r_bench_rows.argtypes = [i32, i64, i32, i64, i32, i32, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.g4r_events_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, i32, C.POINTER(vp)]
     for fn in (L.g4r_events_rows, L.g4r_events_items, L.g4r_events_item_bytes):
         fn.argtypes, fn.restype = [vp], i64
@@ -430,6 +431,13 @@ def comm_unique_id():
     buf = C.create_string_buffer(128)
     _chk(lib().g4r_comm_unique_id(buf))
     return buf.raw
+
+
+def bench_rows(n_items, width, rows_per_launch, launches=200, mode=1, device=0, seed=1):
+    """(mean kernel us, wall us per launch) of the row gather / scatter micro-benchmark (g4r_bench_rows)."""
+    k, w = C.c_double(), C.c_double()
+    _chk(lib().g4r_bench_rows(device, int(n_items), int(width), int(rows_per_launch), int(launches), int(mode), int(seed), C.byref(k), C.byref(w)))
+    return k.value, w.value
 
 
 def selftest_mfma():

@@ -14,6 +14,7 @@
 
 #include "g4r_eval_kernels.cuh"
 #include "g4r_sync_kernels.cuh"
+#include "g4r_micro_kernels.cuh"
 
 // Host code below is compiled in the host pass only: on the device pass the descriptor pointer fields are
 // address-space qualified (g4r_device.cuh) and the template kernels are instantiated explicitly.
@@ -74,6 +75,7 @@ struct g4r_model {
     int64_t gstep = 0;
     // launch geometry
     DenseTile* d_tiles = nullptr;
+    int dt = 32;                                 // edge of the dense-gradient tiles (64 for wide layers)
     int ntiles = 0, nblkA = 0, nblkB = 0, ndtA = 0, ndtB = 0, nrtB = 0, nblk_occ = 0;
     size_t smem_score = 0, smem_loss = 0, smem_sparse = 0;
     float* d_tmpH = nullptr;
@@ -135,6 +137,7 @@ static constexpr size_t tile_smem() { return (size_t)TileCfg<BM, BN, BK, AKM, BN
 static const size_t SMEM_NN = tile_smem<GT_BM, GT_BN, GT_BK, false, false>() + GT_BM * sizeof(int);   // A [m][k], B [k][n] (+ row items)
 static const size_t SMEM_NT = tile_smem<GT_BM, GT_BN, GT_BK, false, true>() + GT_BM * sizeof(int);    // A [m][k], B [n][k] (+ row items)
 static const size_t SMEM_TN = tile_smem<GT_BM, GT_BN, GT_BK, true, false>();    // A [k][m], B [k][n]
+static const size_t SMEM_DIRECT = (size_t)(GT_NTH_FEW / 64) * 4 * 64 * sizeof(f32x4);      // dense_grad_direct: partial accumulators of the waves
 // wide layers: 64-column tiles halve the number of GRU phase-1 workgroups (all resident at once) and read the weights in
 // 256-byte runs; the 32-column tiles spread the tiny GEMMs of D ~ 100 over more CUs
 static constexpr auto k_gru_p1_n32 = k_gru_p1<GT_BN, P1_BK>;
@@ -310,11 +313,20 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     // dense-gradient tile table
     {
         std::vector<DenseTile> tiles;
+        {
+            static const bool narrow = getenv("G4R_NARROW_TILES") != nullptr;
+            int dmax = 0;
+            for (int l = 0; l < L; ++l) dmax = std::max(dmax, d.D[l]);
+            // dense-gradient tiles: 32 x 32, LDS-staged (default) or register-fed with K split over the waves (G4R_DT=0, experiment)
+            m->dt = (getenv("G4R_DT") && atoi(getenv("G4R_DT")) == 0) ? 0 : 32;
+            (void)dmax; (void)narrow;
+        }
+        const int DTE = 32;
         for (int l = 0; l < L; ++l) {
             const int D = d.D[l], IN = d.IN[l];
             auto add = [&](const float* x0, const float* x1, int ldx, int nrows, int ncols, int coff, int ldo, long long base) {
-                for (int r = 0; r < nrows; r += GT_BM)
-                    for (int c = 0; c < ncols; c += GT_BN) {
+                for (int r = 0; r < nrows; r += DTE)
+                    for (int c = 0; c < ncols; c += DTE) {
                         DenseTile t;
                         t.X0 = x0; t.X1 = x1; t.dV = d.dV[l]; t.base = base; t.ldx = ldx; t.ldv = 3 * D; t.nrows = nrows;
                         t.ncols = ncols; t.coff = coff; t.ldo = ldo; t.r0 = r; t.c0 = c; t.gather = (x0 == nullptr && nrows > 1) ? 1 : 0; t.pad = 0;
@@ -350,18 +362,23 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd_w, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_a, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_b, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_dense_grad, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_dense_grad<0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_update<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_dense_grad<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update_generic<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update_generic<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_update<1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_store, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel"); }
-    if (getenv("G4R_CLK")) { if (dalloc(m, &d.dbgclk, 64 + 8 * (size_t)d.R)) { g4r_destroy(m); return -1; } }
+    if (getenv("G4R_CLK")) {
+        if (dalloc(m, &d.dbgclk, 64 + 8 * (size_t)d.R) || dalloc(m, &d.dbgtile, 8 * (size_t)std::max(m->ntiles, 1))) { g4r_destroy(m); return -1; }
+    }
     if (dalloc(m, &m->d_dm, 1) || sync_dm(m)) { g4r_destroy(m); return -1; }
     *out = m;
     return 0;
@@ -602,6 +619,7 @@ int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
 
 // ------------------------------------------------------------------------------------------------ the step
 static inline bool no_merge_tail() { static const bool v = getenv("G4R_NO_MERGE") != nullptr; return v; }
+static inline bool merged_update(const g4r_model* m) { return !m->dm.generic && !no_merge_tail(); }
 // part: 0 = the whole step; 1 = head (everything up to the dense gradients); 2 = tail (all-reduce, dense apply, sparse update)
 static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     DevModel& d = m->dm;
@@ -692,20 +710,28 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     if (merged) {
         // dense-gradient tiles (+ fused dense Adagrad on a single GPU; gradients to the RCCL buffer otherwise) and the sparse row
         // update in ONE launch (k_update): the two are independent, the all-reduce / dense apply of N > 1 follow behind
-        const size_t smem = std::max(SMEM_TN, m->smem_sparse);
+        const size_t smem = std::max(m->dt == 32 ? SMEM_TN : SMEM_DIRECT, m->smem_sparse);
+        const dim3 grid(m->ntiles + m->nblk_occ + 1), blk(SP_WAVES * 64);
+        const bool one = std::max(d.Dtop, d.Ein) <= 256;
         begin(KN_UPDATE);
-        if (std::max(d.Dtop, d.Ein) <= 256) LK(k_update<1>, dim3(m->ntiles + m->nblk_occ + 1), dim3(SP_WAVES * 64), smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);
-        else LK(k_update<2>, dim3(m->ntiles + m->nblk_occ + 1), dim3(SP_WAVES * 64), smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);
+        if (m->dt == 0) {
+            if (one) LK((k_update<1, 0>), grid, blk, smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);
+            else LK((k_update<2, 0>), grid, blk, smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);
+        } else {
+            if (one) LK((k_update<1, 32>), grid, blk, smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);
+            else LK((k_update<2, 32>), grid, blk, smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);
+        }
         end();
         if (d.apply_dense_inplace || part == 1) { HIPCHK(hipGetLastError()); return 0; }
     } else {
     begin(KN_DENSE);
-    LK(k_dense_grad, dim3(m->ntiles), dim3(GT_NTH_FEW), SMEM_TN, s, dmp, stp, (const DenseTile*)m->d_tiles);
+    if (m->dt == 0) LK(k_dense_grad<0>, dim3(m->ntiles), dim3(GT_NTH_FEW), SMEM_DIRECT, s, dmp, stp, (const DenseTile*)m->d_tiles);
+    else LK(k_dense_grad<32>, dim3(m->ntiles), dim3(GT_NTH_FEW), SMEM_TN, s, dmp, stp, (const DenseTile*)m->d_tiles);
     end();
     }
     }
     if (part == 1) { HIPCHK(hipGetLastError()); return 0; }
-    if (part == 2) merged = !d.generic && !no_merge_tail();
+    if (part == 2) merged = merged_update(m);
     // multi-rank: dense-gradient all-reduce, dense Adagrad, then the sparse embedding update, in stream order.
     // Optionally the first two run on their own stream next to the sparse update (which touches item rows only)
     // and join before the next step reads the GRU weights
@@ -1513,6 +1539,8 @@ int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
     else if (s == "Hprev") { p = d.H[l][(m->gstep + 1) & 1]; n = bd; }
     else if (s == "occ_idx") { p = (const float*)d.occ_idx; n = d.R; }
     else if (s == "dbgclk") { if (!d.dbgclk) return fail("G4R_CLK not set"); p = (const float*)d.dbgclk; n = 2 * (64 + 8 * (int64_t)d.R); }
+    else if (s == "dbgtile") { if (!d.dbgtile) return fail("G4R_CLK not set"); p = (const float*)d.dbgtile; n = 2 * 8 * (int64_t)std::max(m->ntiles, 1); }
+    else if (s == "ntiles") { if (count < 1) return fail("count"); host[0] = (float)m->ntiles; return 0; }
     else if (s == "ldSc") { if (count < 1) return fail("count"); host[0] = (float)d.ldSc; return 0; }
     else if (s == "ksplit") { if (count < 1) return fail("count"); host[0] = (float)d.ksplit; return 0; }
     else if (s == "graph_mode") {      // 0: no graph yet, 1: whole steps replayed (RCCL captured when N > 1), 2: head graph + eager tail
@@ -1524,6 +1552,65 @@ int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
     if (count != n) return fail(std::string("size mismatch for debug buffer ") + name + " expected " + std::to_string(n));
     HIPCHK(hipStreamSynchronize(m->stream));
     HIPCHK(hipMemcpy(host, p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- row gather / scatter micro-benchmark (g4r_micro_kernels.cuh) ------------------------------------------------
+int g4r_bench_rows(int32_t device, int64_t n_items, int32_t W, int64_t rows_per_launch, int32_t launches, int32_t mode, uint64_t seed,
+                   double* kernel_us, double* wall_us) {
+    if (n_items < 1 || W < 4 || W % 4 != 0 || W > 512 || rows_per_launch < 1 || launches < 1 || mode < 0 || mode > 2 || !kernel_us || !wall_us)
+        return fail("bad argument");
+    if (device < 0 || device >= g4r_device_count()) return fail("device ordinal out of range");
+    HIPCHK(hipSetDevice(device));
+    float *table = nullptr, *acc = nullptr, *buf = nullptr;
+    int* idx = nullptr;
+    hipStream_t s = nullptr;
+    std::vector<hipEvent_t> ev;
+    auto cleanup = [&]() {
+        (void)hipFree(table); (void)hipFree(acc); (void)hipFree(buf); (void)hipFree(idx);
+        for (auto e : ev) (void)hipEventDestroy(e);
+        if (s) (void)hipStreamDestroy(s);
+    };
+#define MBCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(std::string(#x ": ") + hipGetErrorString(e_)); } } while (0)
+    const size_t tab = (size_t)n_items * W;
+    const int warm = 3, total = launches + warm;
+    MBCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    MBCHK(hipMalloc((void**)&table, tab * sizeof(float)));
+    MBCHK(hipMemsetAsync(table, 0, tab * sizeof(float), s));
+    if (mode == 2) { MBCHK(hipMalloc((void**)&acc, tab * sizeof(float))); MBCHK(hipMemsetAsync(acc, 0, tab * sizeof(float), s)); }
+    MBCHK(hipMalloc((void**)&buf, (size_t)rows_per_launch * W * sizeof(float)));
+    MBCHK(hipMemsetAsync(buf, 0, (size_t)rows_per_launch * W * sizeof(float), s));
+    // every launch gets its own rows (distinct within a launch: a random start and an odd stride modulo n_items would cluster,
+    // so a multiplicative hash of a counter is used; duplicates inside a launch are a fraction ~rows/n_items and harmless here)
+    std::vector<int> h((size_t)total * rows_per_launch);
+    unsigned long long x = seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    for (auto& v : h) { x ^= x >> 12; x ^= x << 25; x ^= x >> 27; v = (int)(((x * 0x2545F4914F6CDD1Dull) >> 11) % (unsigned long long)n_items); }
+    MBCHK(hipMalloc((void**)&idx, h.size() * sizeof(int)));
+    MBCHK(hipMemcpyAsync(idx, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    MBCHK(hipStreamSynchronize(s));
+    ev.resize(2 * (size_t)launches + 2);
+    for (auto& e : ev) MBCHK(hipEventCreate(&e));
+    const long long waves = (rows_per_launch + MB_RPW - 1) / MB_RPW;
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    for (int l = 0; l < total; ++l) {
+        const int* ix = idx + (size_t)l * rows_per_launch;
+        const int t = l - warm;
+        if (t == 0) MBCHK(hipEventRecord(ev[2 * (size_t)launches], s));
+        hipEvent_t a = t >= 0 ? ev[2 * (size_t)t] : nullptr, b = t >= 0 ? ev[2 * (size_t)t + 1] : nullptr;
+        if (W <= 256) hipExtLaunchKernelGGL(k_micro_rows<1>, grid, block, 0, s, a, b, 0, (const float*)table, acc, ix, buf, (long long)rows_per_launch, (int)W, (int)mode);
+        else hipExtLaunchKernelGGL(k_micro_rows<2>, grid, block, 0, s, a, b, 0, (const float*)table, acc, ix, buf, (long long)rows_per_launch, (int)W, (int)mode);
+    }
+    MBCHK(hipEventRecord(ev[2 * (size_t)launches + 1], s));
+    MBCHK(hipStreamSynchronize(s));
+    MBCHK(hipGetLastError());
+    double ksum = 0.0;
+    for (int t = 0; t < launches; ++t) { float ms = 0.f; MBCHK(hipEventElapsedTime(&ms, ev[2 * (size_t)t], ev[2 * (size_t)t + 1])); ksum += ms; }
+    float wall = 0.f;
+    MBCHK(hipEventElapsedTime(&wall, ev[2 * (size_t)launches], ev[2 * (size_t)launches + 1]));
+#undef MBCHK
+    *kernel_us = 1000.0 * ksum / launches;
+    *wall_us = 1000.0 * wall / launches;
+    cleanup();
     return 0;
 }
 

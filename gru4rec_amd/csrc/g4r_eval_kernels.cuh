@@ -237,8 +237,12 @@ template __global__ void k_sparse_update<1>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update<2>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update_generic<1>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update_generic<2>(const DevModel*, StepState*, int);
-template __global__ void k_update<1>(const DevModel*, StepState*, const DenseTile*, int, int);
-template __global__ void k_update<2>(const DevModel*, StepState*, const DenseTile*, int, int);
+template __global__ void k_update<1, 32>(const DevModel*, StepState*, const DenseTile*, int, int);
+template __global__ void k_update<2, 32>(const DevModel*, StepState*, const DenseTile*, int, int);
+template __global__ void k_update<1, 0>(const DevModel*, StepState*, const DenseTile*, int, int);
+template __global__ void k_update<2, 0>(const DevModel*, StepState*, const DenseTile*, int, int);
+template __global__ void k_dense_grad<0>(const DevModel*, StepState*, const DenseTile*);
+template __global__ void k_dense_grad<32>(const DevModel*, StepState*, const DenseTile*);
 template __global__ void k_score_fwd<GT_BN, GT_BK>(const DevModel*, StepState*);
 template __global__ void k_score_fwd<32, 64>(const DevModel*, StepState*);
 template __global__ void k_score_bwd<32, GT_BK>(const DevModel*, StepState*, int, int, int, int);

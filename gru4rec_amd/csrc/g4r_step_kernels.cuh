@@ -1297,6 +1297,7 @@ __device__ __forceinline__ void dense_adagrad(const DevModel& m, size_t off, flo
 // with the dense Adagrad(+momentum) update (gru4rec.py:330-334,390-406) fused into the epilogue when no all-reduce
 // is needed (single GPU); otherwise the gradient goes to dense_g for RCCL.  Layer-0 input rows come from yin0
 // (published by k_gru_p1), never from the embedding table, so this may run next to the sparse update.
+template <int DT>
 __device__ __forceinline__ void dense_grad_tile(const DevModel& m, StepState* st, const DenseTile* tiles_, int tile, float* smem) {
     const GAS DenseTile* tiles = (const GAS DenseTile*)tiles_;   // same mangled signature on both passes
     const StepCtx c = load_ctx(st);
@@ -1338,11 +1339,131 @@ __device__ __forceinline__ void dense_grad_tile(const DevModel& m, StepState* st
             dp[off] = p.y * (1.0f - lr * lmbd) - lr * gs;
         }
     };
+    static_assert(DT == 32, "tile edge");
     gemm_tile<GT_BM, GT_BN, GT_BK, true, false, GT_NTH_FEW>(tl.r0, tl.c0, M, aload, bload, pre, epi, smem);
 }
+// The same 32 x 32 tile WITHOUT operand staging: the contraction runs over the batch (K = M <= a few hundred), so a tile's
+// operands are K x 32 floats each and every k-step of an MFMA chain can be fed straight from L2: lane (li, lg) loads the two
+// floats X[k0 + lg][r0 + 2 li .. + 1] and dV[k0 + lg][c0 + 2 li .. + 1] (16 lanes x 8 B = one 128-byte run per k) and uses them as
+// the A / B operands of the 2 x 2 sub-tiles whose row i / column j stand for output row r0 + 2 i + s / column c0 + 2 j + s'.  The
+// NW waves of the workgroup split K and add their accumulators through LDS (fixed order); no LDS staging, no barrier inside the
+// K loop, all loads of a wave in flight at once.  EXPERIMENT (G4R_DT=0), not the default: measured against the staged tile it is
+// no faster (cfg3: 20.8 vs 19.1 us alone), because both are bound by L2 -> CU bandwidth, not by staging.
+__device__ __forceinline__ float2 ld2_if(const GAS float* base, size_t off, bool ok) {
+    const float2 v = *(const GAS float2*)(base + (ok ? off : (size_t)0));
+    return make_float2(ok ? v.x : 0.f, ok ? v.y : 0.f);
+}
+template <int NW>
+__device__ __forceinline__ void dense_grad_direct(const DevModel& m, StepState* st, const DenseTile* tiles_, int tile, float* smem) {
+    const GAS DenseTile* tiles = (const GAS DenseTile*)tiles_;
+    GAS long long* trc = m.dbgtile ? m.dbgtile + 8 * (size_t)tile : nullptr;
+    const long long tr0 = trc ? wall_clock64() : 0;
+    const StepCtx c = load_ctx(st);
+    const DenseTile tl = tiles[tile];
+    const GAS float* X = tl.gather ? (const GAS float*)m.yin0 : ((c.g & 1) ? tl.X1 : tl.X0);
+    const GAS float* dV = tl.dV;
+    const int M = c.M;
+    const bool ones = (X == nullptr);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const float lr = m.lr, momc = m.mom, lmbd = m.lmbd;
+    const int inplace = m.apply_dense_inplace;
+    long long tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0;
+    if (trc) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tr1 = wall_clock64(); }      // context + descriptor here
+    GAS float *dp = m.dense_p, *dacc = m.dense_acc, *dvel = m.dense_vel, *dg = m.dense_g;
+    // optimizer state of the elements this lane finishes (issued first: they fly during the K loop).  Finishing wave w takes
+    // output rows of parity sa = w & 1 and NRG = 8 / NW accumulator registers rg of every lane, both columns (sb = 0, 1) of each:
+    // 16 lanes x 8 bytes = 128-byte runs.
+    constexpr int NRG = 8 / NW;                        // 1 (8 waves) or 2 (4 waves)
+    const int sa = wid & 1, rg0 = (wid >> 1) * NRG;
+    float2 pa[NRG], pp[NRG], pv[NRG];
+    size_t eoff[NRG];
+    bool eok[NRG];
+#pragma unroll
+    for (int q = 0; q < NRG; ++q) {
+        const int row = tl.r0 + 2 * (4 * lg + rg0 + q) + sa, col = tl.c0 + 2 * li;
+        eok[q] = row < tl.nrows && col < tl.ncols;      // column counts are even
+        eoff[q] = (size_t)tl.base + (size_t)row * tl.ldo + col;
+        const bool ok = eok[q] && inplace;
+        const size_t o = ok ? eoff[q] : (size_t)0;
+        pa[q] = *(const GAS float2*)(dacc + o);
+        pp[q] = *(const GAS float2*)(dp + o);
+        pv[q] = make_float2(0.f, 0.f);
+        if (momc > 0.f) pv[q] = *(const GAS float2*)(dvel + o);
+    }
+    const int nsteps = (M + 3) >> 2, per = (nsteps + NW - 1) / NW;
+    const int s0 = wid * per, s1 = min(nsteps, s0 + per);
+    const int mcol = tl.r0 + 2 * li, ncol = tl.c0 + 2 * li;
+    const bool mok = mcol < tl.nrows, nok = ncol < tl.ncols;      // row / column counts are even (1 for the bias row: `ones`)
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8;
+    for (int s = s0; s < s1; s += U) {
+        float2 av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = 4 * (s + u) + lg;
+            const bool ok = (s + u < s1) && k < M;
+            if (ones) av[u] = make_float2((ok && mcol == 0) ? 1.f : 0.f, 0.f);
+            else av[u] = ld2_if(X, (size_t)k * tl.ldx + mcol, ok && mok);
+            bv[u] = ld2_if(dV, (size_t)k * tl.ldv + tl.coff + ncol, ok && nok);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc[0][0] = mfma16(av[u].x, bv[u].x, acc[0][0]);
+            acc[0][1] = mfma16(av[u].x, bv[u].y, acc[0][1]);
+            acc[1][0] = mfma16(av[u].y, bv[u].x, acc[1][0]);
+            acc[1][1] = mfma16(av[u].y, bv[u].y, acc[1][1]);
+        }
+    }
+    if (trc) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tr2 = wall_clock64(); }      // K loop done (and pre loads landed)
+    // partial accumulators of the NW waves -> LDS, summed in wave order by the finishing waves
+    f32x4* sR = reinterpret_cast<f32x4*>(smem);      // [NW][4 sub-tiles][64 lanes]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) sR[(wid * 4 + 2 * a + b) * 64 + lane] = acc[a][b];
+    __syncthreads();
+    if (trc) tr3 = wall_clock64();
+    float gx[NRG], gy[NRG];
+#pragma unroll
+    for (int q = 0; q < NRG; ++q) { gx[q] = 0.f; gy[q] = 0.f; }
+    for (int w = 0; w < NW; ++w) {
+        const f32x4 o0 = sR[(w * 4 + 2 * sa + 0) * 64 + lane], o1 = sR[(w * 4 + 2 * sa + 1) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < NRG; ++q) { gx[q] += o0[rg0 + q]; gy[q] += o1[rg0 + q]; }
+    }
+#pragma unroll
+    for (int q = 0; q < NRG; ++q) {
+        if (!eok[q]) continue;
+        const float g[2] = {gx[q], gy[q]};
+        if (!inplace) { *(GAS float2*)(dg + eoff[q]) = make_float2(g[0], g[1]); continue; }
+        const float a0[2] = {pa[q].x, pa[q].y}, p0[2] = {pp[q].x, pp[q].y}, v0[2] = {pv[q].x, pv[q].y};
+        float an[2], pn[2], vn[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            an[e] = a0[e] + g[e] * g[e];            // gru4rec.py:330-334,390-406
+            const float gs = g[e] * frsq(an[e] + G4R_EPS_ADAGRAD);
+            if (momc > 0.f) { vn[e] = momc * v0[e] - lr * (gs + lmbd * p0[e]); pn[e] = p0[e] + vn[e]; }
+            else { vn[e] = 0.f; pn[e] = p0[e] * (1.0f - lr * lmbd) - lr * gs; }
+        }
+        *(GAS float2*)(dacc + eoff[q]) = make_float2(an[0], an[1]);
+        *(GAS float2*)(dp + eoff[q]) = make_float2(pn[0], pn[1]);
+        if (momc > 0.f) *(GAS float2*)(dvel + eoff[q]) = make_float2(vn[0], vn[1]);
+    }
+    if (trc) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tr4 = wall_clock64();
+        if (tid == 0) { trc[0] = tr0; trc[1] = tr1; trc[2] = tr2; trc[3] = tr3; trc[4] = tr4; trc[5] = c.t; trc[6] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) ; }
+    }
+}
+template <int DT>
 __global__ __launch_bounds__(GT_NTH_FEW) void k_dense_grad(const DevModel* __restrict__ mp, StepState* st, const DenseTile* __restrict__ tiles_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    dense_grad_tile(*mp, st, tiles_, blockIdx.x, smem);
+    if constexpr (DT == 0) dense_grad_direct<GT_NTH_FEW / 64>(*mp, st, tiles_, blockIdx.x, smem);
+    else dense_grad_tile<DT>(*mp, st, tiles_, blockIdx.x, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1784,15 +1905,18 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevMod
 // (the tiles read layer-0 input rows from yin0, not from the table), so they share ONE launch: blocks [0, ntiles) are
 // dense tiles, the rest sparse-update blocks.  One dispatch (~4.5 us) less per step.
 static_assert(GT_NTH_FEW == SP_WAVES * 64, "both roles use the same workgroup size");
-template <int MAXCH>
+template <int MAXCH, int DT>
 __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_update(const DevModel* __restrict__ mp, StepState* st, const DenseTile* __restrict__ tiles_,
                                                              int ntiles, int nblk_occ) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // workgroup 0: step bookkeeping (dispatched first: off the tail), then the dense tiles, then the sparse-update workgroups
+    // (interleaving the two kinds in dispatch order was measured: no change -- both draw on L2 / fabric bandwidth)
     const int b = (int)blockIdx.x - 1;
     if (b < 0) sparse_update_block<MAXCH>(mp, st, nblk_occ, nblk_occ, smem);
-    else if (b < ntiles) dense_grad_tile(*mp, st, tiles_, b, smem);
-    else sparse_update_block<MAXCH>(mp, st, nblk_occ, b - ntiles, smem);
+    else if (b < ntiles) {
+        if constexpr (DT == 0) dense_grad_direct<SP_WAVES>(*mp, st, tiles_, b, smem);
+        else dense_grad_tile<DT>(*mp, st, tiles_, b, smem);
+    } else sparse_update_block<MAXCH>(mp, st, nblk_occ, b - ntiles, smem);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -204,7 +204,14 @@ int g4r_comm_nranks(g4r_model* m);                             /* ranks RCCL rep
 /* ---- debugging / tests ---------------------------------------------------------------------- */
 /* copy a named intermediate of the most recent step (e.g. "scores", "dS", "dV0", "hd0") */
 int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count);
-int g4r_selftest_mfma(float* max_abs_err);                    /* 16x16x4 f32 MFMA layout check */
+int g4r_selftest_mfma(float* max_abs_err);
+/* Row gather / scatter micro-benchmark on a table of n_items x W floats (fresh allocation, random rows, every launch its own
+ * rows): mode 0 gather to a compact buffer, 1 gather consumed in registers (what the step's fused gathers do), 2 Adagrad scatter
+ * (gradient row read + parameter r/w + accumulator r/w).  Replaces, as an object of measurement, the reference's gather kernel
+ * custom_theano_ops.py:505-519 and its sparse Adagrad scatter gru4rec.py:335-340,428-431.  kernel_us: mean dispatch-to-completion
+ * time of a launch (HIP events attached to the dispatch); wall_us: back-to-back launches on one stream, per launch. */
+int g4r_bench_rows(int32_t device, int64_t n_items, int32_t W, int64_t rows_per_launch, int32_t launches, int32_t mode, uint64_t seed,
+                   double* kernel_us, double* wall_us);                    /* 16x16x4 f32 MFMA layout check */
 
 #ifdef __cplusplus
 }
