@@ -217,6 +217,7 @@ def main():
     ap.add_argument('--profile-steps', type=int, default=300)
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-micro', action='store_true', help='skip the row gather / scatter micro-benchmark object')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -315,22 +316,56 @@ def main():
             kern[name] = e
         out['kernels'] = kern
         out['kernel_time_sum_us_per_step'] = sum(1000.0 * ms / n_profile for ms, n in kt.values())
-        # the roofline entry: the embedding gather/scatter kernel north_star names (HBM-bound)
-        rk = 'k_update' if 'k_update' in kern else 'k_sparse_update'
-        k = kern.get(rk)
-        if k:
-            traffic, tnote = None, ''
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic_%s.json' % args.config)
-            if os.path.exists(pmc):     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_summary.py)
-                traffic = json.load(open(pmc))['kernels'].get(rk, {}).get('traffic_bytes')
-                tnote = '; traffic = 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/%s)' % os.path.basename(pmc)
-            out['roofline'] = {'kernel': rk, 'bound': 'hbm', 'achieved': k['achieved'], 'peak': 8000.0,
-                               'unit': 'GB/s', 'frac': k['achieved'] / 8000.0, 'traffic': traffic,
-                               'note': 'algorithmic bytes per launch = %d (sparse update: gradient rows + param/accumulator r/w per '
-                                       'occurrence, SURVEY 8d; + dense params/accumulators r/w when the dense tiles share the launch); '
-                                       'the 15 MB table is Infinity-Cache resident at cfg2%s' % (alg[rk]['bytes'], tnote)}
         dom = max(kern.items(), key=lambda kv: kv[1]['avg_us'] * kv[1]['launches_per_step'])
         out['dominant_kernel'] = dom[0]
+        pmc_path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_%s.json' % args.config)
+        pmc = json.load(open(pmc_path))['kernels'] if os.path.exists(pmc_path) else {}
+
+        def traffic_of(name):      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_summary.py), bytes per launch
+            for k, v in pmc.items():
+                if k == name or k.startswith(name):
+                    return v.get('traffic_bytes')
+            return None
+        # the roofline entry: the DOMINANT kernel of the step (largest time per step), priced with its algorithmic flops / bytes
+        dk, dv = dom
+        if 'bound' in dv:
+            a = alg[dk]
+            out['roofline'] = {'kernel': dk, 'bound': dv['bound'], 'achieved': dv['achieved'], 'peak': PEAK[dv['bound']][0],
+                               'unit': dv['unit'], 'frac': dv['frac'], 'traffic': traffic_of(dk),
+                               'algorithmic': a.get('flops', a.get('bytes')), 'avg_us': dv['avg_us'],
+                               'note': 'dominant kernel of the step by time; achieved = algorithmic %s per launch / mean launch duration '
+                                       '(HIP events attached to the dispatches, %d steps); traffic = 2 x FETCH_SIZE + WRITE_SIZE from separate '
+                                       'rocprofv3 --pmc passes (profiles/%s) when that file is present' % (
+                                           'flops' if dv['bound'] == 'mfma' else 'bytes', n_profile, os.path.basename(pmc_path))}
+        # the launch that holds the embedding gather / scatter north_star names: SPARSE bytes only (gradient row read +
+        # parameter r/w + accumulator r/w per gathered occurrence, By path, index list); the dense parameters it also updates on a
+        # single GPU are listed separately, not counted
+        rk = 'k_update' if 'k_update' in kern else ('k_sparse_update' if 'k_sparse_update' in kern else None)
+        if rk:
+            k = kern[rk]
+            sparse_bytes = alg['k_sparse_update']['bytes']
+            gbps = sparse_bytes / (k['avg_us'] * 1e-6) / 1e9
+            out['roofline_gather_scatter'] = {
+                'kernel': rk, 'bound': 'hbm', 'achieved': gbps, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbps / 8000.0,
+                'traffic': traffic_of(rk), 'sparse_bytes': sparse_bytes, 'avg_us': k['avg_us'],
+                'dense_param_bytes_same_launch': (alg['k_update']['bytes'] - sparse_bytes) if rk == 'k_update' else 0,
+                'note': 'sparse bytes per launch = (5 R D + 5 N + R) * 4, R = 2B + n_sample gathered rows, N = B + n_sample score columns '
+                        '(SURVEY 8d); on one GPU the same launch also holds the dense-gradient tiles (their parameter / accumulator bytes '
+                        'are listed, not counted)%s' % ('; the %d-item table (%.0f MB) is Infinity-Cache resident at this config' % (
+                            cfg['n_items'], cfg['n_items'] * cfg['layers'][-1] * 4 / 1e6) if cfg['n_items'] * cfg['layers'][-1] * 4 < 2.5e8 else '')}
+        if not args.no_micro:
+            # the access pattern alone (tools/micro_rows.py for the full sweep): R random rows of a table far beyond the Infinity Cache
+            W = max(4, (cfg['layers'][-1] + 3) // 4 * 4)
+            R = 2 * cfg['batch_size'] + cfg['n_sample']
+            n_big = int(6.2e9 / (4 * W))
+            micro = []
+            for mode, name, streams in ((1, 'gather_fused', 1), (2, 'adagrad_scatter', 5)):
+                for mult in (1, 16):
+                    k_us, _ = _native.bench_rows(n_big, W, R * mult, launches=100 if mult == 1 else 40, mode=mode)
+                    nb = streams * R * mult * W * 4 + R * mult * 4
+                    micro.append({'mode': name, 'rows_per_launch': R * mult, 'steps_batched': mult, 'width': W, 'table_GB': n_big * W * 4 / 1e9 * (2 if mode == 2 else 1),
+                                  'kernel_us': k_us, 'GBps': nb / k_us / 1e3, 'frac_of_8TBps': nb / k_us / 1e3 / 8000.0})
+            out['gather_scatter_micro'] = micro
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, plan, support)
     m.close()

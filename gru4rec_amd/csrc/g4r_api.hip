@@ -164,6 +164,9 @@ static constexpr auto k_score_fwd_k128 = k_score_fwd<GT_BN, GT_BK>;
 #define SFW_BN 32
 #define SFW_BK 64
 static constexpr auto k_score_fwd_k64 = k_score_fwd<SFW_BN, SFW_BK>;
+static constexpr auto k_score_fwd_t2 = k_score_fwd<64, 32>;      // gemm_tile2: 64 x 64 tiles, double-buffered 32-deep chunks
+static const size_t SMEM_SF2 = (size_t)Tile2Cfg<T2_BK>::SMEM_FLOATS * sizeof(float);
+static inline bool score_tile2() { static const bool off = getenv("G4R_NO_TILE2") != nullptr; return !off; }
 static const size_t SMEM_SF64 = tile_smem<SF_BM, SFW_BN, SFW_BK, false, true>() + SFW_BN * sizeof(int);
 static constexpr auto k_score_bwd_n = k_score_bwd<32, GT_BK>;
 static constexpr auto k_score_bwd_w = k_score_bwd<64, 64>;
@@ -356,6 +359,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_p2, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_k128, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_k64, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_t2, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd_n, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_fwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -377,7 +381,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel"); }
     if (getenv("G4R_CLK")) {
-        if (dalloc(m, &d.dbgclk, 64 + 8 * (size_t)d.R) || dalloc(m, &d.dbgtile, 8 * (size_t)std::max(m->ntiles, 1))) { g4r_destroy(m); return -1; }
+        if (dalloc(m, &d.dbgclk, 64 + 8 * (size_t)d.R) || dalloc(m, &d.dbgtile, 8 * (size_t)(4096 + 4096))) { g4r_destroy(m); return -1; }
     }
     if (dalloc(m, &m->d_dm, 1) || sync_dm(m)) { g4r_destroy(m); return -1; }
     *out = m;
@@ -677,7 +681,8 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         end();
     }
     begin(KN_SCORE_FWD);
-    if (wide_scores(d)) LK(k_score_fwd_k64, dim3(cdiv(d.ldSc, SFW_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF64, s, dmp, stp);
+    if (wide_scores(d) && score_tile2() && d.Dtop % T2_BK == 0) LK(k_score_fwd_t2, dim3(cdiv(d.ldSc, 64), cdiv(B, 64)), dim3(GT_NTH), SMEM_SF2, s, dmp, stp);
+    else if (wide_scores(d)) LK(k_score_fwd_k64, dim3(cdiv(d.ldSc, SFW_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF64, s, dmp, stp);
     else LK(k_score_fwd_k128, dim3(cdiv(d.ldSc, GT_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF, s, dmp, stp);
     end();
     begin(KN_LOSS);
@@ -1539,10 +1544,20 @@ int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
     else if (s == "Hprev") { p = d.H[l][(m->gstep + 1) & 1]; n = bd; }
     else if (s == "occ_idx") { p = (const float*)d.occ_idx; n = d.R; }
     else if (s == "dbgclk") { if (!d.dbgclk) return fail("G4R_CLK not set"); p = (const float*)d.dbgclk; n = 2 * (64 + 8 * (int64_t)d.R); }
-    else if (s == "dbgtile") { if (!d.dbgtile) return fail("G4R_CLK not set"); p = (const float*)d.dbgtile; n = 2 * 8 * (int64_t)std::max(m->ntiles, 1); }
+    else if (s == "dbgtile") { if (!d.dbgtile) return fail("G4R_CLK not set"); p = (const float*)d.dbgtile; n = 2 * 8 * (int64_t)8192; }      // [0, 4096): dense tiles, [4096, 8192): k_score_fwd tiles
     else if (s == "ntiles") { if (count < 1) return fail("count"); host[0] = (float)m->ntiles; return 0; }
     else if (s == "ldSc") { if (count < 1) return fail("count"); host[0] = (float)d.ldSc; return 0; }
     else if (s == "ksplit") { if (count < 1) return fail("count"); host[0] = (float)d.ksplit; return 0; }
+    else if (s == "occ_score_tile") {      // resident workgroups per CU the runtime reports for the gemm_tile2 scoring kernel
+        if (count < 1) return fail("count");
+        int nb = 0;
+        for (size_t lds = SMEM_SF2; lds >= SMEM_SF2 - 2048; lds -= 512) {
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_score_fwd_t2, GT_NTH, lds));
+            fprintf(stderr, "[g4r] k_score_fwd_t2 dynamic LDS %zu -> %d workgroups per CU\n", lds, nb);
+        }
+        host[0] = (float)nb;
+        return 0;
+    }
     else if (s == "graph_mode") {      // 0: no graph yet, 1: whole steps replayed (RCCL captured when N > 1), 2: head graph + eager tail
         if (count < 1) return fail("count");
         host[0] = m->gexec ? 1.f : (m->gexec_head ? 2.f : 0.f);
@@ -1631,6 +1646,23 @@ int g4r_selftest_mfma(float* max_abs_err) {
     (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
     float e = 0.f;
     for (int i = 0; i < 256; ++i) e = std::max(e, std::fabs(C[i] - R[i]));
+    // 32x32x2 shape (gemm_tile2)
+    {
+        const int K2 = 18;
+        std::vector<float> A2(32 * K2), B2(K2 * 32), C2(1024), R2(1024, 0.f);
+        for (int i = 0; i < 32; ++i) for (int k = 0; k < K2; ++k) A2[i * K2 + k] = 0.25f * (float)((i * 5 + k * 3) % 13) - 1.5f;
+        for (int k = 0; k < K2; ++k) for (int j = 0; j < 32; ++j) B2[k * 32 + j] = 0.5f * (float)((k * 7 + j * 11) % 9) - 2.0f + 0.01f * j;
+        for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) { float s = 0.f; for (int k = 0; k < K2; ++k) s = fmaf(A2[i * K2 + k], B2[k * 32 + j], s); R2[i * 32 + j] = s; }
+        float *dA2, *dB2, *dC2;
+        HIPCHK(hipMalloc(&dA2, A2.size() * 4)); HIPCHK(hipMalloc(&dB2, B2.size() * 4)); HIPCHK(hipMalloc(&dC2, 1024 * 4));
+        HIPCHK(hipMemcpy(dA2, A2.data(), A2.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dB2, B2.data(), B2.size() * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_selftest_mfma32, dim3(1), dim3(64), 0, 0, (const float*)dA2, (const float*)dB2, dC2, K2);
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(C2.data(), dC2, 1024 * 4, hipMemcpyDeviceToHost));
+        (void)hipFree(dA2); (void)hipFree(dB2); (void)hipFree(dC2);
+        for (int i = 0; i < 1024; ++i) e = std::max(e, std::fabs(C2[i] - R2[i]));
+    }
     if (max_abs_err) *max_abs_err = e;
     return 0;
 }

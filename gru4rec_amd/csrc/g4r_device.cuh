@@ -188,6 +188,15 @@ __device__ __forceinline__ float block_max_256(float v, float* red) {
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// D(32x32) += A(32x2) * B(2x32), fp32.  lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; holds
+// D[row = 8*(reg>>2) + 4*(l>>5) + (reg&3)][col = l&31] in its 16 registers.  Measured on MI355X with register-resident operands
+// (tools/probes/mfma_probe.hip): this shape sustains 155 TFLOP/s (65 cycles per 4096 flop per SIMD) from ONE dependent chain per
+// wave, the 16x16x4 shape 99-126 TFLOP/s (40-51 cycles per 2048 flop) whatever the number of chains / waves: the mid-size GEMMs
+// (gemm_tile2) use this one.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
 
 
 // ---------------------------------------------------------------------------------------------

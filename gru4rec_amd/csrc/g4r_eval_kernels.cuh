@@ -227,6 +227,15 @@ __global__ void k_selftest_mfma(const float* A, const float* Bm, float* C, int K
     for (int rg = 0; rg < 4; ++rg) C[(4 * lg + rg) * 16 + li] = acc[rg];
 }
 
+// 32x32x2 fp32 MFMA operand/accumulator layout self-test: C(32x32) = A(32xK) * B(Kx32)
+__global__ void k_selftest_mfma32(const float* A, const float* Bm, float* C, int K) {
+    const int lane = threadIdx.x & 63, l32 = lane & 31, lh = lane >> 5;
+    f32x16 acc;
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int k = 0; k < K; k += 2) acc = mfma32(A[l32 * K + k + lh], Bm[(k + lh) * 32 + l32], acc);
+    for (int r = 0; r < 16; ++r) C[(8 * (r >> 2) + 4 * lh + (r & 3)) * 32 + l32] = acc[r];
+}
+
 __global__ void k_scale(float* p, long long n, float s) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] *= s;
@@ -245,6 +254,7 @@ template __global__ void k_dense_grad<0>(const DevModel*, StepState*, const Dens
 template __global__ void k_dense_grad<32>(const DevModel*, StepState*, const DenseTile*);
 template __global__ void k_score_fwd<GT_BN, GT_BK>(const DevModel*, StepState*);
 template __global__ void k_score_fwd<32, 64>(const DevModel*, StepState*);
+template __global__ void k_score_fwd<64, 32>(const DevModel*, StepState*);
 template __global__ void k_score_bwd<32, GT_BK>(const DevModel*, StepState*, int, int, int, int);
 template __global__ void k_score_bwd<64, 64>(const DevModel*, StepState*, int, int, int, int);
 template __global__ void k_gru_p1<GT_BN, P1_BK>(const DevModel*, StepState*, int, int, int, GruFwdPredict);

@@ -195,3 +195,119 @@ __device__ __forceinline__ void gemm_tile(int m0, int n0, int K, ALoad aload, BL
     }
     if (clk && tid == 0) clk[3] = wall_clock64();      // epilogue issued
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// gemm_tile2: the tile for the MID-SIZE GEMMs (hundreds of MFLOP: scoring at thousands of negatives, wide layers).  Both
+// operands K-contiguous in memory (A [m][k], B [n][k]), K a multiple of 32.
+//   * 64 x 64 tile, 4 waves as 2 x 2, each wave a 32 x 32 quadrant = ONE v_mfma_f32_32x32x2_f32 accumulator (g4r_device.cuh: the
+//     32x32x2 shape sustains 155 TFLOP/s, the 16x16x4 shape 100-126): one A and one B fragment read per MFMA;
+//   * K in chunks of 32 through a DOUBLE-buffered LDS tile: the loads of chunk i + 1 are issued before the MFMAs of chunk i and
+//     written to the other buffer behind them -- ONE barrier per chunk;
+//   * the LDS tile is exactly 32 KiB (FIVE workgroups per CU: at B = 512, N = 8704 all 1088 tiles are resident at once; with
+//     padded rows, 35 KB, four fit and the 64 tiles of the second round stretched the launch from 23 to 33 us): rows are 32 floats,
+//     element (row, k) sits at k ^ (2 * ((row >> 1) & 15)), which keeps the fragment reads conflict-free (lanes 0-31 = rows of one
+//     quadrant, same k: 32 distinct even banks; lanes 32-63 the odd ones) and the staging stores 8-byte aligned;
+//   * operands come as ROW POINTERS (`arow(r)` / `brow(r)`: start of row r of the tile, or nullptr for a row outside the
+//     matrix / an inactive gathered item), resolved once per thread before the K loop: per chunk a thread spends one 64-bit add
+//     per load.  (Counters at B = 512, N = 8704, D = 256, rocprofv3 --pmc: with providers that rebuild (row * D + k) and its
+//     clamp for every chunk the VALU work per wave equalled the MFMA work, MFMA pipe 28 % busy.)
+//   * epilogue operands (`pre`, 16 per lane) are requested before the K loop.
+template <int BK2>
+struct Tile2Cfg {
+    static constexpr int BM = 64, BN = 64, BK = BK2, LDK = BK2;
+    static constexpr int SMEM_FLOATS = 2 * (BM + BN) * LDK;
+};
+// PRE_COL: `pre` depends on the column only (a bias per column): one fetch per lane instead of one per element.
+// BK2 = 32: 32 KiB of LDS per workgroup; BK2 = 16: 16 KiB (the runtime reports 5 workgroups per CU for 32 KiB, but only 4 run:
+// with 16 KiB the register file sets the limit, 5).
+template <int BK2, bool PRE_COL, class ARow, class BRow, class Pre, class Epi>
+__device__ __forceinline__ void gemm_tile2(int m0, int n0, int K, ARow arow, BRow brow, Pre pre, Epi epi, float* smem, GAS long long* trc = nullptr) {
+    using C = Tile2Cfg<BK2>;
+    static_assert(BK2 == 16 || BK2 == 32, "chunk depth");
+    constexpr int LDK = C::LDK, BUF = 64 * LDK;
+    constexpr int TPR = BK2 / 4, RPP = 256 / TPR, NQ = 64 / RPP;      // threads per row, rows per pass, passes (quads per thread and operand)
+    constexpr int SWS = BK2 == 32 ? 1 : 2, SWM = BK2 == 32 ? 15 : 7;  // swizzle = 2 * ((row >> SWS) & SWM)
+    // buffer b of A at smem + b * BUF, of B at smem + (2 + b) * BUF -- as OFFSETS from the one LDS base: an array of two pointers
+    // indexed by (i & 1) loses the address space and the fragment reads compile to flat_load (which also drain vmcnt)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int sr = tid / TPR, sc = 4 * (tid % TPR);      // staging slots of a thread: rows sr + RPP q, k offset sc, of A and of B
+    const GAS float* pa[NQ];
+    const GAS float* pb[NQ];
+    bool oka[NQ], okb[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const GAS float* a = arow(sr + RPP * q);
+        const GAS float* b = brow(sr + RPP * q);
+        oka[q] = a != nullptr; okb[q] = b != nullptr;
+        pa[q] = (oka[q] ? a : arow(0)) + sc;          // rows outside the matrix re-read a valid row; their quads are zeroed at commit
+        pb[q] = (okb[q] ? b : brow(0)) + sc;
+    }
+    float4 ra[NQ], rb[NQ];
+    auto issue = [&]() {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { ra[q] = ld4(pa[q]); rb[q] = ld4(pb[q]); pa[q] += C::BK; pb[q] += C::BK; }
+    };
+    auto commit = [&](int buf) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float4 va = oka[q] ? ra[q] : z, vb = okb[q] ? rb[q] : z;
+            // swizzle of the row: the quad moves as a whole by bits >= 2, its halves swap by bit 1
+            const int row = sr + RPP * q, sw = 2 * ((row >> SWS) & SWM);
+            float2* da = reinterpret_cast<float2*>(smem + buf * BUF + row * LDK + (sc ^ (sw & ~3)));
+            da[(sw >> 1) & 1] = make_float2(va.x, va.y); da[((sw >> 1) & 1) ^ 1] = make_float2(va.z, va.w);
+            float2* db = reinterpret_cast<float2*>(smem + (2 + buf) * BUF + row * LDK + (sc ^ (sw & ~3)));
+            db[(sw >> 1) & 1] = make_float2(vb.x, vb.y); db[((sw >> 1) & 1) ^ 1] = make_float2(vb.z, vb.w);
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    const int l32 = lane & 31, lh = lane >> 5;
+    const int sw_fr = 2 * ((l32 >> SWS) & SWM);        // swizzle of this lane's fragment row (the same for A and B quadrant rows)
+    const int nchunk = K / C::BK;
+    issue();
+    // epilogue operands of the 16 elements this lane finishes (rows 8 g + 4 lh + r of the quadrant, column l32): requested here,
+    // they land during the K loop (fetched behind it, sub-tile by sub-tile, they cost 7 us per tile in the in-kernel trace:
+    // all tiles of the launch reach their epilogue together, so nothing else fills the MFMA pipe meanwhile)
+    const int n = n0 + wn * 32 + l32;
+    constexpr int NPF = PRE_COL ? 1 : 16;
+    float4 pf[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) pf[j] = pre(m0 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3), n);
+    commit(0);
+    if (trc && tid == 0) trc[2] = wall_clock64();          // first chunk landed and written
+    for (int i = 0; i < nchunk; ++i) {
+        __syncthreads();                                   // chunk i is in buffer i & 1; buffer (i + 1) & 1 is no longer read
+        const float* fa = smem + (i & 1) * BUF + (wm * 32 + l32) * LDK + lh;
+        const float* fb = smem + (2 + (i & 1)) * BUF + (wn * 32 + l32) * LDK + lh;
+        // groups of 8 k-steps (fragment registers for 8: 5 waves per SIMD need <= 96 registers)
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { av[u] = fa[(2 * u) ^ sw_fr]; bv[u] = fb[(2 * u) ^ sw_fr]; }
+        // chunk i + 1: loads out now (behind the LDS address arithmetic), landed by the end of this chunk's MFMAs, written to the
+        // other buffer before the next barrier.  Issue and commit sit in the SAME iteration on purpose: carried around the loop
+        // edge, the loaded registers were copied out right behind the loads (a full memory round trip per chunk).
+        const bool more = i + 1 < nchunk;
+        if (more) issue();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = mfma32(av[u], bv[u], acc);
+        if constexpr (BK2 == 32) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { av[u] = fa[(16 + 2 * u) ^ sw_fr]; bv[u] = fb[(16 + 2 * u) ^ sw_fr]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = mfma32(av[u], bv[u], acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) commit((i + 1) & 1);
+    }
+    if (trc && tid == 0) trc[3] = wall_clock64();          // K loop done
+    // lane holds rows 8 (reg >> 2) + 4 lh + (reg & 3), column l32 of the wave's quadrant: 32 lanes x 4 bytes = 128-byte runs
+#pragma unroll
+    for (int j = 0; j < 16; ++j) epi(m0 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3), n, acc[j], pf[PRE_COL ? 0 : j]);
+    if (trc && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[4] = wall_clock64(); }
+}

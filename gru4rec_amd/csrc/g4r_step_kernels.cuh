@@ -533,13 +533,19 @@ __global__ __launch_bounds__(512) void k_gru_fwd_fused(const DevModel* __restric
 #ifndef SF_BM
 #define SF_BM 64
 #endif
+#ifndef T2_BK
+#define T2_BK 16     // K chunk of the gemm_tile2 kernels
+#endif
 template <int TBN, int TBK>
 __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict__ mp, StepState* st) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
-    using C = TileCfg<SF_BM, TBN, TBK, false, true>;
-    int* sItem = reinterpret_cast<int*>(smem + C::SMEM_FLOATS);   // [TBN]
+    constexpr int SMEM_TILE = (TBN == 64 && TBK == 32) ? Tile2Cfg<T2_BK>::SMEM_FLOATS : TileCfg<SF_BM, TBN, TBK, false, true>::SMEM_FLOATS;
+    int* sItem = reinterpret_cast<int*>(smem + SMEM_TILE);   // [TBN]
     const int tid = threadIdx.x;
+    const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
+    GAS long long* trc = (m.dbgtile && wgid < 4096) ? m.dbgtile + 8 * (size_t)(4096 + wgid) : nullptr;
+    if (trc && tid == 0) trc[0] = wall_clock64();
     const StepCtx c = load_ctx(st);
     const int M = c.M, B = m.B, D = m.Dtop, N = m.N;
     const int n0 = blockIdx.x * TBN, m0 = blockIdx.y * SF_BM;
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
         const int n = n0 + tid;
         int item = m.cur_col[min(n, m.ldSc - 1)];      // targets | samples of this step, staged by the previous step's bookkeeping
         if (n >= m.ldSc) item = -1;
-        sItem[tid] = item;
+        if constexpr (!(TBN == 64 && TBK == 32)) sItem[tid] = item;
         if (blockIdx.y == 0 && n < m.ldSc) {
             m.col_item[n] = item;
             if (n < N) {
@@ -563,6 +569,7 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
     }
     if (m0 >= M) return;
     __syncthreads();
+    if (trc && tid == 0) { trc[1] = wall_clock64(); trc[5] = c.t; }      // step context + column items here
     const GAS float* hsrc = m.hd[m.n_layers - 1];
     const GAS float *Wy = m.Wy, *By = m.By, *lq_tgt = m.lq_tgt, *lq_smp = m.lq_smp;
     GAS float* Sc = m.Sc;
@@ -588,7 +595,25 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
         if (row >= M || n >= N) return;
         Sc[(size_t)row * ldSc + n] = v + p.x;
     };
-    gemm_tile<SF_BM, TBN, TBK, false, true, GT_NTH>(m0, n0, D, aload, bload, pre, epi, smem);
+    if constexpr (TBN == 64 && TBK == 32) {      // long score rows / big batches, D a multiple of 32 (host)
+        // the LDS tile fills the workgroup's 32 KiB: column items come straight from the staged list (L2), not from sItem
+        const GAS int* ccol = m.cur_col;
+        const int ldc = m.ldSc;
+        auto arow = [&](int r) -> const GAS float* { return (m0 + r < M) ? hsrc + (size_t)(m0 + r) * D : nullptr; };
+        auto brow = [&](int r) -> const GAS float* {
+            const int item = (n0 + r < ldc) ? ccol[n0 + r] : -1;
+            return item >= 0 ? Wy + (size_t)item * D : nullptr;
+        };
+        auto pre2 = [&](int row, int n) -> float4 {
+            const int item = (n < N) ? ccol[min(n, ldc - 1)] : -1;
+            const bool ok = item >= 0;
+            float x = ldf_at(By, max(item, 0), ok);
+            const bool lq = ok && logq != 0.f;
+            x -= logq * ldf_at(lq ? (n < B ? lq_tgt : lq_smp) : By, max(item, 0), lq);
+            return make_float4(x, 0.f, 0.f, 0.f);
+        };
+        gemm_tile2<T2_BK, true>(m0, n0, D, arow, brow, pre2, epi, smem, trc);
+    } else gemm_tile<SF_BM, TBN, TBK, false, true, GT_NTH>(m0, n0, D, aload, bload, pre, epi, smem);
 }
 
 // ---------------------------------------------------------------------------------------------

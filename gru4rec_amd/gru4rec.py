@@ -39,6 +39,27 @@ def _parse_act(name, allow_softmax):
     raise NotImplementedError
 
 
+def _pad4(n):
+    return (int(n) + 3) // 4 * 4
+
+
+def _pad_cols(a, nblk, D, Dp):
+    """(…, nblk * D) -> (…, nblk * Dp): every one of the nblk column blocks gets Dp - D zero columns."""
+    if D == Dp:
+        return a
+    a = np.asarray(a)
+    out = np.zeros(a.shape[:-1] + (nblk * Dp,), dtype=a.dtype)
+    for b in range(nblk):
+        out[..., b * Dp:b * Dp + D] = a[..., b * D:(b + 1) * D]
+    return out
+
+
+def _strip_cols(a, nblk, D, Dp):
+    if D == Dp:
+        return a
+    return np.concatenate([a[..., b * Dp:b * Dp + D] for b in range(nblk)], axis=-1)
+
+
 def _markers(*names):
     """Methods that only carry a name (a bound method pickles as getattr(obj, __name__))."""
     out = []
@@ -241,7 +262,7 @@ class GRU4Rec:
             raise IndexError('adapt={} needs {} value(s) in adapt_params'.format(self.adapt, need))     # the reference indexes adapt_params[0..1]
         if self.smoothing and self.loss not in ('cross-entropy', 'xe_logit'):
             raise NotImplementedError('smoothing is only defined for cross-entropy / xe_logit (gru4rec.py:226-235)')
-        if not self.constrained_embedding and not self.embedding and 3 * self.layers[0] > 512:
+        if not self.constrained_embedding and not self.embedding and 3 * _pad4(self.layers[0]) > 512:
             raise NotImplementedError('one-hot input (embedding=0, constrained_embedding=False) needs 3 * layers[0] <= 512 '
                                       'in the MI355X path; use constrained_embedding=True or embedding=<size> for wider layers')
 
@@ -253,13 +274,13 @@ class GRU4Rec:
         nranks = self._dist['nranks'] if self._dist else 1
         rank = self._dist['rank'] if self._dist else 0
         m = _native.Model(
-            n_items=int(self.n_items), layers=self.layers, batch_size=int(batch_size or self.batch_size),
+            n_items=int(self.n_items), layers=[_pad4(D) for D in self.layers], batch_size=int(batch_size or self.batch_size),
             n_sample=int(self.n_sample), loss=self._loss_id,
             final_act=self._final[0], final_act_p0=self._final[1], final_act_p1=self._final[2],
             hidden_act=self._hidden[0], hidden_act_p0=self._hidden[1], hidden_act_p1=self._hidden[2],
             embed_mode=_native.EMBED_CONSTRAINED if self.constrained_embedding else (
                 _native.EMBED_SEPARATE if self.embedding else _native.EMBED_ONEHOT),
-            embedding=int(self.embedding or 0), learning_rate=self.learning_rate, momentum=self.momentum,
+            embedding=_pad4(self.embedding or 0), learning_rate=self.learning_rate, momentum=self.momentum,
             lmbd=self.lmbd, bpreg=self.bpreg, logq=self.logq, sample_alpha=self.sample_alpha, smoothing=float(self.smoothing),
             adapt=_native.ADAPT_IDS.get(self.adapt, _native.ADAPT_IDS[None]),      # any other value: plain SGD (gru4rec.py:392-399 fall through)
             adapt_p0=float(self.adapt_params[0]) if len(self.adapt_params) > 0 else 0.0,
@@ -271,31 +292,86 @@ class GRU4Rec:
             m.comm_init(self._dist['unique_id'], nranks, rank)
         return m
 
+    # ---- device layout: the library wants layer / embedding widths that are multiples of 4 (16-byte rows).  Other widths are
+    # padded with zero columns / rows on the way to the device and stripped on the way back.  A padded unit has zero weights in
+    # and out, so its activation is act(0) = 0, its state stays 0, and every gradient, accumulator and update that touches it
+    # is exactly 0 (g = 0 gives a zero step under every `adapt`): the computation on the real units is unchanged.
+    def _dev_spec(self, name, layer):
+        """(rows, padded rows, column blocks, block width, padded block width) of a parameter array; rows = None for vectors."""
+        base = name.split('_', 1)[1] if name.split('_', 1)[0] in ('acc', 'vel', 'acc2', 'cnt') else name
+        L = self.layers
+        D = L[layer] if base in ('Wx', 'Wh', 'Wrz', 'Bh', 'H') else L[-1]
+        if base == 'Wx':
+            if layer > 0:
+                n_in = L[layer - 1]
+            elif self.constrained_embedding:
+                n_in = L[-1]
+            elif self.embedding:
+                n_in = self.embedding
+            else:
+                return self.n_items, self.n_items, 3, D, _pad4(D)      # one-hot input: Wx[0] is the (n_items, 3D) row table
+            return n_in, _pad4(n_in), 3, D, _pad4(D)
+        if base == 'Wh':
+            return D, _pad4(D), 1, D, _pad4(D)
+        if base == 'Wrz':
+            return D, _pad4(D), 2, D, _pad4(D)
+        if base == 'Bh':
+            return None, None, 3, D, _pad4(D)
+        if base == 'H':
+            return None, None, 1, D, _pad4(D)      # rows = batch: taken from the array
+        if base == 'Wy':
+            return self.n_items, self.n_items, 1, D, _pad4(D)
+        if base == 'E':
+            return self.n_items, self.n_items, 1, self.embedding, _pad4(self.embedding)
+        if base == 'By':
+            return None, None, 1, 1, 1
+        raise KeyError(name)
+
+    def _dev_put(self, m, name, arr, layer=0):
+        rows, rows_p, nblk, D, Dp = self._dev_spec(name, layer)
+        a = _pad_cols(np.asarray(arr, dtype=np.float32), nblk, D, Dp) if name.split('_')[-1] != 'By' else np.asarray(arr, dtype=np.float32).reshape(-1)
+        if rows is not None and rows_p != rows:
+            a = np.concatenate([a, np.zeros((rows_p - rows, a.shape[1]), dtype=np.float32)])
+        m.set_param(name, a, layer)
+
+    def _dev_get(self, m, name, shape, layer=0):
+        rows, rows_p, nblk, D, Dp = self._dev_spec(name, layer)
+        if name.split('_')[-1] == 'By':
+            return m.get_param(name, (self.n_items,), layer).reshape(shape)
+        if rows is None:
+            pshape = tuple(shape[:-1]) + (nblk * Dp,)
+        else:
+            pshape = (rows_p, nblk * Dp)
+        a = _strip_cols(m.get_param(name, pshape, layer), nblk, D, Dp)
+        if rows is not None and rows_p != rows:
+            a = a[:rows]
+        return np.ascontiguousarray(a).reshape(shape)
+
     def _upload_weights(self, m):
         for i in range(len(self.layers)):
-            m.set_param('Wx', self.Wx[i], i)
-            m.set_param('Wh', self.Wh[i], i)
-            m.set_param('Wrz', self.Wrz[i], i)
-            m.set_param('Bh', self.Bh[i], i)
-        m.set_param('Wy', self.Wy)
-        m.set_param('By', self.By.reshape(-1))
+            self._dev_put(m, 'Wx', self.Wx[i], i)
+            self._dev_put(m, 'Wh', self.Wh[i], i)
+            self._dev_put(m, 'Wrz', self.Wrz[i], i)
+            self._dev_put(m, 'Bh', self.Bh[i], i)
+        self._dev_put(m, 'Wy', self.Wy)
+        self._dev_put(m, 'By', self.By.reshape(-1))
         if not self.constrained_embedding and self.embedding:
-            m.set_param('E', self.E)
+            self._dev_put(m, 'E', self.E)
 
     def _download_weights(self):
         m = self._model
         L = self.layers
         for i, D in enumerate(L):
             n_in = self.Wx[i].shape[0]
-            self.Wx[i] = m.get_param('Wx', (n_in, 3 * D), i)
-            self.Wh[i] = m.get_param('Wh', (D, D), i)
-            self.Wrz[i] = m.get_param('Wrz', (D, 2 * D), i)
-            self.Bh[i] = m.get_param('Bh', (3 * D,), i)
-            self.H[i] = m.get_param('H', (m.cfg.batch_size, D), i)
-        self.Wy = m.get_param('Wy', (self.n_items, L[-1]))
-        self.By = m.get_param('By', (self.n_items,)).reshape(-1, 1)
+            self.Wx[i] = self._dev_get(m, 'Wx', (n_in, 3 * D), i)
+            self.Wh[i] = self._dev_get(m, 'Wh', (D, D), i)
+            self.Wrz[i] = self._dev_get(m, 'Wrz', (D, 2 * D), i)
+            self.Bh[i] = self._dev_get(m, 'Bh', (3 * D,), i)
+            self.H[i] = self._dev_get(m, 'H', (m.cfg.batch_size, D), i)
+        self.Wy = self._dev_get(m, 'Wy', (self.n_items, L[-1]))
+        self.By = self._dev_get(m, 'By', (self.n_items,)).reshape(-1, 1)
         if not self.constrained_embedding and self.embedding:
-            self.E = m.get_param('E', (self.n_items, self.embedding))
+            self.E = self._dev_get(m, 'E', (self.n_items, self.embedding))
 
     # ---- optimizer state (SURVEY 8f rank 2: "plus new optimizer-state save"; the reference's pickles hold the weights only)
     def _opt_tables(self):
@@ -323,12 +399,12 @@ class GRU4Rec:
         m = self._model
         st = {'arrays': {}, 'global_step': m.global_step(), 'refills': m.refills()}
         for name, layer, shape in self._opt_tables():
-            st['arrays'][(name, layer)] = m.get_param(name, shape, layer)
+            st['arrays'][(name, layer)] = self._dev_get(m, name, shape, layer)
         return st
 
     def _upload_optimizer_state(self, m, st):
         for name, layer, shape in self._opt_tables():
-            m.set_param(name, st['arrays'][(name, layer)], layer)
+            self._dev_put(m, name, st['arrays'][(name, layer)], layer)
         m.set_step_counters(st['global_step'], st['refills'])
 
     def set_distributed(self, rank, nranks, unique_id):
