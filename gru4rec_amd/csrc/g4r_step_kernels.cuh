@@ -764,10 +764,14 @@ __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict
         block_reduce<1, false>(sm, red + 9 * LOSS_NW);
         const float inv_sm = 1.f / sm[0];
         float s[3] = {0.f, 0.f, 0.f};
+        // sigmoid(yd - y_j) = 1 / (1 + exp(y_j - yd)) = 1 / (1 + e_j c) with the stored softmax numerator e_j = exp(y_j - mx) and
+        // the row constant c = exp(mx - yd): no exp per element in the two passes below (the row kernel is bound by transcendental
+        // issue at long rows).  c is clamped so that an underflowed e_j = 0 gives 0 * c = 0 (sigma = 1, and p_j = 0 anyway).
+        const float cexp = fexp(fminf(mx - yd, 80.f));
         if (lossk == G4R_LOSS_BPR_MAX) {
             for (int j = tid; j < N; j += LOSS_T)
                 if (ACTIVE(j) && j != i) {
-                    const float y = sy[j], p = se[j] * inv_sm, sg = sigmoidf_(yd - y);
+                    const float y = sy[j], e = se[j], p = e * inv_sm, sg = frcp(1.0f + e * cexp);
                     s[0] += sg * p;                 // A
                     s[1] += y * y * p;              // Q
                     s[2] += sg * (1.f - sg) * p;    // sum sigma' p
@@ -775,7 +779,7 @@ __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict
         } else {
             for (int j = tid; j < N; j += LOSS_T)
                 if (ACTIVE(j) && j != i) {
-                    const float y = sy[j], p = se[j] * inv_sm, u = sigmoidf_(y - yd), q = sigmoidf_(y * y);
+                    const float y = sy[j], e = se[j], p = e * inv_sm, u = 1.0f - frcp(1.0f + e * cexp), q = sigmoidf_(y * y);
                     s[0] += p * (u + q);            // T
                     s[2] += p * u * (1.f - u);
                 }
@@ -797,12 +801,12 @@ __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict
                 float d;
                 if (j == i) d = dyd;
                 else {
-                    const float p = se[j] * inv_sm;
+                    const float e = se[j], p = e * inv_sm;
                     if (lossk == G4R_LOSS_BPR_MAX) {
-                        const float sg = sigmoidf_(yd - y);
+                        const float sg = frcp(1.0f + e * cexp);
                         d = -p * (sg - sg * (1.f - sg) - s1) * inv_A + bpreg * p * (2.f * y + y * y - s2);
                     } else {
-                        const float u = sigmoidf_(y - yd), q = sigmoidf_(y * y);
+                        const float u = 1.0f - frcp(1.0f + e * cexp), q = sigmoidf_(y * y);
                         d = p * (u + q - s1) + p * (u * (1.f - u) + 2.f * y * q * (1.f - q));
                     }
                 }
