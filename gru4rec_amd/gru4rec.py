@@ -121,6 +121,7 @@ class GRU4Rec:
         self.steps_per_call = 16384  # plan steps per C-ABI call (NaN check granularity)
         self._model = None
         self._dist = None
+        self._cpu_store = False
         self.loss_history = []
         self.optimizer_state = None   # filled by savemodel(fname, optimizer_state=True); read by fit(resume=True)
         self.epochs_done = 0
@@ -453,6 +454,10 @@ class GRU4Rec:
         self._model = self._create_model(sample_store)
         m = self._model
         self._upload_weights(m)
+        self._cpu_store = bool(store_type == 'cpu' and self.n_sample)
+        if self._cpu_store and resume:
+            raise NotImplementedError('resume=True with store_type="cpu": the host sampler runs on NumPy\'s global random stream, '
+                                      'which a checkpoint does not hold')
         if self.n_sample and m.sample_store_rows() <= 1:
             print('No example store was used')      # negatives are then drawn anew for every step (gru4rec.py:548-550,614-615)
         lq_t = lq_s = None
@@ -463,9 +468,14 @@ class GRU4Rec:
         pop = support.astype(np.float64) ** self.sample_alpha
         pop = pop.cumsum() / pop.sum()
         pop[-1] = 1
+        self._pop64 = pop
+        if self._cpu_store:
+            # store_type='cpu' (gru4rec.py:551-554): the reference's own host sampler, on NumPy's global stream right behind the
+            # weight initialisation -- the negatives are the reference's, draw for draw
+            m.set_sample_store(self._cpu_samples(m.sample_store_rows()))
         m.set_popularity(pop.astype(np.float32), lq_t, lq_s)
         if self.n_sample and m.sample_store_rows() > 1:
-            print('Created sample store with {} batches of samples (type=GPU)'.format(m.sample_store_rows()))
+            print('Created sample store with {} batches of samples (type={})'.format(m.sample_store_rows(), 'CPU' if self._cpu_store else 'GPU'))
         if resume:
             self._upload_optimizer_state(m, self.optimizer_state)
         if self.time_sort:
@@ -479,6 +489,15 @@ class GRU4Rec:
         if not resume:
             self.loss_history = []
         self.step_costs = []          # per-epoch arrays of the per-mini-batch cost (gru4rec.py:623)
+
+    def _cpu_samples(self, length):
+        """generate_neg_samples, gru4rec.py:507-514: searchsorted (side='left') in the float64 cumulative table, or a uniform
+        choice when sample_alpha == 0; `length` rows of n_sample."""
+        if self.sample_alpha:
+            sample = np.searchsorted(self._pop64, np.random.rand(self.n_sample * length))
+        else:
+            sample = np.random.choice(self.n_items, size=self.n_sample * length)
+        return sample.reshape(length, self.n_sample).astype(np.int32)
 
     def _epoch_plan(self):
         n_sessions = len(self._offsets) - 1
@@ -509,6 +528,13 @@ class GRU4Rec:
         done = 0
         while done < T:
             n = min(self.steps_per_call, T - done)
+            if self._cpu_store:
+                # host sample store: the row pointer is the global step modulo the store length; a new store is drawn when it
+                # wraps (gru4rec.py:609-613), so no device call runs across that point
+                g, gl = m.global_step(), m.sample_store_rows()
+                if g > 0 and g % gl == 0:
+                    m.set_sample_store(self._cpu_samples(gl))
+                n = min(n, gl - g % gl)
             m.train_steps(done, n)
             c = m.get_losses(done, n)
             costs[done:done + n] = c
@@ -593,7 +619,7 @@ class GRU4Rec:
 
     def __getstate__(self):
         st = dict(self.__dict__)
-        for k in ('_model', '_plan', '_plan_key', '_data_items', '_offsets', '_base_order', '_dist', '_loss_id', '_final', '_hidden'):
+        for k in ('_model', '_plan', '_plan_key', '_data_items', '_offsets', '_base_order', '_dist', '_loss_id', '_final', '_hidden', '_pop64', '_cpu_store'):
             st.pop(k, None)
         st['predict'] = None
         return st

@@ -13,11 +13,12 @@ class OracleRun:
 
 
 def oracle_fit(data, params, sample_store, seed=12345, dtype=np.float32, session_key='SessionId', item_key='ItemId',
-               time_key='Time', max_steps=None):
+               time_key='Time', max_steps=None, store_type='gpu'):
     """Returns an OracleRun with .model, .costs (per step, all epochs), .M (per step), .itemidmap."""
     p = dict(params)
     n_epochs = p.pop('n_epochs', 10)
     time_sort = p.pop('time_sort', True)
+    random_order = p.pop('train_random_order', False)
     data = data.copy()
     itemids = data[item_key].unique()
     n_items = len(itemids)
@@ -30,7 +31,7 @@ def oracle_fit(data, params, sample_store, seed=12345, dtype=np.float32, session
     model = OracleGRU4Rec(n_items=n_items, dtype=dtype, seed=seed, **p)
     support = data.groupby(item_key).size()[itemidmap.index.values].values
     model.set_popularity(support)
-    model.make_sample_store(sample_store)
+    model.make_sample_store(sample_store, store_type)
     if time_sort:
         order = np.argsort(data.groupby(session_key)[time_key].min().values)
     else:
@@ -42,6 +43,8 @@ def oracle_fit(data, params, sample_store, seed=12345, dtype=np.float32, session
         for i in range(len(model.layers)):
             model.H[i] = np.zeros((model.batch_size, model.layers[i]), dtype=dtype)
         c, cc = [], []
+        if random_order:
+            order = np.random.permutation(len(offsets) - 1)      # gru4rec.py:592-593
         for ev in fit_schedule(offsets, order, items, model.batch_size, model.n_sample):
             if ev[0] == 'step':
                 c.append(model.train_step(ev[1], ev[2], ev[3], ev[4]))

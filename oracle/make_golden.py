@@ -74,6 +74,18 @@ SCENARIOS = {
                               batch_size=8, dropout_p_embed=0.0, dropout_p_hidden=0.0, learning_rate=0.2,
                               momentum=0.0, n_sample=16, sample_alpha=0.5, smoothing=0.1, logq=1.0,
                               constrained_embedding=True),
+    # store_type='cpu' (README.md:470-475 route): the reference samples on the host with NumPy's global stream, right behind its
+    # weight initialisation -- no random numbers are substituted in these runs (no dropout): negatives, session order and weights
+    # are the reference's own draws
+    'cpu_store_bprmax': dict(loss='bpr-max', final_act='elu-0.5', hidden_act='tanh', layers=[12], n_epochs=2, batch_size=8,
+                             dropout_p_embed=0.0, dropout_p_hidden=0.0, learning_rate=0.2, momentum=0.1, n_sample=16,
+                             sample_alpha=0.5, bpreg=0.5, constrained_embedding=True, store_type='cpu'),
+    'cpu_store_uniform_random_order': dict(loss='top1-max', final_act='tanh', hidden_act='tanh', layers=[12], n_epochs=2, batch_size=8,
+                                           dropout_p_embed=0.0, dropout_p_hidden=0.0, learning_rate=0.1, momentum=0.0, n_sample=16,
+                                           sample_alpha=0.0, constrained_embedding=True, train_random_order=True, store_type='cpu'),
+    'cpu_no_store_per_step': dict(loss='cross-entropy', final_act='softmax', hidden_act='tanh', layers=[12], n_epochs=1, batch_size=8,
+                                  dropout_p_embed=0.0, dropout_p_hidden=0.0, learning_rate=0.1, momentum=0.0, n_sample=16,
+                                  sample_alpha=0.75, logq=1.0, constrained_embedding=True, store_type='cpu', sample_store_rows=1),
 }
 SAMPLE_STORE_ROWS = 9        # generate_length: small, so that the store is refilled several times
 
@@ -126,9 +138,12 @@ def run_scenario(name, params):
     test = test[np.isin(test.ItemId, train.ItemId)]
     state = {'refills': 0}
     install_rng_hook(params, state)
+    params = dict(params)
+    store_type = params.pop('store_type', 'gpu')
+    rows = params.pop('sample_store_rows', SAMPLE_STORE_ROWS)
     gru = ref_gru4rec.GRU4Rec(**params)
-    store = SAMPLE_STORE_ROWS * params['n_sample'] if params['n_sample'] else 0
-    gru.fit(train.copy(), sample_store=store, store_type='gpu')
+    store = rows * params['n_sample'] if params['n_sample'] else 0
+    gru.fit(train.copy(), sample_store=store, store_type=store_type)
     costs = np.array([np.asarray(o).reshape(()) for (fid, o) in theano.CALL_LOG if o is not None], dtype=np.float32)
     out = dict(costs=costs, n_items=gru.n_items, itemids=np.array(list(gru.itemidmap.index)))
     for i in range(len(params['layers'])):
@@ -161,6 +176,7 @@ def run_scenario(name, params):
         out['test_' + c] = test[c].values
     out['params'] = np.array(repr(params))
     out['sample_store'] = store
+    out['store_type'] = np.array(store_type)
     out['seed'] = SEED
     out = {k: (np.asarray(v).astype(str) if np.asarray(v).dtype == object else v) for k, v in out.items()}
     path = os.path.join(ROOT, 'tests', 'golden', name + '.npz')

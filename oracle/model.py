@@ -288,6 +288,7 @@ class OracleGRU4Rec:
         pop = support ** self.sample_alpha
         pop = pop.cumsum() / pop.sum()
         pop[-1] = 1
+        self.pop64 = pop                      # the CPU store samples from the float64 table (gru4rec.py:507-514)
         self.P = pop.astype(np.float32)
         # logQ tables (gru4rec.py:495): log(P0) for in-batch targets, log(P0**alpha) for sampled negatives
         self.lq_tgt = np.log(self.P0).astype(np.float32)
@@ -301,12 +302,14 @@ class OracleGRU4Rec:
         out[x <= P[0]] = 0
         return out
 
-    def make_sample_store(self, sample_store):
-        """gru4rec.py:546-566: ST[generate_length, n_sample]; uniforms from Philox instead of MRG.  A store that cannot hold
+    def make_sample_store(self, sample_store, store_type='gpu'):
+        """gru4rec.py:546-566: ST[generate_length, n_sample]; uniforms from Philox instead of MRG (store_type 'gpu'), or the
+        reference's own host sampler on NumPy's global stream (store_type 'cpu', gru4rec.py:507-514,551-554).  A store that cannot hold
         two rows means "no store": a fresh row of negatives is drawn for every step (gru4rec.py:548-550,614-615), which is a
         one-row store refilled before every step."""
         self.generate_length = sample_store // self.n_sample if self.n_sample else 0
         self.n_refills = 0
+        self.store_type = store_type
         if self.n_sample:
             self.generate_length = max(self.generate_length, 1)
             self._refill()
@@ -315,6 +318,14 @@ class OracleGRU4Rec:
 
     def _refill(self):
         n = self.generate_length * self.n_sample
+        if getattr(self, 'store_type', 'gpu') == 'cpu':      # generate_neg_samples, gru4rec.py:507-514 (side='left', float64 table)
+            if self.sample_alpha:
+                smp = np.searchsorted(self.pop64, np.random.rand(n))
+            else:
+                smp = np.random.choice(self.n_items, size=n)
+            self.ST = smp.reshape(self.generate_length, self.n_sample).astype(np.int32)
+            self.n_refills += 1
+            return
         u = philox.uniform_block(n, self.seed, self.n_refills, 0, philox.STREAM_SAMPLE)
         self.ST = self.searchsorted_gpu(self.P, u).reshape(self.generate_length, self.n_sample).astype(np.int32)
         self.n_refills += 1

@@ -35,7 +35,8 @@ def oracle_params(params):
 @pytest.mark.parametrize('path', GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_oracle_reproduces_reference_run(path):
     g, params, train, test = load(path)
-    run = oracle_fit(train, oracle_params(params), int(g['sample_store']), seed=int(g['seed']))
+    store_type = str(g['store_type']) if 'store_type' in g else 'gpu'
+    run = oracle_fit(train, oracle_params(params), int(g['sample_store']), seed=int(g['seed']), store_type=store_type)
     m = run.model
     assert m.n_items == int(g['n_items'])
     assert list(run.itemidmap.index) == list(g['itemids'])
