@@ -30,7 +30,7 @@ OPTIONS = [
     ('-e', '--eval_type', dict(metavar='EVAL_TYPE', choices=['standard', 'conservative', 'median', 'tiebreaking'], default='standard',
                                help='tie handling when ranking the target item (default standard)')),
     ('-ss', '--sample_store_size', dict(metavar='SS', type=int, default=10000000, help='number of pre-drawn negative samples kept on the device (default 10000000)')),
-    (None, '--sample_store_on_cpu', dict(action='store_true', help='accepted for compatibility; the sample store of this implementation always lives in HBM')),
+    (None, '--sample_store_on_cpu', dict(action='store_true', help='draw the negative samples with the reference\'s host sampler (NumPy stream) and upload them store by store, instead of sampling on the device')),
     ('-g', '--gru4rec_model', dict(metavar='GRFILE', default='gru4rec_amd.gru4rec', help='module that provides the GRU4Rec class (default gru4rec_amd.gru4rec)')),
     ('-ik', '--item_key', dict(metavar='IK', default='ItemId', help='item id column (default ItemId)')),
     ('-sk', '--session_key', dict(metavar='SK', default='SessionId', help='session id column (default SessionId)')),
