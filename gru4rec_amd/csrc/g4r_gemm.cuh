@@ -311,3 +311,94 @@ __device__ __forceinline__ void gemm_tile2(int m0, int n0, int K, ARow arow, BRo
     for (int j = 0; j < 16; ++j) epi(m0 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3), n, acc[j], pf[PRE_COL ? 0 : j]);
     if (trc && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[4] = wall_clock64(); }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// gemm_tile2 for operands that are K-MAJOR in memory ([k][m]: a row per k, the 64 elements of the tile contiguous in it) -- the
+// GEMMs that contract over the batch (dS = ds^T h) or over gathered rows (dh = ds Sy).  Same tile, MFMA shape and pipeline as
+// gemm_tile2; differences:
+//   * a K-major operand is staged as [k][64] (one float4 per thread and chunk: thread t -> k row t >> 4, columns 4 (t & 15)), with
+//     the two 32-column halves of odd k rows swapped, so that the fragment reads of lanes 0-31 (k even) and 32-63 (k odd) fall on
+//     different banks; fragment addresses are lane constants + 128 u floats (immediate offsets);
+//   * its provider is called per chunk, `ptr(kk, kr, c)` -> address of element (k = kk + kr, column c) or nullptr (outside the
+//     matrix / inactive gathered row): rows of a gathered operand change from chunk to chunk.
+// A_KM = false: A is K-contiguous ([m][k], row pointers `arow(r)` as in gemm_tile2, XOR-swizzled rows of 16 floats).
+template <bool A_KM, bool PRE_COL, class AProv, class BProv, class Pre, class Epi>
+__device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, BProv bprov, Pre pre, Epi epi, float* smem, GAS long long* trc = nullptr) {
+    constexpr int BK = 16;
+    constexpr int BUF = 64 * BK;                        // floats per operand buffer, either layout
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l32 = lane & 31, lh = lane >> 5;
+    // K-major staging slot: k row kr, columns kc .. kc + 3
+    const int kr = tid >> 4, kc = 4 * (tid & 15);
+    const int kofs = kr * 64 + (kc ^ (32 * (kr & 1)));
+    // K-contiguous staging slot of A (A_KM == false): row sr, k offset sc (one quad per thread: 64 rows x 16 floats)
+    const int sr = tid >> 2, sc = 4 * (tid & 3);
+    const int sw_st = 2 * ((sr >> 2) & 7);
+    const GAS float* pa = nullptr;
+    bool oka = false;
+    if constexpr (!A_KM) {
+        const GAS float* a = aprov(sr);
+        oka = a != nullptr;
+        pa = (oka ? a : aprov(0)) + sc;
+    }
+    // (measured and rejected: three register sets with the loads of chunk i + 2 issued in iteration i -- the compiler's waitcnt
+    // placement still drains to the newest load before every commit, and the extra registers cost a workgroup per CU: 68.5 vs 64.5 us)
+    float4 ra, rb;
+    const GAS float* qa = nullptr;
+    const GAS float* qb = nullptr;
+    auto issue = [&](int kk) {
+        if constexpr (A_KM) { qa = aprov(kk, kr, kc); ra = ld4(qa ? qa : aprov(0, 0, 0)); }
+        else { ra = ld4(pa); pa += BK; }
+        qb = bprov(kk, kr, kc);
+        rb = ld4(qb ? qb : bprov(0, 0, 0));
+    };
+    // (component-wise selects: a ternary on the float4 struct was compiled to a select between two scratch copies)
+    auto mask4 = [](float4 v, bool ok) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); };
+    auto commit = [&](int buf) {
+        if constexpr (A_KM) {
+            *reinterpret_cast<float4*>(smem + buf * BUF + kofs) = mask4(ra, qa != nullptr);
+        } else {
+            const float4 va = mask4(ra, oka);
+            float2* da = reinterpret_cast<float2*>(smem + buf * BUF + sr * BK + (sc ^ (sw_st & ~3)));
+            da[(sw_st >> 1) & 1] = make_float2(va.x, va.y); da[((sw_st >> 1) & 1) ^ 1] = make_float2(va.z, va.w);
+        }
+        *reinterpret_cast<float4*>(smem + (2 + buf) * BUF + kofs) = mask4(rb, qb != nullptr);
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    const int sw_fr = 2 * ((l32 >> 2) & 7);             // K-contiguous A: swizzle of this lane's fragment row
+    const int nchunk = (K + BK - 1) / BK;
+    issue(0);
+    const int n = n0 + wn * 32 + l32;
+    constexpr int NPF = PRE_COL ? 1 : 16;
+    float4 pf[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) pf[j] = pre(m0 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3), n);
+    commit(0);
+    if (trc && tid == 0) trc[2] = wall_clock64();
+    for (int i = 0; i < nchunk; ++i) {
+        __syncthreads();
+        const float* fa = A_KM ? smem + (i & 1) * BUF + lh * 64 + ((wm * 32 + l32) ^ (32 * lh))
+                               : smem + (i & 1) * BUF + (wm * 32 + l32) * BK + lh;
+        const float* fb = smem + (2 + (i & 1)) * BUF + lh * 64 + ((wn * 32 + l32) ^ (32 * lh));
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            av[u] = A_KM ? fa[128 * u] : fa[(2 * u) ^ sw_fr];
+            bv[u] = fb[128 * u];
+        }
+        const bool more = i + 1 < nchunk;
+        if (more) issue((i + 1) * BK);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = mfma32(av[u], bv[u], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) commit((i + 1) & 1);
+    }
+    if (trc && tid == 0) trc[3] = wall_clock64();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) epi(m0 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3), n, acc[j], pf[PRE_COL ? 0 : j]);
+    if (trc && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[4] = wall_clock64(); }
+}

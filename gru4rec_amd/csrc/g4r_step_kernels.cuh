@@ -921,6 +921,102 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
     gemm_tile<TB, TB, TBK, false, false, GT_NTH>(m0, d0, min(kch, ld - kbeg), aload, bload, NoPre(), epi, smem);
 }
 
+// Scoring backward for long score rows / big batches (B >= 256, >= 4096 score columns, D a multiple of 64) on gemm_tile2k: 64 x 64
+// tiles, v_mfma_f32_32x32x2_f32, 16-deep double-buffered chunks.  Three roles in one launch (block ranges):
+//   A  [0, nblkA)               dSy[n0.., d0..] = ds^T h over the batch (both operands K-major); epilogue as k_score_bwd role A
+//   B  [nblkA, nblkA + nblkB)   split-K slab kc of dh = ds Sy (ds K-contiguous, gathered Wy rows K-major)
+//   C  the rest                 dSBy = column sums of ds over the batch for 64 columns (the ones column of k_score_bwd's role A
+//                               costs a fifth d tile at D = 256), Adagrad-scaled like role A's epilogue
+__global__ __launch_bounds__(256) void k_score_bwd2(const DevModel* __restrict__ mp, StepState* st, int nblkA, int nblkB, int ndt, int nrt) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevModel& m = *mp;
+    const StepCtx c = load_ctx(st);
+    const int M = c.M, B = m.B, D = m.Dtop, N = m.N, ld = m.ldSc, tid = threadIdx.x;
+    const GAS float* h = m.hd[m.n_layers - 1];
+    const GAS float* Sc = m.Sc;
+    const GAS float* Wy = m.Wy;
+    const float lr = m.lr;
+    const bool generic = m.generic != 0;
+    constexpr int TILE_FLOATS = 4 * 64 * 16;
+    int* sIt = reinterpret_cast<int*>(smem + TILE_FLOATS);      // role A: items of the tile's 64 score columns; role B: of the slab
+    GAS long long* trc = (m.dbgtile && blockIdx.x < 2048) ? m.dbgtile + 8 * (size_t)(4096 + 2048 + blockIdx.x) : nullptr;
+    if (trc && tid == 0) { trc[0] = wall_clock64(); trc[5] = c.t; trc[6] = (int)blockIdx.x < nblkA ? 0 : ((int)blockIdx.x < nblkA + nblkB ? 1 : 2); }
+    if ((int)blockIdx.x < nblkA) {
+        const int nt = blockIdx.x / ndt, dt = blockIdx.x - nt * ndt;
+        const int n0 = nt * 64, d0 = dt * 64;
+        if (tid < 64) sIt[tid] = (n0 + tid < N) ? m.col_item[n0 + tid] : -1;
+        __syncthreads();
+        auto aptr = [&](int kk, int kr, int cc) -> const GAS float* {       // ds[b = kk + kr][n0 + cc ..]
+            return (kk + kr < M && n0 + cc < ld) ? Sc + (size_t)(kk + kr) * ld + n0 + cc : nullptr;
+        };
+        auto bptr = [&](int kk, int kr, int cc) -> const GAS float* {       // h[b = kk + kr][d0 + cc ..]
+            return (kk + kr < M) ? h + (size_t)(kk + kr) * D + d0 + cc : nullptr;
+        };
+        const GAS float* accWy = m.accWy;
+        GAS float *dSy = m.dSy, *dAy = m.dAy;
+        auto pre = [&](int n, int d) -> float4 {
+            const int item = sIt[n - n0];
+            const bool ok = item >= 0;
+            return make_float4(ldf_at(accWy, (size_t)max(item, 0) * D + d, ok), ok ? 1.f : 0.f, 0.f, 0.f);
+        };
+        auto epi = [&](int n, int d, float g, float4 p) {
+            if (n >= N) return;
+            const float an = p.x + g * g;
+            float step = (p.y != 0.f) ? lr * g * frsq(an + G4R_EPS_ADAGRAD) : 0.f;
+            if (generic) step = (p.y != 0.f) ? g : 0.f;
+            dSy[(size_t)n * D + d] = step; dAy[(size_t)n * D + d] = an;
+        };
+        if (trc && tid == 0) trc[1] = wall_clock64();
+        gemm_tile2k<true, false>(n0, d0, M, aptr, bptr, pre, epi, smem, trc);
+        return;
+    }
+    if ((int)blockIdx.x < nblkA + nblkB) {
+        const int w = blockIdx.x - nblkA;
+        const int per_kc = nrt * ndt;
+        const int kc = w / per_kc, rem = w - kc * per_kc, rt = rem / ndt, dt = rem - rt * ndt;
+        const int kch = m.kch, m0 = rt * 64, d0 = dt * 64, kbeg = kc * kch;
+        if (m0 >= M) return;
+        for (int i = tid; i < kch; i += 256) sIt[i] = (kbeg + i < ld) ? m.col_item[kbeg + i] : -1;
+        __syncthreads();
+        GAS float* dhpart = m.dhpart;
+        auto arow = [&](int r) -> const GAS float* { return (m0 + r < M) ? Sc + (size_t)(m0 + r) * ld + kbeg : nullptr; };
+        auto bptr = [&](int kk, int kr, int cc) -> const GAS float* {       // Wy[item of column kbeg + kk + kr][d0 + cc ..]
+            const int item = sIt[min(kk + kr, kch - 1)];
+            return (item >= 0 && kk + kr < kch) ? Wy + (size_t)item * D + d0 + cc : nullptr;
+        };
+        auto epi = [&](int b, int d, float v, float4) {
+            if (b < M) dhpart[((size_t)kc * B + b) * D + d] = v;
+        };
+        if (trc && tid == 0) trc[1] = wall_clock64();
+        gemm_tile2k<false, true>(m0, d0, min(kch, ld - kbeg), arow, bptr, NoPre(), epi, smem, trc);
+        return;
+    }
+    // ---- role C: 64 columns, thread (column tid & 63, row group tid >> 6)
+    {
+        const int n0 = ((int)blockIdx.x - nblkA - nblkB) * 64, cl = tid & 63, grp = tid >> 6, n = n0 + cl;
+        const bool nok = n < ld;
+        float s = 0.f;
+        for (int b0 = grp; b0 < M; b0 += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ldf_if(Sc, (size_t)min(b0 + 4 * u, M - 1) * ld + (nok ? n : 0), nok && b0 + 4 * u < M);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        smem[grp * 64 + cl] = s;
+        __syncthreads();
+        if (tid < 64 && n < N) {
+            const float g = (smem[cl] + smem[64 + cl]) + (smem[128 + cl] + smem[192 + cl]);
+            const int item = m.col_item[n];
+            const bool ok = item >= 0;
+            const float an = ldf_at(m.accBy, max(item, 0), ok) + g * g;
+            float step = ok ? lr * g * frsq(an + G4R_EPS_ADAGRAD) : 0.f;
+            if (generic) step = ok ? g : 0.f;
+            m.dSBy[n] = step; m.dABy[n] = an;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // GRU backward (no BPTT: H is a constant input, gru4rec.py:460-463,576), element-wise head:
 //   dh = sum of split-K slabs (top layer) or the upper layer's dy ; hidden-dropout mask ;

@@ -13,8 +13,19 @@ m.set_plan(plan); m.reset_hidden()
 m.train_steps(0, 100)
 for rep in range(3):
     m.train_steps(100 + rep, 1)
-    tr = m.get_debug('dbgtile', (2 * 8 * 8192,)).view(np.int64).reshape(8192, 8)[4096:]
+    allt = m.get_debug('dbgtile', (2 * 8 * 8192,)).view(np.int64).reshape(8192, 8)
+    which = os.environ.get('KERNEL', 'fwd')
+    tr = allt[4096:6144] if which == 'fwd' else allt[6144:]
     tr = tr[(tr[:, 5] == 100 + rep) & (tr[:, 4] > 0)]
+    if which != 'fwd':
+        for role, name in ((0, 'role A (dSy tiles)'), (1, 'role B (dh slabs)')):
+            r = tr[tr[:, 6] == role]
+            if len(r):
+                t00 = tr[:, 0].min()
+                php = np.diff(r[:, 0:5], axis=1) / 100.0
+                print('   %s: %d tiles, start median %.2f max %.2f, end median %.2f max %.2f | setup %.2f first chunk %.2f K loop %.2f epilogue %.2f' % (
+                    name, len(r), np.median(r[:, 0] - t00) / 100, (r[:, 0] - t00).max() / 100, np.median(r[:, 4] - t00) / 100, (r[:, 4] - t00).max() / 100,
+                    *np.median(php, axis=0)))
     t0 = tr[:, 0].min()
     pc = lambda x: np.round(np.percentile(x, [0, 10, 50, 90, 100]), 2)
     ph = np.diff(tr[:, 0:5], axis=1) / 100.0
