@@ -21,7 +21,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(' '.join(host))
     subprocess.check_call(host)
-    cmd = [os.path.join(rocm, 'bin', 'hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+    trace = ['-DG4R_CLK_TRACE'] if os.environ.get('G4R_BUILD_CLK') else []      # in-kernel phase traces for tools/clk*.py
+    cmd = [os.path.join(rocm, 'bin', 'hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC'] + trace + [
            '-I' + os.path.join(rocm, 'include'), '-o', OUT, SRC, '-Wl,' + obj, '-pthread', '-L' + os.path.join(rocm, 'lib'), '-lrccl',
            '-Wl,-rpath,' + os.path.join(rocm, 'lib')]
     if verbose:

@@ -1550,6 +1550,9 @@ int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
     else if (s == "dyl") { p = d.dyl[l]; n = bd; }
     else if (s == "Hprev") { p = d.H[l][(m->gstep + 1) & 1]; n = bd; }
     else if (s == "occ_idx") { p = (const float*)d.occ_idx; n = d.R; }
+#if !defined(G4R_CLK_TRACE)
+    else if (s == "dbgclk" || s == "dbgtile") return fail("in-kernel traces need a library built with G4R_BUILD_CLK=1 (python -m gru4rec_amd.build --force) and G4R_CLK=1 at run time");
+#endif
     else if (s == "dbgclk") { if (!d.dbgclk) return fail("G4R_CLK not set"); p = (const float*)d.dbgclk; n = 2 * (64 + 8 * (int64_t)d.R); }
     else if (s == "dbgtile") { if (!d.dbgtile) return fail("G4R_CLK not set"); p = (const float*)d.dbgtile; n = 2 * 8 * (int64_t)8192; }      // [0, 4096): dense tiles, [4096, 8192): k_score_fwd tiles
     else if (s == "ntiles") { if (count < 1) return fail("count"); host[0] = (float)m->ntiles; return 0; }

@@ -132,11 +132,21 @@ struct DevModel {
     GP(long long) dbgtile;  // optional [dense tile][8] phase timestamps of the dense-gradient tiles (G4R_CLK)
 };
 
+// In-kernel phase traces (tools/clk*.py) exist only in builds made with G4R_BUILD_CLK=1 (-DG4R_CLK_TRACE): a test of a
+// descriptor field at the top of a kernel makes its first instructions wait for the descriptor's scalar loads, which the vector
+// loads of the step state otherwise overlap -- measured 0.5 us per launch on k_score_fwd.
+#if defined(G4R_CLK_TRACE)
+#define G4R_DBGCLK(m) ((m).dbgclk)
+#define G4R_DBGTILE(m) ((m).dbgtile)
+#else
+#define G4R_DBGCLK(m) ((GAS long long*)nullptr)
+#define G4R_DBGTILE(m) ((GAS long long*)nullptr)
+#endif
 // phase timestamp (debug): one lane of block 0 records the constant-rate wall clock
 #define G4R_TICK(m, kern, phase)                                                                     \
     do {                                                                                             \
-        if ((m).dbgclk && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)                     \
-            (m).dbgclk[(kern) * 16 + (phase)] = wall_clock64();                                       \
+        if (G4R_DBGCLK(m) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)                  \
+            G4R_DBGCLK(m)[(kern) * 16 + (phase)] = wall_clock64();                                       \
     } while (0)
 
 // ---------------------------------------------------------------------------------------------

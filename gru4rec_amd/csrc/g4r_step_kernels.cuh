@@ -114,7 +114,7 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_p1(const DevModel* __restric
         M = pa.M; Hcur = pa.Hcur; gidx = pa.in_idx; ysrc = pa.ysrc; Vc = pa.Vc; zb = pa.z; Hrb = pa.Hr;
     }
     const int m0 = blockIdx.y * GT_BM, n0 = blockIdx.x * TBN;
-    GAS long long* clk = (m.dbgclk && blockIdx.x == 1 && blockIdx.y == 1) ? m.dbgclk + 0 : nullptr;      // kernel 0 of tools/clk.py
+    GAS long long* clk = (G4R_DBGCLK(m) && blockIdx.x == 1 && blockIdx.y == 1) ? G4R_DBGCLK(m) + 0 : nullptr;      // kernel 0 of tools/clk.py
     if (clk && tid == 0) clk[4] = wall_clock64();     // context known
     // gather indices of the tile's rows go to LDS first: the row loads must not chain behind index loads
     int* sRow = reinterpret_cast<int*>(smem + TileCfg<GT_BM, TBN, TBK, false, false>::SMEM_FLOATS);
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(512) void k_gru_fwd_fused(const DevModel* __restric
     f32x4* sJ = reinterpret_cast<f32x4*>(smem + L.sJoin);
     const int LDA = L.LDA, LDH = L.LDH;
     const GAS float* Hcur = m.H[l][g & 1];
-    GAS long long* clk = (m.dbgclk && blockIdx.x == 1 && blockIdx.y == 1) ? m.dbgclk + 0 : nullptr;      // kernel 0 of tools/clk.py
+    GAS long long* clk = (G4R_DBGCLK(m) && blockIdx.x == 1 && blockIdx.y == 1) ? G4R_DBGCLK(m) + 0 : nullptr;      // kernel 0 of tools/clk.py
     if (clk && tid == 0) clk[0] = wall_clock64();
     // ---- row items first (the gathers wait for them), then everything that does not depend on them
     const int rrow = m0 + (tid & 15);
@@ -543,9 +543,14 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
     constexpr int SMEM_TILE = (TBN == 64 && TBK == 32) ? Tile2Cfg<T2_BK>::SMEM_FLOATS : TileCfg<SF_BM, TBN, TBK, false, true>::SMEM_FLOATS;
     int* sItem = reinterpret_cast<int*>(smem + SMEM_TILE);   // [TBN]
     const int tid = threadIdx.x;
-    const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
-    GAS long long* trc = (m.dbgtile && wgid < 4096) ? m.dbgtile + 8 * (size_t)(4096 + wgid) : nullptr;
-    if (trc && tid == 0) trc[0] = wall_clock64();
+    // in-kernel phase trace (tools/clk_score.py), gemm_tile2 variant only: in the small-shape variant the test of the descriptor
+    // field in front of everything else cost 0.5 us per launch
+    GAS long long* trc = nullptr;
+    if constexpr (TBN == 64 && TBK == 32) {
+        const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
+        trc = (G4R_DBGTILE(m) && wgid < 2048) ? G4R_DBGTILE(m) + 8 * (size_t)(4096 + wgid) : nullptr;
+        if (trc && tid == 0) trc[0] = wall_clock64();
+    }
     const StepCtx c = load_ctx(st);
     const int M = c.M, B = m.B, D = m.Dtop, N = m.N;
     const int n0 = blockIdx.x * TBN, m0 = blockIdx.y * SF_BM;
@@ -939,7 +944,7 @@ __global__ __launch_bounds__(256) void k_score_bwd2(const DevModel* __restrict__
     const bool generic = m.generic != 0;
     constexpr int TILE_FLOATS = 4 * 64 * 16;
     int* sIt = reinterpret_cast<int*>(smem + TILE_FLOATS);      // role A: items of the tile's 64 score columns; role B: of the slab
-    GAS long long* trc = (m.dbgtile && blockIdx.x < 2048) ? m.dbgtile + 8 * (size_t)(4096 + 2048 + blockIdx.x) : nullptr;
+    GAS long long* trc = (G4R_DBGTILE(m) && blockIdx.x < 2048) ? G4R_DBGTILE(m) + 8 * (size_t)(4096 + 2048 + blockIdx.x) : nullptr;
     if (trc && tid == 0) { trc[0] = wall_clock64(); trc[5] = c.t; trc[6] = (int)blockIdx.x < nblkA ? 0 : ((int)blockIdx.x < nblkA + nblkB ? 1 : 2); }
     if ((int)blockIdx.x < nblkA) {
         const int nt = blockIdx.x / ndt, dt = blockIdx.x - nt * ndt;
@@ -1126,7 +1131,7 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_bwd_b(const DevModel* __rest
             dylo[(size_t)row * IN + n] = v;
         }
     };
-    GAS long long* clk = (m.dbgclk && blockIdx.x == 1 && blockIdx.y == 1) ? m.dbgclk + 16 : nullptr;     // kernel 1 of tools/clk.py
+    GAS long long* clk = (G4R_DBGCLK(m) && blockIdx.x == 1 && blockIdx.y == 1) ? G4R_DBGCLK(m) + 16 : nullptr;     // kernel 1 of tools/clk.py
     gemm_tile<GT_BM, GT_BN, BB_BK, false, true, GT_NTH_FEW>(m0, n0, D3, aload, bload, pre, epi, smem, clk);
 }
 
@@ -1154,7 +1159,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd_fused(const DevModel* __restric
     const int M = c.M, B = m.B, D = m.D[l], IN = m.IN[l], D3 = 3 * D, Dq = D >> 2, D3q = D3 >> 2;
     const int m0 = blockIdx.y * BF_ROWS, n0 = blockIdx.x * 32;
     if (m0 >= M) return;
-    GAS long long* clk = (m.dbgclk && blockIdx.x == 1 && blockIdx.y == 1) ? m.dbgclk + 16 : nullptr;     // kernel 1 of tools/clk.py
+    GAS long long* clk = (G4R_DBGCLK(m) && blockIdx.x == 1 && blockIdx.y == 1) ? G4R_DBGCLK(m) + 16 : nullptr;     // kernel 1 of tools/clk.py
     if (clk && tid == 0) clk[0] = wall_clock64();
     const int LDV = D3 + 2, LDW = D + 2;      // row strides with ld / 2 odd: MFMA fragment reads are conflict-free
     float* sV = smem;                          // [16][LDV]   dV rows of the tile
@@ -1481,7 +1486,7 @@ __device__ __forceinline__ float2 ld2_if(const GAS float* base, size_t off, bool
 template <int NW>
 __device__ __forceinline__ void dense_grad_direct(const DevModel& m, StepState* st, const DenseTile* tiles_, int tile, float* smem) {
     const GAS DenseTile* tiles = (const GAS DenseTile*)tiles_;
-    GAS long long* trc = m.dbgtile ? m.dbgtile + 8 * (size_t)tile : nullptr;
+    GAS long long* trc = G4R_DBGTILE(m) ? G4R_DBGTILE(m) + 8 * (size_t)tile : nullptr;
     const long long tr0 = trc ? wall_clock64() : 0;
     const StepCtx c = load_ctx(st);
     const DenseTile tl = tiles[tile];
@@ -1736,7 +1741,7 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
         stage_step_inputs(m, c.t + 1, c.g + 1, Mn, tid, SP_WAVES * 64);
         return;
     }
-    const long long t_start = m.dbgclk ? wall_clock64() : 0;
+    const long long t_start = G4R_DBGCLK(m) ? wall_clock64() : 0;
     // LDS: occurrence list padded with -2 to a multiple of 256 (+256) | hot-item slots | per-wave match lists |
     // per-wave partial sums
     const int Rpad = ((R + 255) & ~255) + 256;
@@ -1805,7 +1810,7 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
         *(GAS int4*)flp = make_int4(0, 0, 0, 0);
         if (m.touched) m.touched[(tableE ? (size_t)nI : 0) + item] = 1;
     }
-    const long long t_own = m.dbgclk ? wall_clock64() : 0;
+    const long long t_own = G4R_DBGCLK(m) ? wall_clock64() : 0;
 
     // scan of sOcc[a, b) for `it`: match number i (ascending) goes to myList[i - 64 * pass]; returns the
     // number of matches, nb = those among Y|samples
@@ -1879,7 +1884,7 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
             }
         }
         __syncthreads();
-        if (m.dbgclk) t_col = wall_clock64();
+        if (G4R_DBGCLK(m)) t_col = wall_clock64();
         // one code path for both kinds of work (rarely executed code is instruction-cache cold, so it is kept small):
         //   h = -1 : a wave sums the (<= UB) earlier occurrences of its own item, range [first, k)
         //   h >= 0 : hot item of wave h; every wave sums the occurrences found in its slice of [first, k_h), the
@@ -1901,7 +1906,7 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
             float4 T[MAXCH];
             float Tb = 0.f;
             int n_w = 0, nb_w = 0;
-            if (m.dbgclk && h >= 0) t_h[0] = wall_clock64();
+            if (G4R_DBGCLK(m) && h >= 0) t_h[0] = wall_clock64();
 #pragma unroll
             for (int q = 0; q < MAXCH; ++q) T[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (active) {
@@ -1912,7 +1917,7 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
                     } else {
                         n_w = scan(it, a, b, pass, nb_w);
                     }
-                    if (m.dbgclk && h >= 0 && pass == 0) t_h[1] = wall_clock64();
+                    if (G4R_DBGCLK(m) && h >= 0 && pass == 0) t_h[1] = wall_clock64();
                     const int cnt = min(n_w - 64 * pass, 64);
                     const int myj = lane < cnt ? myList[lane] : -1;
                     const float bd = (tb && myj >= B) ? g_dSBy[max(myj - B, 0)] : 0.f;
@@ -1947,10 +1952,10 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
                     for (int q = 0; q < MAXCH; ++q) S[q] = T[q];
                     Sb = Tb; n_e = n_w; nb_e = nb_w;
                 }
-                if (m.dbgclk) t_app = wall_clock64();
+                if (G4R_DBGCLK(m)) t_app = wall_clock64();
                 continue;
             }
-            if (m.dbgclk) t_h[2] = wall_clock64();
+            if (G4R_DBGCLK(m)) t_h[2] = wall_clock64();
             float* part = sPart + wid * PW;
 #pragma unroll
             for (int q = 0; q < MAXCH; ++q) {
@@ -1959,7 +1964,7 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
             }
             if (lane == 0) { part[PW - 4] = Tb; part[PW - 3] = __int_as_float(n_w); part[PW - 2] = __int_as_float(nb_w); }
             __syncthreads();
-            if (m.dbgclk) t_h[3] = wall_clock64();
+            if (G4R_DBGCLK(m)) t_h[3] = wall_clock64();
             if (wid == h) {
                 for (int w = 0; w < SP_WAVES; ++w) {
 #pragma unroll
@@ -1973,7 +1978,7 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
                 }
             }
             __syncthreads();
-            if (m.dbgclk) t_h[4] = wall_clock64();
+            if (G4R_DBGCLK(m)) t_h[4] = wall_clock64();
         }
     }
     // ---- final row values from S + s_k (sum over all occurrences) and the last occurrence's rows, and the stores
@@ -2011,9 +2016,9 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
             taBy[item] = bak;
         }
     }
-    if (m.dbgclk && lane == 0 && k < R) {
+    if (G4R_DBGCLK(m) && lane == 0 && k < R) {
         const long long t_end = wall_clock64();
-        GAS long long* tr = m.dbgclk + 64 + 8 * k;
+        GAS long long* tr = G4R_DBGCLK(m) + 64 + 8 * k;
         tr[0] = t_start; tr[1] = t_own; tr[2] = t_col; tr[3] = t_app; tr[4] = t_end; tr[5] = (owner ? fl.z : 0) | ((t_h[0] ? t_h[0] - t_app : 0) << 20); tr[6] = c.t;
         tr[7] = (t_h[1] - t_h[0]) | ((t_h[2] - t_h[1]) << 16) | ((t_h[3] - t_h[2]) << 32) | ((t_h[4] - t_h[3]) << 48);
     }

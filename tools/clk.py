@@ -1,4 +1,4 @@
-"""In-kernel phase timing (debug): G4R_CLK=1 python tools/clk.py"""
+"""In-kernel phase timing (debug): G4R_BUILD_CLK=1 python -m gru4rec_amd.build --force; G4R_CLK=1 python tools/clk.py"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,4 @@
-"""In-kernel phase timing of the dense-gradient tiles (debug):  G4R_CLK=1 G4R_NO_MERGE=1 CFG=cfg3 python tools/clk_dense.py"""
+"""In-kernel phase timing of the dense-gradient tiles (debug):  G4R_BUILD_CLK=1 python -m gru4rec_amd.build --force; G4R_CLK=1 G4R_NO_MERGE=1 CFG=cfg3 python tools/clk_dense.py"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,4 @@
-"""In-kernel phase timing of the k_score_fwd tiles (gemm_tile2 path; debug):  G4R_CLK=1 CFG=cfg4 python tools/clk_score.py"""
+"""In-kernel phase timing of the k_score_fwd tiles (gemm_tile2 path; debug):  G4R_BUILD_CLK=1 python -m gru4rec_amd.build --force; G4R_CLK=1 CFG=cfg4 python tools/clk_score.py"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
