@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -1269,8 +1270,15 @@ int g4r_comm_init(g4r_model* m, const char* id128, int32_t nranks, int32_t rank)
     HIPCHK(hipSetDevice(m->cfg.device));
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
-    NCCLCHK(ncclCommInitRank(&m->comm, nranks, id, rank));
-    fflush(stdout);      // RCCL's version banner must not surface after the caller's own output at exit
+    // RCCL prints a version banner on stdout when a communicator is created; stdout belongs to the caller (bench.py prints one
+    // JSON line there), so file descriptor 1 points at stderr while RCCL initialises
+    fflush(stdout);
+    const int saved_out = dup(1);
+    if (saved_out >= 0) (void)dup2(2, 1);
+    const ncclResult_t rc_init = ncclCommInitRank(&m->comm, nranks, id, rank);
+    fflush(stdout);
+    if (saved_out >= 0) { (void)dup2(saved_out, 1); (void)close(saved_out); }
+    NCCLCHK(rc_init);
     m->comm_ready = true;
     return g4r_sync_enable(m);      // base snapshot of the item tables as they are now (g4r_set_param keeps it in step)
 }
