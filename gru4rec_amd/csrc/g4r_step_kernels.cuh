@@ -763,33 +763,36 @@ __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict
     } else {
         // softmax over the negatives, with the positive zeroed first (so the max includes a 0)
         const float mx = mneg[0];
-        float sm[1] = {0.f};
-        for (int j = tid; j < N; j += LOSS_T)
-            if (ACTIVE(j) && j != i) { const float e = fexp(sy[j] - mx); se[j] = e; sm[0] += e; }
-        block_reduce<1, false>(sm, red + 9 * LOSS_NW);
-        const float inv_sm = 1.f / sm[0];
-        float s[3] = {0.f, 0.f, 0.f};
-        // sigmoid(yd - y_j) = 1 / (1 + exp(y_j - yd)) = 1 / (1 + e_j c) with the stored softmax numerator e_j = exp(y_j - mx) and
-        // the row constant c = exp(mx - yd): no exp per element in the two passes below (the row kernel is bound by transcendental
-        // issue at long rows).  c is clamped so that an underflowed e_j = 0 gives 0 * c = 0 (sigma = 1, and p_j = 0 anyway).
+        // sigmoid(yd - y_j) = 1 / (1 + exp(y_j - yd)) = 1 / (1 + e_j c) with the softmax numerator e_j = exp(y_j - mx) and the row
+        // constant c = exp(mx - yd): one exp per element serves both.  c is clamped so that an underflowed e_j = 0 gives 0 * c = 0
+        // (sigma = 1, and p_j = 0 anyway).  The row statistics A = sum sigma p, Q = sum y^2 p, ... are linear in p = e / Z, so
+        // their unnormalised sums are taken in the SAME pass as Z = sum e and divided afterwards: one pass over the row and one
+        // block reduction less than "Z first, then the statistics".
         const float cexp = fexp(fminf(mx - yd, 80.f));
+        float s[4] = {0.f, 0.f, 0.f, 0.f};      // Z, and unnormalised A / T, Q, sum sigma' e
         if (lossk == G4R_LOSS_BPR_MAX) {
             for (int j = tid; j < N; j += LOSS_T)
                 if (ACTIVE(j) && j != i) {
-                    const float y = sy[j], e = se[j], p = e * inv_sm, sg = frcp(1.0f + e * cexp);
-                    s[0] += sg * p;                 // A
-                    s[1] += y * y * p;              // Q
-                    s[2] += sg * (1.f - sg) * p;    // sum sigma' p
+                    const float y = sy[j], e = fexp(y - mx), sg = frcp(1.0f + e * cexp);
+                    se[j] = e;
+                    s[0] += e;
+                    s[1] += sg * e;                 // A Z
+                    s[2] += y * y * e;              // Q Z
+                    s[3] += sg * (1.f - sg) * e;    // (sum sigma' p) Z
                 }
         } else {
             for (int j = tid; j < N; j += LOSS_T)
                 if (ACTIVE(j) && j != i) {
-                    const float y = sy[j], e = se[j], p = e * inv_sm, u = 1.0f - frcp(1.0f + e * cexp), q = sigmoidf_(y * y);
-                    s[0] += p * (u + q);            // T
-                    s[2] += p * u * (1.f - u);
+                    const float y = sy[j], e = fexp(y - mx), u = 1.0f - frcp(1.0f + e * cexp), q = sigmoidf_(y * y);
+                    se[j] = e;
+                    s[0] += e;
+                    s[1] += e * (u + q);            // T Z
+                    s[3] += e * u * (1.f - u);
                 }
         }
-        block_reduce<3, false>(s, red + 12 * LOSS_NW);
+        block_reduce<4, false>(s, red + 9 * LOSS_NW);
+        const float inv_sm = 1.f / s[0];
+        s[0] = s[1] * inv_sm; s[1] = s[2] * inv_sm; s[2] = s[3] * inv_sm;
         const float s1 = s[0], s2 = s[1], s3 = s[2];
         float dyd;
         const float inv_A = 1.f / (s1 + G4R_EPS_LOSS);
