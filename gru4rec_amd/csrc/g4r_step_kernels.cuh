@@ -660,15 +660,22 @@ __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict
     const DevModel& m = *mp;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
-    const StepCtx c = load_ctx(st);
-    const int M = c.M, B = m.B, N = m.N, i = blockIdx.x;
+    const int B = m.B, N = m.N, i = blockIdx.x;
     const int fact = m.final_act, lossk = m.loss, ldSc = m.ldSc;    // snapshot: used inside the loops below
     const float fp0 = m.fa_p0, fp1 = m.fa_p1, invB = m.inv_B, bpreg = m.bpreg, smooth = m.smoothing;
-    if (i >= M) return;
     float* sy = smem;                  // [ldSc] yhat
     float* se = smem + ldSc;           // [ldSc] softmax numerators, later d L / d yhat
     float* red = smem + 2 * ldSc;      // [8][3 * LOSS_NW] one region per reduction
     GAS float* row = m.Sc + (size_t)i * ldSc;
+    // The first LOSS_PRE scores of every thread are requested TOGETHER with the step state (row i exists for every i < B), so
+    // the kernel starts with one memory round trip instead of two (state -> M -> predicated row loads); M only masks them.
+    constexpr int LOSS_PRE = 4;
+    const StepCtx c = load_ctx(st);
+    float pre_s[LOSS_PRE];
+#pragma unroll
+    for (int q = 0; q < LOSS_PRE; ++q) pre_s[q] = row[min(tid + q * LOSS_T, ldSc - 1)];
+    const int M = c.M;
+    if (i >= M) return;
     const bool fsm = (fact == G4R_ACT_SOFTMAX), fsl = (fact == G4R_ACT_SOFTMAX_LOGIT);
     const float n_out = (float)(M + (N - B));      // active columns (gru4rec.py:227,233,244: M + n_sample)
 #define ACTIVE(j) ((j) < M || (j) >= B)
@@ -676,7 +683,12 @@ __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict
     float mneg[1] = {0.f};
     if (fsm || fsl) {
         float mx[1] = {-INFINITY};
-        for (int j = tid; j < N; j += LOSS_T)
+#pragma unroll
+        for (int q = 0; q < LOSS_PRE; ++q) {
+            const int j = tid + q * LOSS_T;
+            if (j < N && ACTIVE(j)) { const float v = pre_s[q]; sy[j] = v; mx[0] = fmaxf(mx[0], v); }
+        }
+        for (int j = tid + LOSS_PRE * LOSS_T; j < N; j += LOSS_T)
             if (ACTIVE(j)) { const float v = row[j]; sy[j] = v; mx[0] = fmaxf(mx[0], v); }
         block_reduce<1, true>(mx, red);
         float sm[1] = {0.f};
@@ -692,7 +704,12 @@ __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict
                 if (j != i) mneg[0] = fmaxf(mneg[0], y);
             }
     } else {
-        for (int j = tid; j < N; j += LOSS_T)
+#pragma unroll
+        for (int q = 0; q < LOSS_PRE; ++q) {
+            const int j = tid + q * LOSS_T;
+            if (j < N && ACTIVE(j)) { const float y = act_fwd(fact, fp0, fp1, pre_s[q]); sy[j] = y; if (j != i) mneg[0] = fmaxf(mneg[0], y); }
+        }
+        for (int j = tid + LOSS_PRE * LOSS_T; j < N; j += LOSS_T)
             if (ACTIVE(j)) { const float y = act_fwd(fact, fp0, fp1, row[j]); sy[j] = y; if (j != i) mneg[0] = fmaxf(mneg[0], y); }
     }
     block_reduce<1, true>(mneg, red + 6 * LOSS_NW);      // its barrier also publishes sy[i]
