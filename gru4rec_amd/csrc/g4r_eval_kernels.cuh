@@ -236,11 +236,6 @@ __global__ void k_selftest_mfma32(const float* A, const float* Bm, float* C, int
     for (int r = 0; r < 16; ++r) C[(8 * (r >> 2) + 4 * lh + (r & 3)) * 32 + l32] = acc[r];
 }
 
-__global__ void k_scale(float* p, long long n, float s) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] *= s;
-}
-
 // explicit instantiations: the launching host code is not visible to the device pass
 template __global__ void k_sparse_update<1>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update<2>(const DevModel*, StepState*, int);
