@@ -57,6 +57,7 @@ struct g4r_model {
     g4r_config cfg;
     DevModel dm;                 // host master copy of the device-resident model descriptor
     DevModel* d_dm = nullptr;    // what the kernels read (passed by pointer: 8-byte kernarg)
+    int n_cu = 256;              // compute units of the device (tile-count heuristics)
     hipStream_t stream = nullptr;
     hipStream_t comm_stream = nullptr;           // all-reduce + dense Adagrad next to the sparse update (nranks > 1)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -165,8 +166,10 @@ static constexpr auto k_score_fwd_k128 = k_score_fwd<GT_BN, GT_BK>;
 #define SFW_BN 32
 #define SFW_BK 64
 static constexpr auto k_score_fwd_k64 = k_score_fwd<SFW_BN, SFW_BK>;
-static constexpr auto k_score_fwd_t2 = k_score_fwd<64, 32>;      // gemm_tile2: 64 x 64 tiles, double-buffered 32-deep chunks
+static constexpr auto k_score_fwd_t2 = k_score_fwd<64, 32, T2_BK>;      // gemm_tile2: 64 x 64 tiles, double-buffered T2_BK-deep chunks
 static const size_t SMEM_SF2 = (size_t)Tile2Cfg<T2_BK>::SMEM_FLOATS * sizeof(float);
+static constexpr auto k_score_fwd_t3 = k_score_fwd<64, 32, 3>;          // gemm_tile3: the same tile fed by LDS-DMA through a ring of stages
+static const size_t SMEM_SF3 = (size_t)Tile3Cfg<T3_NST, T3_BKS>::SMEM_FLOATS * sizeof(float);
 static inline bool score_tile2() { static const bool off = getenv("G4R_NO_TILE2") != nullptr; return !off; }
 static inline bool wide_scores(const DevModel& d);
 // gemm_tile2k scoring backward (k_score_bwd2): long score rows / big batches and D a multiple of 64
@@ -175,7 +178,21 @@ static const size_t SMEM_SF64 = tile_smem<SF_BM, SFW_BN, SFW_BK, false, true>() 
 static constexpr auto k_score_bwd_n = k_score_bwd<32, GT_BK>;
 static constexpr auto k_score_bwd_w = k_score_bwd<64, 64>;
 static const size_t SMEM_SBW = std::max(tile_smem<64, 64, 64, true, false>(), tile_smem<64, 64, 64, false, false>());
-static inline bool wide_scores(const DevModel& d) { static const bool off = getenv("G4R_NARROW_TILES") != nullptr; return !off && d.B >= 256 && d.ldSc >= 4096; }
+static inline int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static inline bool wide_scores(const DevModel& d) {
+    static const bool off = getenv("G4R_NARROW_TILES") != nullptr;
+    static const int minB = env_int("G4R_WIDE_B", 256), minN = env_int("G4R_WIDE_N", 4096);
+    return !off && d.B >= minB && d.ldSc >= minN;
+}
+// LDS-DMA tiles (gemm_tile3, k_score_fwd_t3), D a multiple of 32: where gemm_tile2 served (long score rows / big batches), and
+// for a wide top layer (D >= 256) whenever the batch fills 64-row tiles -- there the launch is a few hundred tiles, fewer than
+// the chip holds at once, and only the ring's depth hides a stage's memory round trip (B = 240, N = 2288, D = 512: 18.7 -> 15.0 us)
+#define ZROW_FLOATS 8192      // DevModel::zrow: an LDS-DMA tile walks K floats along it
+static inline bool score_fwd_dma(const DevModel& d) {
+    static const int on = env_int("G4R_TILE3", 1);
+    if (!on || !score_tile2() || d.Dtop % 32 != 0) return false;
+    return wide_scores(d) || (d.Dtop >= 256 && d.B >= 64 && d.ldSc >= 1024);
+}
 static const size_t SMEM_SF = tile_smem<SF_BM, GT_BN, GT_BK, false, true>() + GT_BN * sizeof(int);
 // publish the host descriptor to the device copy (stream-ordered; pageable source is staged before return)
 static int sync_dm(g4r_model* m) {
@@ -218,8 +235,11 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     if (ndev <= 0) return fail("no HIP device visible: the gfx950 path has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev) return fail("device ordinal out of range");
     HIPCHK(hipSetDevice(cfg->device));
+    int n_cu = 0;
+    HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device));
     g4r_model* m = new g4r_model();
     m->cfg = *cfg;
+    m->n_cu = std::max(n_cu, 1);
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return fail("stream create"); }
     if (hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -303,6 +323,21 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         // k_gru_bwd_fused sums the slabs next to everything else it loads: half as many, twice as deep (k_score_bwd +0.4 us at cfg2)
         const int slabs_target = getenv("G4R_KSLABS") ? atoi(getenv("G4R_KSLABS")) : (fused_bwd(d, d.n_layers - 1) ? 9 : 17);
         d.kch = GT_BK * std::max(1, (cdiv(d.ldSc, GT_BK) + slabs_target / 2) / slabs_target);      // ~17 slabs whatever the number of negatives
+        if (score_bwd2(d) && !getenv("G4R_KSLABS")) {
+            // k_score_bwd2: its 64 x 64 tiles cost microseconds of MFMA each and all of them are resident at once, so the launch
+            // lasts as long as the CU with one tile more than the others.  The number of dh slabs is free: take the one (12..24)
+            // that makes role A + role B tiles fill whole rounds of CUs best (B = 512, N = 8704, D = 256: 17 slabs = 1088 tiles
+            // 64.2 us, 15 slabs = 1024 tiles 60.6 us).  Slab depth only needs the 16-byte alignment of the row loads.
+            const int ndt = d.Dtop / 64, nrt = cdiv(B, 64), nA = cdiv(d.ldSc, 64) * ndt;
+            double best = 2.0;
+            for (int ks = 12; ks <= 24; ++ks) {
+                const int kch = (cdiv(d.ldSc, ks) + 7) & ~7;
+                if (cdiv(d.ldSc, kch) != ks) continue;
+                const double rounds = (double)(nA + ks * nrt * ndt) / m->n_cu;
+                const double waste = (std::ceil(rounds) - rounds) / std::ceil(rounds) + 1e-3 * std::abs(ks - 17);
+                if (waste < best) { best = waste; d.kch = kch; }
+            }
+        }
         d.ksplit = cdiv(d.ldSc, d.kch);
         DA(d.dhpart, (size_t)d.ksplit * B * d.Dtop);
         const int TB = wide_scores(d) ? 64 : 32;      // tile edge of k_score_bwd
@@ -364,6 +399,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_k128, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_k64, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_t2, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_t3, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd_n, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_fwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -385,6 +421,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_score_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel"); }
+    { float* z = nullptr; if (dalloc(m, &z, ZROW_FLOATS)) { g4r_destroy(m); return -1; } d.zrow = z; }
     if (getenv("G4R_CLK")) {
         if (dalloc(m, &d.dbgclk, 64 + 8 * (size_t)d.R) || dalloc(m, &d.dbgtile, 8 * (size_t)(4096 + 4096))) { g4r_destroy(m); return -1; }
     }
@@ -686,7 +723,8 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         end();
     }
     begin(KN_SCORE_FWD);
-    if (wide_scores(d) && score_tile2() && d.Dtop % T2_BK == 0) LK(k_score_fwd_t2, dim3(cdiv(d.ldSc, 64), cdiv(B, 64)), dim3(GT_NTH), SMEM_SF2, s, dmp, stp);
+    if (score_fwd_dma(d)) LK(k_score_fwd_t3, dim3(cdiv(d.ldSc, 64), cdiv(B, 64)), dim3(GT_NTH), SMEM_SF3, s, dmp, stp);
+    else if (wide_scores(d) && score_tile2() && d.Dtop % T2_BK == 0) LK(k_score_fwd_t2, dim3(cdiv(d.ldSc, 64), cdiv(B, 64)), dim3(GT_NTH), SMEM_SF2, s, dmp, stp);
     else if (wide_scores(d)) LK(k_score_fwd_k64, dim3(cdiv(d.ldSc, SFW_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF64, s, dmp, stp);
     else LK(k_score_fwd_k128, dim3(cdiv(d.ldSc, GT_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF, s, dmp, stp);
     end();

@@ -129,6 +129,7 @@ struct DevModel {
     GP(const float) lq_tgt; GP(const float) lq_smp;
     GP(StepState) st;
     GP(long long) dbgclk;   // optional [kernel][16] phase timestamps (100 MHz wall clock), block 0 only
+    GP(const float) zrow;   // 8192 zero floats: what the LDS-DMA tiles read for rows outside the matrix / inactive gathered rows
     GP(long long) dbgtile;  // optional [dense tile][8] phase timestamps of the dense-gradient tiles (G4R_CLK)
 };
 

@@ -249,7 +249,8 @@ template __global__ void k_dense_grad<0>(const DevModel*, StepState*, const Dens
 template __global__ void k_dense_grad<32>(const DevModel*, StepState*, const DenseTile*);
 template __global__ void k_score_fwd<GT_BN, GT_BK>(const DevModel*, StepState*);
 template __global__ void k_score_fwd<32, 64>(const DevModel*, StepState*);
-template __global__ void k_score_fwd<64, 32>(const DevModel*, StepState*);
+template __global__ void k_score_fwd<64, 32, T2_BK>(const DevModel*, StepState*);
+template __global__ void k_score_fwd<64, 32, 3>(const DevModel*, StepState*);
 template __global__ void k_score_bwd<32, GT_BK>(const DevModel*, StepState*, int, int, int, int);
 template __global__ void k_score_bwd<64, 64>(const DevModel*, StepState*, int, int, int, int);
 template __global__ void k_gru_p1<GT_BN, P1_BK>(const DevModel*, StepState*, int, int, int, GruFwdPredict);

@@ -134,6 +134,7 @@ __device__ __forceinline__ void gemm_tile(int m0, int n0, int K, ALoad aload, BL
             stage_issue(rb, kk + BK, bload, tid);
         }
         const int kend = min(BK, K - kk);
+        if (clk && tid == 0 && kk / BK < 8) clk[6 + kk / BK] = wall_clock64();      // chunk kk / BK in LDS, next one requested
         hook(sA, kk, kend);
         // The k-steps run in groups of GT_KU (fully unrolled: all fragment reads of a group are in flight before its first MFMA;
         // a rolled loop waits out one LDS round trip per MFMA).  The chunk length is rounded up to whole groups: the staging
@@ -294,10 +295,11 @@ __device__ __forceinline__ void gemm_tile2(int m0, int n0, int K, ARow arow, BRo
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc = mfma32(av[u], bv[u], acc);
-        if constexpr (BK2 == 32) {
+#pragma unroll
+        for (int g = 1; g < BK2 / 16; ++g) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { av[u] = fa[(16 + 2 * u) ^ sw_fr]; bv[u] = fb[(16 + 2 * u) ^ sw_fr]; }
+            for (int u = 0; u < 8; ++u) { av[u] = fa[(16 * g + 2 * u) ^ sw_fr]; bv[u] = fb[(16 * g + 2 * u) ^ sw_fr]; }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc = mfma32(av[u], bv[u], acc);
@@ -307,6 +309,123 @@ __device__ __forceinline__ void gemm_tile2(int m0, int n0, int K, ARow arow, BRo
     }
     if (trc && tid == 0) trc[3] = wall_clock64();          // K loop done
     // lane holds rows 8 (reg >> 2) + 4 lh + (reg & 3), column l32 of the wave's quadrant: 32 lanes x 4 bytes = 128-byte runs
+#pragma unroll
+    for (int j = 0; j < 16; ++j) epi(m0 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3), n, acc[j], pf[PRE_COL ? 0 : j]);
+    if (trc && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[4] = wall_clock64(); }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// gemm_tile3: gemm_tile2's tile (64 x 64, 4 waves 2 x 2, one v_mfma_f32_32x32x2_f32 accumulator per wave, both operands
+// K-contiguous) fed by LDS-DMA (`global_load_lds_dwordx4`: global -> LDS without passing through registers) through a ring of
+// NST stages of 32 k each.  What it changes against gemm_tile2:
+//   * NST - 1 stages are in flight per workgroup (gemm_tile2: one chunk, held in registers), no ds_write pass, ONE barrier per
+//     stage; the wait for a stage is a counted `s_waitcnt vmcnt(N)` (hipcc does not see the asm loads, so it neither drains them
+//     at the barrier nor waits for them: the waits below are the only ones);
+//   * the DMA writes LDS lane-linearly (wave-uniform base + 16 bytes x lane), so a stage is plain [64 rows][8 quads] per operand and
+//     the bank spreading is done on the SOURCE side: slot q of row r holds the row's quad q ^ ((r >> 1) & 7); the same involution
+//     on the read side makes the 16 lanes of every ds_read_b128 lane group fall on 16 different 16-byte bank columns;
+//   * fragments are read as quads (ds_read_b128: one read per operand and FOUR MFMAs): lanes 0-31 take quad 2 j, lanes 32-63 quad
+//     2 j + 1 of k-group j, and MFMA u of the group multiplies component u -- a permutation of k inside the group that A and B share;
+//   * rows outside the matrix / inactive gathered rows read `zrow` (>= K zero floats in global memory) instead of being masked.
+// LDS: NST stages of 2 * 64 * BKS floats.  K must be a multiple of BKS.
+template <int NST, int BKS = 32>
+struct Tile3Cfg { static constexpr int STAGE = 2 * 64 * BKS, SMEM_FLOATS = NST * STAGE; };
+
+__device__ __forceinline__ void glds16(const GAS float* src, unsigned lds_byte) {      // 64 lanes x 16 bytes -> LDS [lds_byte, + 1 KiB)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_byte) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {      // my LDS-DMA pieces except the newest N have landed; then the workgroup meets
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N) : "memory");
+}
+
+// BKS = 32: a row of a stage is 8 quads, a DMA piece (1 KiB) 8 rows, 2 pieces per wave and operand, f(row) = (row >> 1) & 7;
+// BKS = 16: 4 quads, 16 rows per piece, 1 piece per wave and operand, f(row) = (row >> 2) & 3 (8 KiB stages: more workgroups per CU).
+template <int NST, int BKS, bool PRE_COL, class ARow, class BRow, class Pre, class Epi>
+__device__ __forceinline__ void gemm_tile3(int m0, int n0, int K, ARow arow, BRow brow, const GAS float* zrow, Pre pre, Epi epi, float* smem,
+                                           GAS long long* trc = nullptr) {
+    using C = Tile3Cfg<NST, BKS>;
+    static_assert(NST >= 3 && NST <= 5, "ring depth");
+    static_assert(BKS == 16 || BKS == 32, "stage depth");
+    constexpr int QPR = BKS / 4, RPP = 64 / QPR, NP = 64 / RPP / 4;      // quads per row, rows per piece, pieces per wave and operand
+    constexpr int FSH = BKS == 32 ? 1 : 2, FMASK = QPR - 1;              // f(row) = (row >> FSH) & FMASK
+    constexpr int LPS = 2 * NP;                                          // DMA pieces per wave and stage
+    constexpr unsigned BOFF = 64 * BKS * 4;                              // byte offset of the B half of a stage
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l32 = lane & 31, lh = lane >> 5;
+    const GAS float* pa[NP];
+    const GAS float* pb[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int row = RPP * (NP * wid + j) + lane / QPR;
+        const int quad = (lane & FMASK) ^ ((row >> FSH) & FMASK);
+        const GAS float* a = arow(row);
+        const GAS float* b = brow(row);
+        pa[j] = (a ? a : zrow) + 4 * quad;
+        pb[j] = (b ? b : zrow) + 4 * quad;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    const unsigned piece = lds0 + 1024u * (NP * wid);      // this wave's first A piece inside a stage
+    auto issue = [&](int buf) {
+        const unsigned base = piece + (unsigned)buf * (C::STAGE * 4);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) glds16(pa[j], base + 1024u * j);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) glds16(pb[j], base + BOFF + 1024u * j);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { pa[j] += BKS; pb[j] += BKS; }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    const int nchunk = K / BKS;
+    // epilogue operands first: requested BEFORE the DMA pieces they are older than every piece, so the counted waits below see
+    // only pieces behind the stage they wait for
+    const int n = n0 + wn * 32 + l32;
+    constexpr int NPF = PRE_COL ? 1 : 16;
+    float4 pf[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) pf[j] = pre(m0 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3), n);
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) if (s < nchunk) issue(s);
+    const int fsw = (l32 >> FSH) & FMASK;                 // f(row) of this lane's fragment rows (A and B: 32 | row offset)
+    const float* fa0 = smem + (wm * 32 + l32) * BKS;
+    const float* fb0 = smem + 64 * BKS + (wn * 32 + l32) * BKS;
+    int buf = 0, nbuf = NST - 1;                          // stage i lives in buffer i % NST; the one issued in iteration i in (i + NST - 1) % NST
+    for (int i = 0; i < nchunk; ++i) {
+        // stages i + 1 .. i + NST - 2 may stay in flight (LPS pieces each); at the tail fewer are behind stage i
+        const int behind = min(NST - 2, nchunk - 1 - i);
+        if (NST >= 5 && behind == 3) wait_vm_barrier<3 * LPS>();
+        else if (NST >= 4 && behind == 2) wait_vm_barrier<2 * LPS>();
+        else if (behind == 1) wait_vm_barrier<LPS>();
+        else wait_vm_barrier<0>();
+        if (trc && tid == 0 && i == 0) trc[2] = wall_clock64();          // first stage landed
+        if (i + NST - 1 < nchunk) issue(nbuf);            // into the buffer stage i - 1 was read from (everyone is past the barrier)
+        const float* fa = fa0 + buf * C::STAGE;
+        const float* fb = fb0 + buf * C::STAGE;
+        constexpr int NG = BKS / 8;                       // k-groups of 8: lanes 0-31 read quad 2 j, lanes 32-63 quad 2 j + 1
+        float4 qa[NG], qb[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            qa[j] = *reinterpret_cast<const float4*>(fa + 4 * ((2 * j + lh) ^ fsw));
+            qb[j] = *reinterpret_cast<const float4*>(fb + 4 * ((2 * j + lh) ^ fsw));
+        }
+        __builtin_amdgcn_sched_barrier(0);      // all reads of the stage out before its first MFMA (else: read, wait, 4 MFMAs, read ...)
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            acc = mfma32(qa[j].x, qb[j].x, acc);
+            acc = mfma32(qa[j].y, qb[j].y, acc);
+            acc = mfma32(qa[j].z, qb[j].z, acc);
+            acc = mfma32(qa[j].w, qb[j].w, acc);
+        }
+        buf = (buf + 1 == NST) ? 0 : buf + 1;
+        nbuf = (nbuf + 1 == NST) ? 0 : nbuf + 1;
+    }
+    if (trc && tid == 0) trc[3] = wall_clock64();
 #pragma unroll
     for (int j = 0; j < 16; ++j) epi(m0 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3), n, acc[j], pf[PRE_COL ? 0 : j]);
     if (trc && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[4] = wall_clock64(); }
@@ -342,7 +461,10 @@ __device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, 
         oka = a != nullptr;
         pa = (oka ? a : aprov(0)) + sc;
     }
-    // (measured and rejected: three register sets with the loads of chunk i + 2 issued in iteration i -- the compiler's waitcnt
+    // (measured and rejected: (a) an LDS-DMA ring like gemm_tile3's for these operands (3 stages of 32 k: K-major stages need no
+    // swizzle, the K-contiguous A is read as quads and the K-major B follows its k order) -- results identical, k_score_bwd2 at
+    // B = 512, N = 8704, D = 256 64.6 vs 64.2 us, with 1024 tiles 59.5 vs 60.6: each role alone is bound by how evenly its 64 x 64 x 512
+    // tiles (7.8 us of MFMA each) spread over the CUs, not by the staging; (b) three register sets with the loads of chunk i + 2 issued in iteration i -- the compiler's waitcnt
     // placement still drains to the newest load before every commit, and the extra registers cost a workgroup per CU: 68.5 vs 64.5 us)
     float4 ra, rb;
     const GAS float* qa = nullptr;

@@ -536,17 +536,26 @@ __global__ __launch_bounds__(512) void k_gru_fwd_fused(const DevModel* __restric
 #ifndef T2_BK
 #define T2_BK 16     // K chunk of the gemm_tile2 kernels
 #endif
-template <int TBN, int TBK>
+#ifndef T3_NST
+#define T3_NST 3     // ring depth of the gemm_tile3 (LDS-DMA) kernels
+#endif
+#ifndef T3_BKS
+#define T3_BKS 32    // k per ring stage (measured at B = 512, N = 8704, D = 256 / B = 240, N = 2288, D = 512, us: 3 x 32: 31.3 / 15.0,
+                     // 4 x 16: 32.3 / 16.1, 5 x 16: 32.7 / 16.4 -- gemm_tile2: 34.1 / 17.5)
+#endif
+// T2 > 3: the gemm_tile2 variant (64 x 64 tiles, mfma 32x32x2) with K chunks of T2 floats; T2 == 3: gemm_tile3 (LDS-DMA ring);
+// TBN / TBK then only name the instance
+template <int TBN, int TBK, int T2 = 0>
 __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict__ mp, StepState* st) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
-    constexpr int SMEM_TILE = (TBN == 64 && TBK == 32) ? Tile2Cfg<T2_BK>::SMEM_FLOATS : TileCfg<SF_BM, TBN, TBK, false, true>::SMEM_FLOATS;
+    constexpr int SMEM_TILE = T2 == 3 ? Tile3Cfg<T3_NST, T3_BKS>::SMEM_FLOATS : T2 ? Tile2Cfg<(T2 > 3) ? T2 : 16>::SMEM_FLOATS : TileCfg<SF_BM, TBN, TBK, false, true>::SMEM_FLOATS;
     int* sItem = reinterpret_cast<int*>(smem + SMEM_TILE);   // [TBN]
     const int tid = threadIdx.x;
     // in-kernel phase trace (tools/clk_score.py), gemm_tile2 variant only: in the small-shape variant the test of the descriptor
     // field in front of everything else cost 0.5 us per launch
     GAS long long* trc = nullptr;
-    if constexpr (TBN == 64 && TBK == 32) {
+    if constexpr (T2 != 0) {
         const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
         trc = (G4R_DBGTILE(m) && wgid < 2048) ? G4R_DBGTILE(m) + 8 * (size_t)(4096 + wgid) : nullptr;
         if (trc && tid == 0) trc[0] = wall_clock64();
@@ -558,7 +567,7 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
         const int n = n0 + tid;
         int item = m.cur_col[min(n, m.ldSc - 1)];      // targets | samples of this step, staged by the previous step's bookkeeping
         if (n >= m.ldSc) item = -1;
-        if constexpr (!(TBN == 64 && TBK == 32)) sItem[tid] = item;
+        if constexpr (T2 == 0) sItem[tid] = item;
         if (blockIdx.y == 0 && n < m.ldSc) {
             m.col_item[n] = item;
             if (n < N) {
@@ -600,7 +609,7 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
         if (row >= M || n >= N) return;
         Sc[(size_t)row * ldSc + n] = v + p.x;
     };
-    if constexpr (TBN == 64 && TBK == 32) {      // long score rows / big batches, D a multiple of 32 (host)
+    if constexpr (T2 != 0) {      // long score rows / big batches, D a multiple of T2 (host)
         // the LDS tile fills the workgroup's 32 KiB: column items come straight from the staged list (L2), not from sItem
         const GAS int* ccol = m.cur_col;
         const int ldc = m.ldSc;
@@ -617,7 +626,8 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
             x -= logq * ldf_at(lq ? (n < B ? lq_tgt : lq_smp) : By, max(item, 0), lq);
             return make_float4(x, 0.f, 0.f, 0.f);
         };
-        gemm_tile2<T2_BK, true>(m0, n0, D, arow, brow, pre2, epi, smem, trc);
+        if constexpr (T2 == 3) gemm_tile3<T3_NST, T3_BKS, true>(m0, n0, D, arow, brow, m.zrow, pre2, epi, smem, trc);
+        else gemm_tile2<(T2 > 3) ? T2 : 16, true>(m0, n0, D, arow, brow, pre2, epi, smem, trc);
     } else gemm_tile<SF_BM, TBN, TBK, false, true, GT_NTH>(m0, n0, D, aload, bload, pre, epi, smem);
 }
 
