@@ -336,6 +336,20 @@ __device__ __forceinline__ void glds16(const GAS float* src, unsigned lds_byte) 
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(lds_byte) : "memory");
 }
+// Cooperative LDS-DMA copy of a [nrows][nq quads] matrix into an LDS tile whose rows are LDQ quads apart (LDQ >= nq: padded rows
+// keep the conflict-free strides of the register-staged layouts).  A piece is 64 / LDQ whole rows; the lanes of pad quads and of
+// rows past the matrix are switched off (a masked lane writes nothing: tools/probes/glds_probe.hip), the 8 (NW) waves take pieces
+// round robin.  `src(row, q)` -> address of quad q of row `row`.  Completion: the caller's own `s_waitcnt vmcnt` + barrier.
+template <int LDQ, int NW, class Src>
+__device__ __forceinline__ void dma_rows(unsigned lds_byte, int nrows, int nq, int wid, int lane, Src src) {
+    constexpr int RPP = 64 / LDQ;
+    const int r = lane / LDQ, q = lane - r * LDQ;
+    const bool lane_ok = r < RPP && q < nq;
+    for (int p = wid; p * RPP < nrows; p += NW) {
+        const int row = p * RPP + r;
+        if (lane_ok && row < nrows) glds16(src(row, q), lds_byte + (unsigned)p * (RPP * LDQ * 16));
+    }
+}
 template <int N>
 __device__ __forceinline__ void wait_vm_barrier() {      // my LDS-DMA pieces except the newest N have landed; then the workgroup meets
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N) : "memory");

@@ -337,22 +337,23 @@ __global__ __launch_bounds__(512) void k_gru_fwd_fused(const DevModel* __restric
     // V_r weights: 16 rows of k per pass, one quad of n per thread (32 quad slots, Dq <= 28 used)
     constexpr int NP_R = 7;
     const int kr = tid >> 5, nq = min(tid & 31, Dq - 1);
-    float4 wr1[NP_R], wr2[NP_R];
+    float4 wr1[NP_R];
 #pragma unroll
-    for (int p = 0; p < NP_R; ++p) {
-        wr1[p] = ld4(Wx + (size_t)min(kr + 16 * p, IN - 1) * D3 + D + 4 * nq);
-        wr2[p] = ld4(Wrz + (size_t)min(kr + 16 * p, D - 1) * D2 + 4 * nq);
-    }
-    // 32-column tiles: 64 rows of k per pass, 8 quads per row; columns past the matrix edge are clamped and zeroed at commit
-    const int kt = tid >> 3, tq = tid & 7;
-    const int nz = min(n0 + 4 * tq, D - 4);
-    float4 wzx[2], wzh[2], wcx[2], whh[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        wzx[p] = ld4(Wx + (size_t)min(kt + 64 * p, IN - 1) * D3 + D2 + nz);
-        wcx[p] = ld4(Wx + (size_t)min(kt + 64 * p, IN - 1) * D3 + nz);
-        wzh[p] = ld4(Wrz + (size_t)min(kt + 64 * p, D - 1) * D2 + D + nz);
-        whh[p] = ld4(Wh + (size_t)min(kt + 64 * p, D - 1) * D + nz);
+    for (int p = 0; p < NP_R; ++p) wr1[p] = ld4(Wx + (size_t)min(kr + 16 * p, IN - 1) * D3 + D + 4 * nq);
+    // Everything else that does not wait for the gather goes global -> LDS by LDS-DMA, into the padded [k][n] tiles (~90 KB per
+    // workgroup without passing through registers: 14 + 8 quads per thread less to hold and to store; k_gru_fwd_fused 10.5 -> 10.2 us
+    // at D = 100 -- the phase is bound by the first-touch latency of weights another XCD rewrote a few microseconds ago, not by the
+    // copy).  Columns of the 32-column tiles past the matrix edge read clamped addresses: they only feed output columns that are
+    // never stored.
+    if (m0 < M) {      // (a row block past the batch leaves below: it must not leave DMA writes behind)
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+        dma_rows<FF_LDR / 4, 8>(lds0 + 4u * L.sWr, D, Dq, wid, lane, [&](int k, int q) { return Wrz + (size_t)k * D2 + 4 * q; });
+        dma_rows<FF_LDT / 4, 8>(lds0 + 4u * L.sWz, KA, 8, wid, lane, [&](int k, int q) {
+            const int nzq = min(n0 + 4 * q, D - 4);
+            return k < IN ? Wx + (size_t)k * D3 + D2 + nzq : Wrz + (size_t)(k - IN) * D2 + D + nzq;
+        });
+        dma_rows<FF_LDT / 4, 8>(lds0 + 4u * L.sWc, IN, 8, wid, lane, [&](int k, int q) { return Wx + (size_t)k * D3 + min(n0 + 4 * q, D - 4); });
+        dma_rows<FF_LDT / 4, 8>(lds0 + 4u * L.sWh, D, 8, wid, lane, [&](int k, int q) { return Wh + (size_t)k * D + min(n0 + 4 * q, D - 4); });
     }
     // hidden part of the A rows: 16 rows x 32 quad slots
     const int ar = tid >> 5, aq = tid & 31;
@@ -384,25 +385,7 @@ __global__ __launch_bounds__(512) void k_gru_fwd_fused(const DevModel* __restric
     if (m0 >= M) return;
     // ---- everything that does not wait for the gather goes to LDS now ([k][n] tiles, 16-byte stores): the hidden-part
     // weights of V_r (the input part follows into the same buffer after stage A1), the 32-column tiles, the H part of the rows
-#pragma unroll
-    for (int p = 0; p < NP_R; ++p) {
-        const int k = kr + 16 * p;
-        if (k < D && (tid & 31) < Dq) st4(sWr + k * FF_LDR + 4 * nq, wr2[p]);
-    }
-    const bool tz = n0 + 4 * tq < D;      // D % 4 == 0: a quad is inside or outside as a whole
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int k = kt + 64 * p;
-        if (k < IN) {
-            st4(sWz + k * FF_LDT + 4 * tq, tz ? wzx[p] : zero4);
-            st4(sWc + k * FF_LDT + 4 * tq, tz ? wcx[p] : zero4);
-        }
-        if (k < D) {
-            st4(sWz + (IN + k) * FF_LDT + 4 * tq, tz ? wzh[p] : zero4);
-            st4(sWh + k * FF_LDT + 4 * tq, tz ? whh[p] : zero4);
-        }
-    }
     const bool arow_ok = m0 + ar < M;      // rows past the batch are zero
     if (aq < Dq) {      // row stride == 2 mod 4: 8-byte stores
         float2* d = reinterpret_cast<float2*>(sA + ar * LDA + IN + 4 * aq);
@@ -410,6 +393,7 @@ __global__ __launch_bounds__(512) void k_gru_fwd_fused(const DevModel* __restric
         d[1] = arow_ok ? make_float2(ah.z, ah.w) : make_float2(0.f, 0.f);
     }
     if (clk && tid == 0) clk[2] = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed (hipcc does not count them)
     __syncthreads();
     if (clk && tid == 0) clk[3] = wall_clock64();
     // input part of the A rows: gathered table rows (layer 0) or the lower layer's output; in flight during stage A1
