@@ -814,23 +814,33 @@ __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict
             Lrow = s1;
             dyd = -s3;
         }
-        for (int j = tid; j < N; j += LOSS_T)
-            if (ACTIVE(j)) {
-                const float y = sy[j];
-                float d;
-                if (j == i) d = dyd;
-                else {
-                    const float e = se[j], p = e * inv_sm;
-                    if (lossk == G4R_LOSS_BPR_MAX) {
-                        const float sg = frcp(1.0f + e * cexp);
-                        d = -p * (sg - sg * (1.f - sg) - s1) * inv_A + bpreg * p * (2.f * y + y * y - s2);
-                    } else {
-                        const float u = 1.0f - frcp(1.0f + e * cexp), q = sigmoidf_(y * y);
-                        d = p * (u + q - s1) + p * (u * (1.f - u) + 2.f * y * q * (1.f - q));
-                    }
-                }
-                se[j] = d;
+        auto dL = [&](int j, float y) -> float {      // d L / d yhat_j
+            if (j == i) return dyd;
+            const float e = se[j], p = e * inv_sm;
+            if (lossk == G4R_LOSS_BPR_MAX) {
+                const float sg = frcp(1.0f + e * cexp);
+                return -p * (sg - sg * (1.f - sg) - s1) * inv_A + bpreg * p * (2.f * y + y * y - s2);
             }
+            const float u = 1.0f - frcp(1.0f + e * cexp), q = sigmoidf_(y * y);
+            return p * (u + q - s1) + p * (u * (1.f - u) + 2.f * y * q * (1.f - q));
+        };
+        if (!(fsm || fsl)) {
+            // element-wise final activation (the usual partner of these losses): d cost / d s = dL f'(s) needs no row sum, so the
+            // gradient goes straight to the row in memory -- one pass over the row (a store and a load of se per element) less
+            for (int j = tid; j < ldSc; j += LOSS_T) {
+                float out = 0.f;
+                if (j < N && ACTIVE(j)) {
+                    const float y = sy[j];
+                    out = dL(j, y) * act_bwd_from_out(fact, fp0, fp1, y);
+                    out *= invB;
+                }
+                row[j] = out;
+            }
+            if (tid == 0) m.lossrow[i] = Lrow;
+            return;
+        }
+        for (int j = tid; j < N; j += LOSS_T)
+            if (ACTIVE(j)) se[j] = dL(j, sy[j]);
     }
     // ---- d L / d yhat -> d cost / d s through the final activation, straight to the row in memory (inactive and
     // padding columns get 0).  softmax: y (d - sum_j d_j y_j); softmax_logit: softmax_k sum_j d_j - d_k with
