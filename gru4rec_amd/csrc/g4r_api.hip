@@ -217,14 +217,14 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     if (cfg->n_layers < 1 || cfg->n_layers > G4R_MAX_LAYERS) return fail("n_layers out of range");
     if (cfg->batch_size < 1 || cfg->n_items < 1) return fail("batch_size / n_items must be positive");
     for (int l = 0; l < cfg->n_layers; ++l)
-        if (cfg->layers[l] % 4 != 0 || cfg->layers[l] < 4 || cfg->layers[l] > 512)
-            return fail("layer sizes must be multiples of 4 in [4, 512]");
-    if (cfg->embed_mode == G4R_EMBED_SEPARATE && (cfg->embedding % 4 != 0 || cfg->embedding < 4 || cfg->embedding > 512))
-        return fail("embedding must be a multiple of 4 in [4, 512]");
+        if (cfg->layers[l] % 4 != 0 || cfg->layers[l] < 4 || cfg->layers[l] > 1024)
+            return fail("layer sizes must be multiples of 4 in [4, 1024]");
+    if (cfg->embed_mode == G4R_EMBED_SEPARATE && (cfg->embedding % 4 != 0 || cfg->embedding < 4 || cfg->embedding > 1024))
+        return fail("embedding must be a multiple of 4 in [4, 1024]");
     if (cfg->embed_mode != G4R_EMBED_CONSTRAINED && cfg->embed_mode != G4R_EMBED_SEPARATE && cfg->embed_mode != G4R_EMBED_ONEHOT)
         return fail("unsupported embedding mode");
-    if (cfg->embed_mode == G4R_EMBED_ONEHOT && 3 * cfg->layers[0] > 512)
-        return fail("one-hot input: 3 * layers[0] must be <= 512 (row width of the Wx[0] table)");
+    if (cfg->embed_mode == G4R_EMBED_ONEHOT && 3 * cfg->layers[0] > 1024)
+        return fail("one-hot input: 3 * layers[0] must be <= 1024 (row width of the Wx[0] table)");
     if (cfg->loss < 0 || cfg->loss > G4R_LOSS_XE_LOGIT) return fail("unsupported loss");
     if (cfg->smoothing != 0.f && cfg->loss != G4R_LOSS_XE && cfg->loss != G4R_LOSS_XE_LOGIT) return fail("smoothing needs a cross-entropy loss");
     if (cfg->hidden_act == G4R_ACT_SOFTMAX_LOGIT) return fail("softmax_logit is not a hidden activation");
@@ -415,6 +415,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update_generic<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update_generic<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update_generic<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_update<1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_store, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -665,7 +667,10 @@ int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
 
 // ------------------------------------------------------------------------------------------------ the step
 static inline bool no_merge_tail() { static const bool v = getenv("G4R_NO_MERGE") != nullptr; return v; }
-static inline bool merged_update(const g4r_model* m) { return !m->dm.generic && !no_merge_tail(); }
+// float4 chunks per lane a gathered row needs in the sparse update: rows of <= 256 / 512 / 1024 floats
+static inline int row_chunks(const DevModel& d) { const int w = std::max(d.Dtop, d.Ein); return w <= 256 ? 1 : (w <= 512 ? 2 : 4); }
+// (rows wider than 512 floats take the two-launch form: k_update's register budget is sized for two chunks per lane)
+static inline bool merged_update(const g4r_model* m) { return !m->dm.generic && !no_merge_tail() && row_chunks(m->dm) <= 2; }
 // part: 0 = the whole step; 1 = head (everything up to the dense gradients); 2 = tail (all-reduce, dense apply, sparse update)
 static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     DevModel& d = m->dm;
@@ -756,14 +761,13 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         else LK(k_gru_bwd_b, dim3(cdiv(d.IN[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_BB, s, dmp, stp, l);
         end();
     }
-    static const bool no_merge = getenv("G4R_NO_MERGE") != nullptr;
-    merged = !d.generic && !no_merge;
+    merged = merged_update(m);
     if (merged) {
         // dense-gradient tiles (+ fused dense Adagrad on a single GPU; gradients to the RCCL buffer otherwise) and the sparse row
         // update in ONE launch (k_update): the two are independent, the all-reduce / dense apply of N > 1 follow behind
         const size_t smem = std::max(m->dt == 32 ? SMEM_TN : SMEM_DIRECT, m->smem_sparse);
         const dim3 grid(m->ntiles + m->nblk_occ + 1), blk(SP_WAVES * 64);
-        const bool one = std::max(d.Dtop, d.Ein) <= 256;
+        const bool one = row_chunks(d) == 1;
         begin(KN_UPDATE);
         if (m->dt == 0) {
             if (one) LK((k_update<1, 0>), grid, blk, smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);
@@ -814,16 +818,18 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     if (d.generic) {
         // generic optimizer path: the sparse rule on raw per-occurrence gradients
         begin(KN_SPARSE);
-        if (std::max(d.Dtop, d.Ein) <= 256) LK(k_sparse_update_generic<1>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
-        else LK(k_sparse_update_generic<2>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
+        if (row_chunks(d) == 1) LK(k_sparse_update_generic<1>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
+        else if (row_chunks(d) == 2) LK(k_sparse_update_generic<2>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
+        else LK(k_sparse_update_generic<4>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
         end();
         HIPCHK(hipGetLastError());
         return 0;
     }
     if (merged) { HIPCHK(hipGetLastError()); return 0; }
     begin(KN_SPARSE);
-    if (std::max(d.Dtop, d.Ein) <= 256) LK(k_sparse_update<1>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
-    else LK(k_sparse_update<2>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
+    if (row_chunks(d) == 1) LK(k_sparse_update<1>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
+    else if (row_chunks(d) == 2) LK(k_sparse_update<2>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
+    else LK(k_sparse_update<4>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
     end();
     if (overlap) HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0));
 #undef begin

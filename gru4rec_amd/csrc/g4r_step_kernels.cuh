@@ -1728,7 +1728,7 @@ __global__ __launch_bounds__(256) void k_dense_apply(const DevModel* __restrict_
 #endif
 // SP_UB: float4 step-row chunks one lane fetches together; items with more earlier occurrences are "hot"
 
-// MAXCH = float4 chunks per lane (1: row width <= 256, 2: <= 512).
+// MAXCH = float4 chunks per lane (1: row width <= 256, 2: <= 512, 4: <= 1024).
 template <int MAXCH>
 __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__ mp, StepState* st, int nblk_occ, int blk, float* smem) {
     const DevModel& m = *mp;
@@ -2049,7 +2049,7 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
 }
 
 template <int MAXCH>
-__global__ __launch_bounds__(SP_WAVES * 64, 4) void k_sparse_update(const DevModel* __restrict__ mp, StepState* st, int nblk_occ) {
+__global__ __launch_bounds__(SP_WAVES * 64, MAXCH > 2 ? 2 : 4) void k_sparse_update(const DevModel* __restrict__ mp, StepState* st, int nblk_occ) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // workgroup 0 does the step bookkeeping (it depends on nothing the other workgroups produce; dispatched first, it is off the tail)
     sparse_update_block<MAXCH>(mp, st, nblk_occ, blockIdx.x == 0 ? nblk_occ : (int)blockIdx.x - 1, smem);

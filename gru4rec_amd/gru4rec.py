@@ -263,8 +263,8 @@ class GRU4Rec:
             raise IndexError('adapt={} needs {} value(s) in adapt_params'.format(self.adapt, need))     # the reference indexes adapt_params[0..1]
         if self.smoothing and self.loss not in ('cross-entropy', 'xe_logit'):
             raise NotImplementedError('smoothing is only defined for cross-entropy / xe_logit (gru4rec.py:226-235)')
-        if not self.constrained_embedding and not self.embedding and 3 * _pad4(self.layers[0]) > 512:
-            raise NotImplementedError('one-hot input (embedding=0, constrained_embedding=False) needs 3 * layers[0] <= 512 '
+        if not self.constrained_embedding and not self.embedding and 3 * _pad4(self.layers[0]) > 1024:
+            raise NotImplementedError('one-hot input (embedding=0, constrained_embedding=False) needs 3 * layers[0] <= 1024 '
                                       'in the MI355X path; use constrained_embedding=True or embedding=<size> for wider layers')
 
     def _create_model(self, sample_store, batch_size=None):

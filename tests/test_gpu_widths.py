@@ -56,3 +56,36 @@ def test_unaligned_widths_train_like_the_oracle(name):
     pr = gru.predict_next_batch(np.arange(4), ids, None, batch=4)
     assert pr.shape == (gru.n_items, 4) and np.isfinite(pr.values).all()
     gru.close()
+
+
+WIDE = {
+    # rows of more than 512 floats: four quads per lane in the sparse update, dense gradients and sparse update as two launches
+    'constrained_640': dict(layers=[640], constrained_embedding=True, loss='bpr-max', final_act='elu-0.5', bpreg=0.5, learning_rate=0.01),      # (0.05 diverges, in the oracle too)
+    'embedding_600_layer_64': dict(layers=[64], constrained_embedding=False, embedding=600, loss='cross-entropy', final_act='softmax', logq=1.0),
+    'onehot_200': dict(layers=[200], constrained_embedding=False, embedding=0, loss='top1-max', final_act='tanh'),      # Wx[0] rows of 600
+    'adadelta_1000': dict(layers=[1000], constrained_embedding=True, loss='bpr-max', final_act='linear', adapt='adadelta', adapt_params=[0.95],
+                          learning_rate=0.5),
+}
+
+
+@pytest.mark.parametrize('name', sorted(WIDE))
+def test_rows_wider_than_512_floats(name):
+    kw = dict(batch_size=16, n_sample=48, learning_rate=0.05, n_epochs=1, sample_alpha=0.5)
+    kw.update(WIDE[name])
+    data = synth.make_sessions(160, n_items=90, seed=11)
+    gru = GRU4Rec(**kw)
+    gru.fit(data.copy(), sample_store=48 * 40)
+    p = dict(kw)
+    p['layers'] = tuple(p['layers'])
+    p['adapt_params'] = tuple(p.get('adapt_params', ()))
+    run = oracle_fit(data.copy(), p, 48 * 40, seed=gru.seed)
+    got = np.concatenate(gru.step_costs)
+    assert len(got) == len(run.costs) > 15
+    np.testing.assert_allclose(got, run.costs, rtol=2e-3, atol=1e-5)
+    o = run.model
+    np.testing.assert_allclose(gru.Wy, o.Wy, rtol=5e-3, atol=2e-4)
+    np.testing.assert_allclose(gru.Wx[0], o.Wx[0], rtol=5e-3, atol=2e-4)
+    np.testing.assert_allclose(gru.Wh[0], o.Wh[0], rtol=5e-3, atol=2e-4)
+    if kw.get('embedding'):
+        np.testing.assert_allclose(gru.E, o.E, rtol=5e-3, atol=2e-4)
+    gru.close()
