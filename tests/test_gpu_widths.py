@@ -88,4 +88,7 @@ def test_rows_wider_than_512_floats(name):
     np.testing.assert_allclose(gru.Wh[0], o.Wh[0], rtol=5e-3, atol=2e-4)
     if kw.get('embedding'):
         np.testing.assert_allclose(gru.E, o.E, rtol=5e-3, atol=2e-4)
+    ids = np.array(list(gru.itemidmap.index))[:4]      # the prediction path at the same widths
+    pr = gru.predict_next_batch(np.arange(4), ids, None, batch=4)
+    assert pr.shape == (gru.n_items, 4) and np.isfinite(pr.values).all()
     gru.close()

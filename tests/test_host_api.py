@@ -62,7 +62,7 @@ def test_reference_paramfiles_load(tmp_path):
 def test_out_of_scope_options_fail_loudly_at_fit():
     data = synth.make_sessions(50, n_items=30, seed=1)
     for kw in (dict(smoothing=0.1, loss='bpr-max', constrained_embedding=True),
-               dict(layers=[256])):   # last: one-hot input wider than the 512-float row limit
+               dict(layers=[400])):   # last: one-hot input wider than the 1024-float row limit (3 x 400)
         kw.setdefault('layers', [8])
         g = GRU4Rec(batch_size=4, **kw)
         g.n_items = 30
