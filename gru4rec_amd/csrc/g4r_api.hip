@@ -80,6 +80,7 @@ struct g4r_model {
     int dt = 32;                                 // edge of the dense-gradient tiles (64 for wide layers)
     int ntiles = 0, nblkA = 0, nblkB = 0, ndtA = 0, ndtB = 0, nrtB = 0, nblk_occ = 0;
     size_t smem_score = 0, smem_loss = 0, smem_sparse = 0;
+    bool loss_long = false;      // k_loss_rows<true>: score rows too long for two LDS copies
     float* d_tmpH = nullptr;
     // graph
     hipGraphExec_t gexec = nullptr;
@@ -392,6 +393,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     // LDS opt-in
     m->smem_score = ((size_t)(SC_BM + 32) * (SC_KC + 2) + 32) * sizeof(float);
     m->smem_loss = (size_t)(2 * d.ldSc + 18 * LOSS_NW) * sizeof(float);
+    m->loss_long = m->smem_loss > (size_t)(156 * 1024);      // one row copy in LDS, the other in the score row itself (k_loss_rows<true>)
+    if (m->loss_long) m->smem_loss = (size_t)(d.ldSc + 18 * LOSS_NW) * sizeof(float);
     const int big = 156 * 1024;      // leaves room for the few bytes of static LDS some kernels use (__syncthreads_or)
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_p1_n32, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_p1_n64, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -421,7 +424,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_store, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel"); }
     { float* z = nullptr; if (dalloc(m, &z, ZROW_FLOATS)) { g4r_destroy(m); return -1; } d.zrow = z; }
     if (getenv("G4R_CLK")) {
@@ -734,7 +738,8 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     else LK(k_score_fwd_k128, dim3(cdiv(d.ldSc, GT_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF, s, dmp, stp);
     end();
     begin(KN_LOSS);
-    LK(k_loss_rows, dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
+    if (m->loss_long) LK(k_loss_rows<true>, dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
+    else LK(k_loss_rows<false>, dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
     end();
     begin(KN_SCORE_BWD);
     if (score_bwd2(d)) {

@@ -241,6 +241,8 @@ template __global__ void k_sparse_update<1>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update<2>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update_generic<1>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update_generic<2>(const DevModel*, StepState*, int);
+template __global__ void k_loss_rows<false>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<true>(const DevModel*, StepState*);
 template __global__ void k_sparse_update<4>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update_generic<4>(const DevModel*, StepState*, int);
 template __global__ void k_update<1, 32>(const DevModel*, StepState*, const DenseTile*, int, int);

@@ -650,6 +650,9 @@ __device__ __forceinline__ float softplusf_(float x) {      // log(1 + e^x), sta
     return fmaxf(x, 0.f) + log1pf(fexp(-fabsf(x)));
 }
 
+// LONG_ROW (score rows whose two copies do not fit the LDS, > ~19 K columns): `se` lives in the row's own memory instead -- a thread
+// has read its columns' scores before it writes anything there, and only ever revisits its own columns.
+template <bool LONG_ROW>
 __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict__ mp, StepState* st) {
     const DevModel& m = *mp;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -657,10 +660,11 @@ __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict
     const int B = m.B, N = m.N, i = blockIdx.x;
     const int fact = m.final_act, lossk = m.loss, ldSc = m.ldSc;    // snapshot: used inside the loops below
     const float fp0 = m.fa_p0, fp1 = m.fa_p1, invB = m.inv_B, bpreg = m.bpreg, smooth = m.smoothing;
-    float* sy = smem;                  // [ldSc] yhat
-    float* se = smem + ldSc;           // [ldSc] softmax numerators, later d L / d yhat
-    float* red = smem + 2 * ldSc;      // [8][3 * LOSS_NW] one region per reduction
     GAS float* row = m.Sc + (size_t)i * ldSc;
+    float* sy = smem;                  // [ldSc] yhat
+    std::conditional_t<LONG_ROW, GAS float*, float*> se;      // [ldSc] softmax numerators, later d L / d yhat
+    if constexpr (LONG_ROW) se = row; else se = smem + ldSc;
+    float* red = smem + (LONG_ROW ? 1 : 2) * ldSc;      // [8][3 * LOSS_NW] one region per reduction
     // The first LOSS_PRE scores of every thread are requested TOGETHER with the step state (row i exists for every i < B), so
     // the kernel starts with one memory round trip instead of two (state -> M -> predicated row loads); M only masks them.
     constexpr int LOSS_PRE = 4;

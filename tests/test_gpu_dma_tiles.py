@@ -52,3 +52,11 @@ def test_slab_count_that_fills_whole_rounds():
     count it picks (the slabs are summed in a fixed order by k_gru_bwd_pre / k_gru_bwd_fused)."""
     _run('slabs', I=15000, B=256, ns=3840, T=6, store_rows=8, tail=False, loss='top1-max', final_act='tanh', constrained_embedding=True,
          layers=(128,), learning_rate=0.1)
+
+
+@pytest.mark.parametrize('loss,fa', [('bpr-max', 'elu-0.5'), ('cross-entropy', 'softmax'), ('top1-max', 'tanh'), ('xe_logit', 'softmax_logit')])
+def test_score_rows_longer_than_two_lds_copies(loss, fa):
+    """B + n_sample = 20,032 score columns: two copies of a row (yhat and dL/dyhat) no longer fit the 160 KB of LDS, so
+    k_loss_rows<true> keeps the second one in the score row itself.  Same tolerances as the other shapes."""
+    _run('long rows %s' % loss, I=40000, B=32, ns=20000, T=4, store_rows=6, tail=False, loss=loss, final_act=fa, constrained_embedding=True,
+         layers=(32,), learning_rate=0.05, logq=1.0 if loss == 'cross-entropy' else 0.0, bpreg=0.5)
