@@ -204,6 +204,22 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // (tools/probes/mfma_probe.hip): this shape sustains 155 TFLOP/s (65 cycles per 4096 flop per SIMD) from ONE dependent chain per
 // wave, the 16x16x4 shape 99-126 TFLOP/s (40-51 cycles per 2048 flop) whatever the number of chains / waves: the mid-size GEMMs
 // (gemm_tile2) use this one.
+// Workgroups are dealt to the 8 XCDs round robin (workgroup id mod 8), and every XCD has its own L2.  xcd_tile turns the
+// id of a workgroup into a tile index such that the workgroups of ONE XCD walk a contiguous range of tiles: neighbouring tiles
+// (same score columns / same slab of gathered rows) then share an L2 instead of pulling the same bytes into eight of them.
+// A bijection on [0, n) for any n (XCD x owns ceil((n - x) / 8) ids).
+__device__ __forceinline__ int xcd_tile(int id, int n) {
+    const int per = n >> 3, rem = n & 7, x = id & 7, s = id >> 3;
+    return x * per + min(x, rem) + s;
+}
+#ifndef G4R_XCD_SWIZZLE
+#define G4R_XCD_SWIZZLE 1
+#endif
+#if G4R_XCD_SWIZZLE
+#define G4R_XCD_TILE(id, n) xcd_tile((int)(id), (int)(n))
+#else
+#define G4R_XCD_TILE(id, n) ((int)(id))
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);

@@ -546,13 +546,22 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
     }
     const StepCtx c = load_ctx(st);
     const int M = c.M, B = m.B, D = m.Dtop, N = m.N;
-    const int n0 = blockIdx.x * TBN, m0 = blockIdx.y * SF_BM;
+    // the row tiles of a column tile run on ONE XCD (they share the gathered Wy rows of the tile's columns): tile order = column
+    // tile major within an XCD's contiguous range (g4r_device.cuh: xcd_tile)
+    // (the 64 x 64 variants keep the plain order: their launches have a multiple of 8 column tiles per row of tiles, which already
+    // puts a column tile's row tiles on one XCD, and the row-major start order measured 0.7 us better at B = 512, N = 8704)
+    int bx = blockIdx.x, by = blockIdx.y;
+    if constexpr (T2 == 0) {
+        const int tile = G4R_XCD_TILE(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+        bx = tile / (int)gridDim.y; by = tile - bx * (int)gridDim.y;
+    }
+    const int n0 = bx * TBN, m0 = by * SF_BM;
     if (tid < TBN) {
         const int n = n0 + tid;
         int item = m.cur_col[min(n, m.ldSc - 1)];      // targets | samples of this step, staged by the previous step's bookkeeping
         if (n >= m.ldSc) item = -1;
         if constexpr (T2 == 0) sItem[tid] = item;
-        if (blockIdx.y == 0 && n < m.ldSc) {
+        if (by == 0 && n < m.ldSc) {
             m.col_item[n] = item;
             if (n < N) {
                 m.occ_idx[B + n] = item;
@@ -891,7 +900,8 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
     int* sIt = reinterpret_cast<int*>(smem + max(TileCfg<TB, TB, TBK, true, false>::SMEM_FLOATS,
                                                   TileCfg<TB, TB, TBK, false, false>::SMEM_FLOATS));
     if ((int)blockIdx.x < nblkA) {
-        const int nt = blockIdx.x / ndtA, dt = blockIdx.x - nt * ndtA;
+        const int tile = G4R_XCD_TILE(blockIdx.x, nblkA);
+        const int nt = tile / ndtA, dt = tile - nt * ndtA;
         const int n0 = nt * TB, d0 = dt * TB;
         if (tid < TB) sIt[tid] = (n0 + tid < N) ? m.col_item[n0 + tid] : -1;
         __syncthreads();
@@ -929,7 +939,7 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
         gemm_tile<TB, TB, TBK, true, false, GT_NTH>(n0, d0, M, aload, bload, pre, epi, smem);
         return;
     }
-    const int w = blockIdx.x - nblkA;
+    const int w = G4R_XCD_TILE(blockIdx.x - nblkA, (int)gridDim.x - nblkA);
     const int per_kc = nrtB * ndtB;
     const int kc = w / per_kc, rem = w - kc * per_kc, rt = rem / ndtB, dt = rem - rt * ndtB;
     // a slab covers kch = (multiple of TBK) score columns: long score rows (many negatives) use wider slabs so that the
@@ -975,7 +985,8 @@ __global__ __launch_bounds__(256) void k_score_bwd2(const DevModel* __restrict__
     GAS long long* trc = (G4R_DBGTILE(m) && blockIdx.x < 2048) ? G4R_DBGTILE(m) + 8 * (size_t)(4096 + 2048 + blockIdx.x) : nullptr;
     if (trc && tid == 0) { trc[0] = wall_clock64(); trc[5] = c.t; trc[6] = (int)blockIdx.x < nblkA ? 0 : ((int)blockIdx.x < nblkA + nblkB ? 1 : 2); }
     if ((int)blockIdx.x < nblkA) {
-        const int nt = blockIdx.x / ndt, dt = blockIdx.x - nt * ndt;
+        const int tile = G4R_XCD_TILE(blockIdx.x, nblkA);
+        const int nt = tile / ndt, dt = tile - nt * ndt;
         const int n0 = nt * 64, d0 = dt * 64;
         if (tid < 64) sIt[tid] = (n0 + tid < N) ? m.col_item[n0 + tid] : -1;
         __syncthreads();
@@ -1004,7 +1015,7 @@ __global__ __launch_bounds__(256) void k_score_bwd2(const DevModel* __restrict__
         return;
     }
     if ((int)blockIdx.x < nblkA + nblkB) {
-        const int w = blockIdx.x - nblkA;
+        const int w = G4R_XCD_TILE(blockIdx.x - nblkA, nblkB);
         const int per_kc = nrt * ndt;
         const int kc = w / per_kc, rem = w - kc * per_kc, rt = rem / ndt, dt = rem - rt * ndt;
         const int kch = m.kch, m0 = rt * 64, d0 = dt * 64, kbeg = kc * kch;
@@ -2072,8 +2083,9 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_update(const DevModel* __r
     const int b = (int)blockIdx.x - 1;
     if (b < 0) sparse_update_block<MAXCH>(mp, st, nblk_occ, nblk_occ, smem);
     else if (b < ntiles) {
-        if constexpr (DT == 0) dense_grad_direct<SP_WAVES>(*mp, st, tiles_, b, smem);
-        else dense_grad_tile<DT>(*mp, st, tiles_, b, smem);
+        const int t = G4R_XCD_TILE(b, ntiles);      // neighbouring tiles of the table share their X rows: keep them on one XCD
+        if constexpr (DT == 0) dense_grad_direct<SP_WAVES>(*mp, st, tiles_, t, smem);
+        else dense_grad_tile<DT>(*mp, st, tiles_, t, smem);
     } else sparse_update_block<MAXCH>(mp, st, nblk_occ, b - ntiles, smem);
 }
 
