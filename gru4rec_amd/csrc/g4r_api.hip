@@ -84,6 +84,7 @@ struct g4r_model {
     float* d_tmpH = nullptr;
     // graph
     hipGraphExec_t gexec = nullptr;
+    hipGraphExec_t gexec_small = nullptr;        // single GPU: G4R_GRAPH_STEPS_SMALL steps, for what a run leaves after the big replays
     hipGraphExec_t gexec_head = nullptr;         // N > 1 fallback: one step's kernels up to the dense gradients, RCCL eager behind it
     int graph_steps = 0;
     bool dist_graph_failed = false;              // capturing the step with its RCCL all-reduce did not work: head graph + eager tail
@@ -442,6 +443,7 @@ void g4r_destroy(g4r_model* m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->comm_stream) (void)hipStreamSynchronize(m->comm_stream);
     if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
+    if (m->gexec_small) (void)hipGraphExecDestroy(m->gexec_small);
     if (m->gexec_head) (void)hipGraphExecDestroy(m->gexec_head);
     if (m->comm_ready) (void)ncclCommDestroy(m->comm);
     for (auto e : m->evs) (void)hipEventDestroy(e);
@@ -665,6 +667,7 @@ int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
         if (ensure_step_graph(m, &whole)) return -1;
         hipGraphExec_t ge = whole ? m->gexec : m->gexec_head;
         if (ge) (void)hipGraphUpload(ge, m->stream);
+        if (whole && m->gexec_small) (void)hipGraphUpload(m->gexec_small, m->stream);
     }
     return 0;
 }
@@ -858,6 +861,7 @@ static int apply_compaction(g4r_model* m, int64_t ci) {
 }
 
 #define G4R_GRAPH_STEPS 16
+#define G4R_GRAPH_STEPS_SMALL 4
 // N > 1 (or the one-rank staged mode): the all-reduce is captured with the step, so that a replay covers 16 whole steps
 // (kernels, RCCL all-reduce, dense apply) with no host work in between; G4R_RCCL_EAGER=1 keeps RCCL out of the graph
 static inline bool dist_graph_wanted(const g4r_model* m) {
@@ -887,6 +891,19 @@ static int ensure_graph(g4r_model* m) {
     (void)hipGraphDestroy(graph);
     if (e != hipSuccess) { m->gexec = nullptr; (void)hipGetLastError(); return fail(std::string("graph instantiate: ") + hipGetErrorString(e)); }
     m->graph_steps = G4R_GRAPH_STEPS;
+    if (!dist) {
+        // a second, short graph: a run of 20 steps replays 16 + 4 instead of 16 + four eager steps (six launches each).  Best
+        // effort: without it the remainder is launched eagerly as before.
+        hipGraph_t g2 = nullptr;
+        if (hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            int rc2 = 0;
+            for (int i = 0; i < G4R_GRAPH_STEPS_SMALL && !rc2; ++i) rc2 = launch_step(m, nullptr);
+            hipError_t e2 = hipStreamEndCapture(m->stream, &g2);
+            if (!rc2 && e2 == hipSuccess && g2 && hipGraphInstantiate(&m->gexec_small, g2, nullptr, nullptr, 0) != hipSuccess) m->gexec_small = nullptr;
+            if (g2) (void)hipGraphDestroy(g2);
+            (void)hipGetLastError();
+        }
+    }
     return 0;
 }
 // the step graph for this model: the whole step (single GPU; N > 1 with RCCL captured), or -- if RCCL cannot be captured on this
@@ -945,9 +962,11 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
         if (m->dm.ns > 0 && !m->store_frozen) run = std::min<int64_t>(run, m->gl - (m->gstep % m->gl));
         if (run <= 0) return fail("internal: empty run");
         int64_t done = 0;
-        if (use_graph && run >= G4R_GRAPH_STEPS) {
+        if (use_graph && run >= G4R_GRAPH_STEPS_SMALL) {
             if (ensure_graph(m)) return -1;
             for (; done + m->graph_steps <= run; done += m->graph_steps) HIPCHK(hipGraphLaunch(m->gexec, m->stream));
+            if (m->gexec_small)
+                for (; done + G4R_GRAPH_STEPS_SMALL <= run; done += G4R_GRAPH_STEPS_SMALL) HIPCHK(hipGraphLaunch(m->gexec_small, m->stream));
         }
         for (; done < run; ++done) {
             if (m->profiling) {
