@@ -29,8 +29,12 @@ __global__ void k_rate(const float* __restrict__ src, long long* out, float* sin
             for (int u = 0; u < NP; ++u) asm volatile("global_load_lds_dwordx4 %0, off" :: "v"(p + 256 * u) : "memory");
         } else {
             float4 v[NP];
+            const float* q = src + (size_t)wid * 65536 + 4 * lane;
+            asm volatile("" : "+v"(q));      // a fresh address every repetition: the loads are not hoisted out of the loop
 #pragma unroll
-            for (int u = 0; u < NP; ++u) v[u] = *(const float4*)(src + (size_t)wid * 65536 + 4 * lane + 256 * u);
+            for (int u = 0; u < NP; ++u) v[u] = *(const float4*)(q + 256 * u);
+#pragma unroll
+            for (int u = 0; u < NP; ++u) asm volatile("" :: "v"(v[u].x), "v"(v[u].w));      // landed values are consumed
 #pragma unroll
             for (int u = 0; u < NP; ++u) acc += v[u].x;
         }
