@@ -99,14 +99,14 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_p1(const DevModel* __restric
     const DevModel& m = *mp;
     const int tid = threadIdx.x;
     const int D = m.D[l], IN = m.IN[l], D3 = 3 * D, K = IN + D;
-    long long t = 0, g = 0;
+    long long g = 0;
     int M;
     const GAS float *Hcur, *ysrc = nullptr;
     const GAS int* gidx = nullptr;
     GAS float *Vc, *zb, *Hrb, *rb = nullptr;
     if (train) {
         const StepCtx c = first ? load_ctx_first(st) : load_ctx(st);
-        t = c.t; g = c.g; M = c.M;
+        g = c.g; M = c.M;
         Hcur = m.H[l][g & 1];
         if (l == 0) gidx = m.cur_in; else ysrc = m.hd[l - 1];      // staged by the previous step's bookkeeping: no wait for t
         Vc = m.Vc[l]; zb = m.z[l]; Hrb = m.Hr[l]; rb = m.r[l];
