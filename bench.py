@@ -8,8 +8,10 @@ RSC15-shaped synthetic sessions (I = 37,483 items), layers=[100], batch=128, n_s
 constrained embedding, Adagrad.  The timed region is K plan steps with the plan, weights and sample store
 already resident in HBM; it includes sample-store refills (as the reference's epoch timing does) and
 excludes plan building / upload.  metric = mini-batches/s exactly as gru4rec.py:661 prints it (steps / seconds);
-events/s is reported next to it.  For N > 1 (one process per GPU, launched by torch.distributed.run) sessions
-are sharded over ranks, dense GRU gradients are all-reduced by RCCL every step, value = sum over ranks.
+events/s is reported next to it.  For N > 1 (one process per GPU: `bench.py --gpus N` spawns its ranks itself, or
+`python -m torch.distributed.run` provides RANK / LOCAL_RANK / WORLD_SIZE) sessions are sharded over ranks, dense GRU gradients
+are all-reduced by RCCL every step, value = sum over ranks.  No torch anywhere: the ranks meet through gru4rec_amd/launch.py
+(file rendezvous of the RCCL unique id) and synchronise through the communicator (g4r_comm_max_i64).
 """
 import argparse
 import json
@@ -185,29 +187,6 @@ def cpu_baseline(cfg, plan, support, budget_s=15.0):
                 events_per_s=ev / dt, host_cpus=os.cpu_count())
 
 
-def spawn_ranks(n):
-    """One process per GPU on this node (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, rendezvous on 127.0.0.1);
-    rank 0's JSON line is this process's output.  Returns the exit code (non-zero if any rank failed)."""
-    import socket
-    import subprocess
-    with socket.socket() as sk:
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this driver
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for r, p in enumerate(procs):
-        code = p.wait()
-        if code != 0:
-            sys.stderr.write('bench.py: rank %d exited with code %d\n' % (r, code))
-            rc = rc or code or 1
-    return rc
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -218,14 +197,15 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-micro', action='store_true', help='skip the row gather / scatter micro-benchmark object')
+    ap.add_argument('--long-steps', type=int, default=2000, help='a run of --steps below this also times that many steps behind the timed region and '
+                    'reports them as "long_run" (a 20-step window is ~1 ms; 0 = off)')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    from gru4rec_amd import launch
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # `python bench.py --gpus N` without a launcher: become the launcher (one process per GPU, as torch.distributed.run would)
-        raise SystemExit(spawn_ranks(args.gpus))
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        raise SystemExit(launch.spawn(__file__, sys.argv[1:], args.gpus))
+    rank, world, local_rank = launch.layout()
     if world != args.gpus:
         raise SystemExit('WORLD_SIZE (%d) != --gpus (%d)' % (world, args.gpus))
     from gru4rec_amd import _native
@@ -233,19 +213,11 @@ def main():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     if world > 1 and _native.device_count() <= local_rank:
         raise SystemExit('rank %d: LOCAL_RANK %d but only %d GPU(s) visible' % (rank, local_rank, _native.device_count()))
-    dist = None
-    unique_id = None
-    if world > 1:
-        # torch.distributed is control plane only (rendezvous, barrier, max-reduce); the data path is RCCL inside the library
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
-        obj = [_native.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(obj, src=0)
-        unique_id = obj[0]
-    n_profile = args.profile_steps if (rank == 0 and world == 1) else 0
-    total_steps = args.warmup + args.steps + n_profile + 8
+    unique_id = launch.unique_id(rank, world)      # rank 0 creates the RCCL id, the others read it (file rendezvous; no torch)
+    # per-kernel durations behind the timed region: every rank runs those steps (the all-reduce is collective), rank 0 reports
+    n_profile = args.profile_steps
+    n_long = args.long_steps if (0 < args.steps < args.long_steps) else 0
+    total_steps = args.warmup + args.steps + n_long + n_profile + 8
     plan, support = make_plan(cfg, total_steps, rank, world)
     assert plan['T'] >= total_steps, 'synthetic plan too short: %d < %d' % (plan['T'], total_steps)
     assert (plan['M'][:total_steps] == cfg['batch_size']).all()
@@ -262,19 +234,32 @@ def main():
     m.train_steps(0, args.warmup)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        if world > 1:
+            launch.barrier(m)      # a max-reduce on the communicator: returns when every rank has entered it
     barrier()
+    launch.cleanup(rank)
     t0 = time.perf_counter()
     m.train_steps(args.warmup, args.steps)        # synchronous at return (hipStreamSynchronize inside)
-    dt = time.perf_counter() - t0
+    dt_own = time.perf_counter() - t0
     barrier()
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
+    dt = dt_own
+    rank_dts = [dt_own]
+    if world > 1:
+        rank_dts = launch.gather_us(m, rank, world, dt_own)
+        dt = max(rank_dts)                        # MAX over ranks
     losses = m.get_losses(args.warmup, args.steps)
+    long_run = None
+    if n_long:
+        # the same measurement over >= 2000 steps right behind the timed region (the driver's --steps 20 is a ~1 ms window)
+        barrier()
+        t1 = time.perf_counter()
+        m.train_steps(args.warmup + args.steps, n_long)
+        dl = time.perf_counter() - t1
+        barrier()
+        if world > 1:
+            dl = launch.max_over_ranks_us(m, dl)
+        long_run = {'steps': n_long, 'value': n_long * world / dl, 'unit': 'mini-batches/s', 'ms_per_step': 1000.0 * dl / n_long,
+                    'note': 'same workload, the next %d plan steps, timed the same way (barrier / synchronize on both sides, max over ranks)' % n_long}
     events = int(plan['M'][args.warmup:args.warmup + args.steps].sum()) * world
     out = {
         'metric': 'mini-batches/sec (gru4rec.py:661), RSC15-shaped batch=128 n_sample=2048 BPR-max' if args.config == 'cfg2'
@@ -293,12 +278,28 @@ def main():
         'events_per_s': events / dt, 'loss_first': float(losses[0]), 'loss_last': float(losses[-1]),
         'loss_finite': bool(np.isfinite(losses).all()),
     }
-    if rank == 0 and world == 1 and n_profile > 0:
+    if long_run:
+        out['long_run'] = long_run
+    kt = {}
+    if n_profile > 0:
         # per-kernel durations: HIP events on the library's own stream, eager launches over the next plan steps
         m.profile(True)
-        m.train_steps(args.warmup + args.steps, n_profile)
+        m.train_steps(args.warmup + args.steps + n_long, n_profile)
         m.profile(False)
         kt = m.kernel_times()
+    if world > 1:
+        def us(name):
+            return 1000.0 * kt[name][0] / max(kt[name][1], 1) if name in kt else None
+        out['multi_gpu'] = {
+            'ncclCommCount': n_ranks, 'rank_ms_per_step': [1000.0 * x / args.steps for x in rank_dts],
+            'rccl_allreduce_us': us('rccl_allreduce'), 'k_dense_apply_us': us('k_dense_apply'),
+            'dense_gradient_bytes': 4 * int(m.get_debug('dense_count', (1,))[0]),
+            'step_graph_holds_allreduce': bool(m.get_debug('graph_mode', (1,))[0] == 1.0),
+            'kernel_us_rank0': {k: 1000.0 * v[0] / max(v[1], 1) for k, v in kt.items()},
+            'note': 'rank_ms_per_step: every rank\'s own wall time of the timed region / steps (value uses the max); all-reduce / dense '
+                    'apply: HIP events around the eager launches of %d profile steps on rank 0 (every step synchronises there, so the '
+                    'all-reduce time includes the skew between ranks)' % n_profile}
+    if rank == 0 and world == 1 and n_profile > 0:
         alg = algorithmic_cost(cfg)
         kern = {}
         for name, (ms, n) in kt.items():
@@ -318,7 +319,9 @@ def main():
         out['kernel_time_sum_us_per_step'] = sum(1000.0 * ms / n_profile for ms, n in kt.values())
         dom = max(kern.items(), key=lambda kv: kv[1]['avg_us'] * kv[1]['launches_per_step'])
         out['dominant_kernel'] = dom[0]
-        pmc_path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_%s.json' % args.config)
+        pmc_path = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic_%s.json' % args.config)
+        if not os.path.exists(pmc_path):
+            pmc_path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_%s.json' % args.config)
         pmc = json.load(open(pmc_path))['kernels'] if os.path.exists(pmc_path) else {}
 
         def traffic_of(name):      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_summary.py), bytes per launch
@@ -333,6 +336,11 @@ def main():
             out['roofline'] = {'kernel': dk, 'bound': dv['bound'], 'achieved': dv['achieved'], 'peak': PEAK[dv['bound']][0],
                                'unit': dv['unit'], 'frac': dv['frac'], 'traffic': traffic_of(dk),
                                'algorithmic': a.get('flops', a.get('bytes')), 'avg_us': dv['avg_us'],
+                               'traffic_source': ('%s (STATIC file: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this '
+                                                  'command, tools/pmc_traffic.sh; not measured by the run that prints this line)' %
+                                                  os.path.relpath(pmc_path, ROOT)) if pmc else None,
+                               'avg_us_source': 'HIP events attached to the dispatches (hipExtLaunchKernelGGL) in this run; rocprofv3 '
+                                                '--kernel-trace of the same command reads 0.3-0.9 us more per kernel (profiles/r0x_kernel_stats_*)',
                                'note': 'dominant kernel of the step by time; achieved = algorithmic %s per launch / mean launch duration '
                                        '(HIP events attached to the dispatches, %d steps); traffic = 2 x FETCH_SIZE + WRITE_SIZE from separate '
                                        'rocprofv3 --pmc passes (profiles/%s) when that file is present' % (
@@ -368,13 +376,10 @@ def main():
             out['gather_scatter_micro'] = micro
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, plan, support)
+    barrier()
     m.close()
-    if dist is not None:
-        dist.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

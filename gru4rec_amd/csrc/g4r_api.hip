@@ -107,6 +107,8 @@ struct g4r_model {
     // rccl
     ncclComm_t comm = nullptr;
     bool comm_ready = false;
+    bool virtual_ranks = false;                  // member of a g4r_virtual_train_steps group: the dense gradients are summed in process
+    float* d_vsum = nullptr;                     // scratch of that sum (first member of the group)
     // reconciliation of the GPU-local item tables (g4r_sync_kernels.cuh): per table group (0: Wy / By rows, 1: E rows) the
     // planes (current values, common base, row width) and scratch
     struct SyncPlane { float* cur; float* base; int W; };
@@ -805,8 +807,8 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     if (!d.apply_dense_inplace) {
         // staged dense path: (RCCL all-reduce when there are ranks) -> (global gradient norm -> clip factor, generic path with
         // grad_cap) -> dense rule on the flat gradient buffer
-        const bool dist = m->cfg.nranks > 1 || m->comm_ready;
-        if (m->cfg.nranks > 1 && !m->comm_ready) return fail("nranks > 1 but g4r_comm_init was not called");
+        const bool dist = !m->virtual_ranks && (m->cfg.nranks > 1 || m->comm_ready);
+        if (m->cfg.nranks > 1 && !m->comm_ready && !m->virtual_ranks) return fail("nranks > 1 but g4r_comm_init was not called");
         hipStream_t cs = overlap ? m->comm_stream : s;
         if (dist) {
             if (overlap) { HIPCHK(hipEventRecord(m->ev_fork, s)); HIPCHK(hipStreamWaitEvent(cs, m->ev_fork, 0)); }
@@ -991,6 +993,60 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
         m->gstep += run;
     }
     HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+// ---- virtual ranks ------------------------------------------------------------------------------------------------------
+// n handles on ONE device stand in for the n ranks of a data-parallel run (each created with nranks = n, its own rank, its own
+// plan): every step runs each handle's kernels up to the dense gradients, sums the n gradient buffers in rank order -- what the
+// RCCL all-reduce delivers -- and lets each handle apply the sum (k_dense_apply divides by nranks) next to its GPU-local sparse
+// update.  Item tables are reconciled by the caller with g4r_sync_export / g4r_sync_import.  Validation only (three stream
+// synchronisations per step): the numbers it produces are what an n-GPU run computes, not how fast.
+int g4r_virtual_train_steps(g4r_model* const* ms, int32_t n, int64_t t0, int64_t n_steps) {
+    if (!ms || n < 1 || n > 16) return fail("virtual ranks: 1..16 handles");
+    for (int q = 0; q < n; ++q) {
+        g4r_model* m = ms[q];
+        if (!m || !m->d_in) return fail("virtual ranks: null model / no plan uploaded");
+        if (m->cfg.nranks != n || m->cfg.rank != q) return fail("virtual ranks: handle q must be created with rank = q, nranks = n");
+        if (m->cfg.device != ms[0]->cfg.device || m->dm.dense_count != ms[0]->dm.dense_count) return fail("virtual ranks: handles differ");
+        if (m->comm_ready) return fail("virtual ranks: the handle already has an RCCL communicator");
+        if (t0 < 0 || n_steps < 0 || t0 + n_steps > m->T) return fail("step range outside the plan");
+        if (m->dm.ns > 0 && !m->have_pop && !m->store_frozen) return fail("negative sampling needs g4r_set_popularity first");
+        m->virtual_ranks = true;
+    }
+    HIPCHK(hipSetDevice(ms[0]->cfg.device));
+    g4r_model* m0 = ms[0];
+    const int cnt = m0->dm.dense_count;
+    if (!m0->d_vsum && dalloc(m0, &m0->d_vsum, (size_t)cnt)) return -1;
+    VSumArgs va;
+    memset(&va, 0, sizeof(va));
+    std::vector<size_t> ci(n);
+    for (int q = 0; q < n; ++q) {
+        g4r_model* m = ms[q];
+        va.src[q] = m->dm.dense_g; va.dst[q] = m->dm.dense_g;
+        hipLaunchKernelGGL(k_set_state, dim3(1), dim3(512), 0, m->stream, (const DevModel*)m->d_dm, (StepState*)m->dm.st, (long long)t0, (long long)m->gstep);
+        ci[q] = std::lower_bound(m->compact_steps.begin(), m->compact_steps.end(), t0) - m->compact_steps.begin();
+    }
+    for (int64_t t = t0; t < t0 + n_steps; ++t) {
+        for (int q = 0; q < n; ++q) {
+            g4r_model* m = ms[q];
+            while (ci[q] < m->compact_steps.size() && m->compact_steps[ci[q]] == t) { if (apply_compaction(m, (int64_t)ci[q])) return -1; ++ci[q]; }
+            if (m->dm.ns > 0 && !m->store_frozen && m->gstep > 0 && m->gstep % m->gl == 0) {
+                if (refill_store(m)) return -1;
+                hipLaunchKernelGGL(k_restage_inputs, dim3(1), dim3(512), 0, m->stream, (const DevModel*)m->d_dm, (StepState*)m->dm.st);
+            }
+            if (launch_step(m, nullptr, 1)) return -1;
+        }
+        for (int q = 0; q < n; ++q) HIPCHK(hipStreamSynchronize(ms[q]->stream));
+        hipLaunchKernelGGL(k_virtual_sum, dim3(cdiv(cnt, 256)), dim3(256), 0, m0->stream, va, n, cnt, m0->d_vsum);
+        hipLaunchKernelGGL(k_virtual_bcast, dim3(cdiv(cnt, 256)), dim3(256), 0, m0->stream, va, n, cnt, (const float*)m0->d_vsum);
+        HIPCHK(hipStreamSynchronize(m0->stream));
+        for (int q = 0; q < n; ++q) {
+            if (launch_step(ms[q], nullptr, 2)) return -1;
+            ms[q]->gstep += 1;
+        }
+    }
+    for (int q = 0; q < n; ++q) HIPCHK(hipStreamSynchronize(ms[q]->stream));
     return 0;
 }
 
@@ -1634,6 +1690,7 @@ int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
     else if (s == "ntiles") { if (count < 1) return fail("count"); host[0] = (float)m->ntiles; return 0; }
     else if (s == "ldSc") { if (count < 1) return fail("count"); host[0] = (float)d.ldSc; return 0; }
     else if (s == "ksplit") { if (count < 1) return fail("count"); host[0] = (float)d.ksplit; return 0; }
+    else if (s == "dense_count") { if (count < 1) return fail("count"); host[0] = (float)d.dense_count; return 0; }
     else if (s == "occ_score_tile") {      // resident workgroups per CU the runtime reports for the gemm_tile2 scoring kernel
         if (count < 1) return fail("count");
         int nb = 0;

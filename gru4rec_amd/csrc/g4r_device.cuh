@@ -11,6 +11,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define G4R_EPS_LOSS 1e-24f    /* gru4rec.py:230,241 */
 #define G4R_EPS_ADAGRAD 1e-6f  /* gru4rec.py:330 */
 
+// Mutation builds for the parity suite's self-test (tests/test_gpu_mutation.py builds them as variant libraries next to the product
+// one and expects the parity tests to turn red): G4R_MUTATE=1 inflates every per-occurrence sparse accumulator increment by
+// 1 %, =2 every sparse Adagrad step by 1 %, =3 every dense accumulator increment by 1 %.  Never defined in the product build.
+#if defined(G4R_MUTATE) && G4R_MUTATE == 1
+#define G4R_MUT_ACC(x) ((x) * 1.01f)
+#else
+#define G4R_MUT_ACC(x) (x)
+#endif
+#if defined(G4R_MUTATE) && G4R_MUTATE == 2
+#define G4R_MUT_STEP(x) ((x) * 1.01f)
+#else
+#define G4R_MUT_STEP(x) (x)
+#endif
+#if defined(G4R_MUTATE) && G4R_MUTATE == 3
+#define G4R_MUT_DACC(x) ((x) * 1.01f)
+#else
+#define G4R_MUT_DACC(x) (x)
+#endif
+
 // Philox stream ids (counter word 3); twin of oracle/philox.py
 #define G4R_STREAM_SAMPLE 0x53414D50u
 #define G4R_STREAM_DROP_EMBED 0x44454D42u

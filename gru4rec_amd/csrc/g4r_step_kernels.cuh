@@ -930,8 +930,8 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
         };
         auto epi = [&](int n, int d, float g, float4 p) {
             if (n >= N || d > D) return;
-            const float an = p.x + g * g;
-            float step = (p.y != 0.f) ? lr * g * frsq(an + G4R_EPS_ADAGRAD) : 0.f;
+            const float an = p.x + G4R_MUT_ACC(g * g);
+            float step = (p.y != 0.f) ? G4R_MUT_STEP(lr * g * frsq(an + G4R_EPS_ADAGRAD)) : 0.f;
             if (generic) step = (p.y != 0.f) ? g : 0.f;      // raw per-occurrence gradient: the update kernel applies the rule
             if (d < D) { dSy[(size_t)n * D + d] = step; dAy[(size_t)n * D + d] = an; }
             else { dSBy[n] = step; dABy[n] = an; }
@@ -1005,8 +1005,8 @@ __global__ __launch_bounds__(256) void k_score_bwd2(const DevModel* __restrict__
         };
         auto epi = [&](int n, int d, float g, float4 p) {
             if (n >= N) return;
-            const float an = p.x + g * g;
-            float step = (p.y != 0.f) ? lr * g * frsq(an + G4R_EPS_ADAGRAD) : 0.f;
+            const float an = p.x + G4R_MUT_ACC(g * g);
+            float step = (p.y != 0.f) ? G4R_MUT_STEP(lr * g * frsq(an + G4R_EPS_ADAGRAD)) : 0.f;
             if (generic) step = (p.y != 0.f) ? g : 0.f;
             dSy[(size_t)n * D + d] = step; dAy[(size_t)n * D + d] = an;
         };
@@ -1053,8 +1053,8 @@ __global__ __launch_bounds__(256) void k_score_bwd2(const DevModel* __restrict__
             const float g = (smem[cl] + smem[64 + cl]) + (smem[128 + cl] + smem[192 + cl]);
             const int item = m.col_item[n];
             const bool ok = item >= 0;
-            const float an = ldf_at(m.accBy, max(item, 0), ok) + g * g;
-            float step = ok ? lr * g * frsq(an + G4R_EPS_ADAGRAD) : 0.f;
+            const float an = ldf_at(m.accBy, max(item, 0), ok) + G4R_MUT_ACC(g * g);
+            float step = ok ? G4R_MUT_STEP(lr * g * frsq(an + G4R_EPS_ADAGRAD)) : 0.f;
             if (generic) step = ok ? g : 0.f;
             m.dSBy[n] = step; m.dABy[n] = an;
         }
@@ -1163,8 +1163,8 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_bwd_b(const DevModel* __rest
         if (row >= M || n >= IN) return;
         if (l == 0) {
             if (drop_e > 0.f) v *= drop_mult(seed, (unsigned)c.g, G4R_STREAM_DROP_EMBED, row, n, 1.0f - drop_e);
-            const float an = p.x + v * v;
-            dSx[(size_t)row * IN + n] = generic ? v : lr * v * frsq(an + G4R_EPS_ADAGRAD);
+            const float an = p.x + G4R_MUT_ACC(v * v);
+            dSx[(size_t)row * IN + n] = generic ? v : G4R_MUT_STEP(lr * v * frsq(an + G4R_EPS_ADAGRAD));
             dAx[(size_t)row * IN + n] = an;
         } else {
             dylo[(size_t)row * IN + n] = v;
@@ -1401,8 +1401,8 @@ __global__ __launch_bounds__(512) void k_gru_bwd_fused(const DevModel* __restric
         float v = acc2[rg];
         if (l == 0) {
             if (drop_e > 0.f) v *= drop_mult(seed, (unsigned)c.g, G4R_STREAM_DROP_EMBED, row, n, 1.0f - drop_e);
-            const float an = a2[rg] + v * v;
-            dSx[(size_t)row * IN + n] = generic ? v : lr * v * frsq(an + G4R_EPS_ADAGRAD);
+            const float an = a2[rg] + G4R_MUT_ACC(v * v);
+            dSx[(size_t)row * IN + n] = generic ? v : G4R_MUT_STEP(lr * v * frsq(an + G4R_EPS_ADAGRAD));
             dAx[(size_t)row * IN + n] = an;
         } else {
             dylo[(size_t)row * IN + n] = v;
@@ -1497,7 +1497,7 @@ __device__ __forceinline__ void dense_grad_tile(const DevModel& m, StepState* st
         if (row >= tl.nrows || col >= tl.ncols) return;
         const size_t off = (size_t)tl.base + (size_t)row * tl.ldo + col;
         if (!inplace) { dg[off] = g; return; }
-        const float acc = p.x + g * g;            // gru4rec.py:330-334,390-406
+        const float acc = p.x + G4R_MUT_DACC(g * g);            // gru4rec.py:330-334,390-406
         dacc[off] = acc;
         const float gs = g * frsq(acc + G4R_EPS_ADAGRAD);
         if (momc > 0.f) {

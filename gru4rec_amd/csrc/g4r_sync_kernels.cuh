@@ -41,3 +41,20 @@ __global__ __launch_bounds__(256) void k_sync_rebase(const float* cur, float* ba
     const size_t o = (size_t)ids[j] * W + (int)(e - j * W);
     base[o] = cur[o];
 }
+
+// ---- virtual ranks (g4r_virtual_train_steps): the dense-gradient buffers of n handles on one device summed in rank order -- what
+// the RCCL all-reduce of a real n-GPU run delivers -- and handed back to every handle
+struct VSumArgs { const float* src[16]; float* dst[16]; };
+__global__ __launch_bounds__(256) void k_virtual_sum(VSumArgs a, int n, int count, float* tmp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int q = 0; q < n; ++q) s += a.src[q][i];      // rank order
+    tmp[i] = s;
+}
+__global__ __launch_bounds__(256) void k_virtual_bcast(VSumArgs a, int n, int count, const float* tmp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const float s = tmp[i];
+    for (int q = 0; q < n; ++q) a.dst[q][i] = s;
+}

@@ -289,7 +289,7 @@ class GRU4Rec:
             dropout_p_hidden=self.dropout_p_hidden, dropout_p_embed=self.dropout_p_embed,
             sample_store=int(sample_store), seed=int(self.seed) + 7919 * rank, device=int(self.device),
             rank=rank, nranks=nranks, use_graph=1 if self.use_graph else 0)
-        if self._dist:
+        if self._dist and self._dist['unique_id'] is not None:
             m.comm_init(self._dist['unique_id'], nranks, rank)
         return m
 
@@ -398,10 +398,20 @@ class GRU4Rec:
 
     def _download_optimizer_state(self):
         m = self._model
-        st = {'arrays': {}, 'global_step': m.global_step(), 'refills': m.refills()}
+        # np_random_state: the session order of train_random_order comes from NumPy's global stream (np.random.permutation per
+        # epoch, gru4rec.py:593), seeded by the weight initialisation; a resumed run has to continue THAT stream
+        st = {'arrays': {}, 'global_step': m.global_step(), 'refills': m.refills(), 'np_random_state': np.random.get_state(),
+              'config': self._opt_config()}
         for name, layer, shape in self._opt_tables():
             st['arrays'][(name, layer)] = self._dev_get(m, name, shape, layer)
         return st
+
+    def _opt_config(self):
+        """What the saved optimizer state is a function of: resuming under another value of any of these would either not find its
+        arrays or silently drop some (e.g. the velocities when momentum goes to 0)."""
+        return dict(adapt=self.adapt, adapt_params=[float(x) for x in self.adapt_params], momentum=float(self.momentum),
+                    layers=[int(x) for x in self.layers], embedding=int(self.embedding or 0),
+                    constrained_embedding=bool(self.constrained_embedding), batch_size=int(self.batch_size), n_sample=int(self.n_sample))
 
     def _upload_optimizer_state(self, m, st):
         for name, layer, shape in self._opt_tables():
@@ -410,8 +420,11 @@ class GRU4Rec:
 
     def set_distributed(self, rank, nranks, unique_id):
         """One process per GPU: sessions are sharded round-robin over ranks, dense GRU gradients are
-        all-reduced with RCCL every step, embedding rows stay GPU-local."""
-        self._dist = dict(rank=int(rank), nranks=int(nranks), unique_id=unique_id) if nranks > 1 else None
+        all-reduced with RCCL every step, embedding rows stay GPU-local.
+        unique_id = None: a virtual rank (gru4rec_amd/virtual_ranks.py: several handles of ONE process stand in for the ranks; no
+        communicator is created and the caller steps the handles together)."""
+        # (a one-rank layout with an id: the N > 1 data path on a one-rank communicator, G4R_FORCE_STAGED=1 -- tests)
+        self._dist = dict(rank=int(rank), nranks=int(nranks), unique_id=unique_id) if (nranks > 1 or unique_id is not None) else None
 
     # ------------------------------------------------------------------ training (gru4rec.py:515-664)
     def prepare(self, data, sample_store=10000000, store_type='gpu', resume=False):
@@ -422,6 +435,10 @@ class GRU4Rec:
         if store_type not in ('gpu', 'cpu'):
             print('Invalid store type {}'.format(store_type))
             raise NotImplementedError
+        if resume and store_type == 'cpu' and self.n_sample:
+            # before anything is built (the reference validates store_type first as well, gru4rec.py:546-555)
+            raise NotImplementedError('resume=True with store_type="cpu": the host sampler interleaves its draws with the session '
+                                      'order on NumPy\'s global random stream; only the device store (store_type="gpu") resumes')
         self.predict = None
         self.error_during_train = False
         item_col = data[self.item_key]
@@ -439,6 +456,13 @@ class GRU4Rec:
                 raise ValueError('resume=True needs a model saved with savemodel(fname, optimizer_state=True)')
             if len(itemids) != self.n_items or not np.array_equal(np.asarray(itemidmap.index), np.asarray(self.itemidmap.index)):
                 raise ValueError('resume=True: the training data does not produce the item map of the checkpoint')
+            saved_cfg = self.optimizer_state.get('config')
+            if saved_cfg is not None and saved_cfg != self._opt_config():
+                diff = sorted(k for k in saved_cfg if saved_cfg[k] != self._opt_config().get(k))
+                raise ValueError('resume=True: %s differ(s) from the checkpoint (%s), its optimizer state does not apply' % (
+                    ', '.join(diff), ', '.join('%s=%r' % (k, saved_cfg[k]) for k in diff)))
+            if self.train_random_order and self.optimizer_state.get('np_random_state') is None:
+                raise ValueError('resume=True with train_random_order: the checkpoint does not hold the random stream of the session order')
         self.n_items = len(itemids)
         self.itemidmap = itemidmap
         datatools.sort_if_needed(data, [self.session_key, self.time_key])
@@ -455,9 +479,6 @@ class GRU4Rec:
         m = self._model
         self._upload_weights(m)
         self._cpu_store = bool(store_type == 'cpu' and self.n_sample)
-        if self._cpu_store and resume:
-            raise NotImplementedError('resume=True with store_type="cpu": the host sampler runs on NumPy\'s global random stream, '
-                                      'which a checkpoint does not hold')
         if self.n_sample and m.sample_store_rows() <= 1:
             print('No example store was used')      # negatives are then drawn anew for every step (gru4rec.py:548-550,614-615)
         lq_t = lq_s = None
@@ -478,6 +499,8 @@ class GRU4Rec:
             print('Created sample store with {} batches of samples (type={})'.format(m.sample_store_rows(), 'CPU' if self._cpu_store else 'GPU'))
         if resume:
             self._upload_optimizer_state(m, self.optimizer_state)
+            if self.optimizer_state.get('np_random_state') is not None:
+                np.random.set_state(self.optimizer_state['np_random_state'])      # continue the stream of np.random.permutation (:593)
         if self.time_sort:
             # data is ordered by (session, time): a session's first row holds its minimum time (the groupby().min() of
             # gru4rec.py:585-586, sessions in ascending id order)
@@ -548,7 +571,10 @@ class GRU4Rec:
             done += n
         cc = plan['M'][:T]
         avgc = np.sum(costs * cc) / max(np.sum(cc), 1)
-        if np.isnan(avgc):
+        bad = bool(np.isnan(avgc))
+        if self._dist:
+            bad = bool(m.comm_max(int(bad)))      # collective like the per-chunk exit: a lone return would hang the other ranks
+        if bad:
             print('Epoch {}: NaN error!'.format(str(epoch)))
             self.error_during_train = True
             return None

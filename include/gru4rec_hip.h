@@ -196,6 +196,13 @@ int64_t g4r_sync_row_floats(g4r_model* m, int32_t group);
 int64_t g4r_sync_export(g4r_model* m, int32_t group, int32_t* ids, float* rows, int64_t cap_rows);
 int g4r_sync_import(g4r_model* m, int32_t group, int32_t nparts, const int64_t* counts, const int32_t* const* ids,
                     const float* const* rows);
+/* Virtual ranks: `n` handles on ONE device stand in for the n ranks of a data-parallel run (handle q created with rank = q,
+ * nranks = n, no communicator; each with its own plan of the same length).  Runs plan steps [t0, t0 + n_steps) in lock-step:
+ * per step every handle's kernels up to the dense gradients, the n gradient buffers summed in rank order (what the RCCL
+ * all-reduce of the real run delivers), every handle's dense apply (divides by nranks) and GPU-local sparse update.  Item tables
+ * are reconciled by the caller (g4r_sync_export / g4r_sync_import).  For validating the N > 1 training semantics -- e.g.
+ * Recall@20 of 2 / 8 ranks against 1 (evaluation.py:62-75) -- on a one-GPU box; not a fast path. */
+int g4r_virtual_train_steps(g4r_model* const* ms, int32_t n, int64_t t0, int64_t n_steps);
 int g4r_comm_min_i64(g4r_model* m, int64_t* value);            /* in-place min over ranks */
 int g4r_comm_max_i64(g4r_model* m, int64_t* value);            /* in-place max over ranks: the common plan length (shorter plans are
                                                                   padded with M = 0 steps so that every rank issues the same all-reduces) */

@@ -37,6 +37,8 @@ OPTIONS = [
     ('-tk', '--time_key', dict(metavar='TK', default='Time', help='timestamp column (default Time)')),
     ('-pm', '--primary_metric', dict(metavar='METRIC', choices=['recall', 'mrr'], default='recall', help='metric reported on the PRIMARY METRIC line (default recall)')),
     ('-lpm', '--log_primary_metric', dict(action='store_true', help='print the PRIMARY METRIC line after every evaluation')),
+    (None, '--gpus', dict(metavar='N', type=int, default=1, help='train on N GPUs of this node (not in the reference): one process per GPU, sessions sharded over '
+                          'the ranks, dense GRU gradients all-reduced by RCCL every step, item rows GPU-local and reconciled per epoch; rank 0 saves / evaluates')),
 ]
 
 
@@ -98,6 +100,19 @@ def train(model_cls, opts):
     print('Creating GRU4Rec model')
     model = model_cls()
     model.set_params(**params)
+    rank, world = 0, 1
+    if opts.gpus > 1 or os.environ.get('G4R_FORCE_STAGED'):
+        # a rank of `run.py --gpus N` (spawned by main() below, or by torch.distributed.run): the communicator is created inside fit
+        from gru4rec_amd import launch
+        rank, world, local_rank = launch.layout()
+        if world != opts.gpus:
+            print('ERROR. WORLD_SIZE ({}) does not match --gpus ({})'.format(world, opts.gpus))
+            sys.exit(1)
+        if not hasattr(model, 'set_distributed'):
+            print('ERROR. The model class {} does not support --gpus'.format(model_cls.__module__))
+            sys.exit(1)
+        model.device = local_rank
+        model.set_distributed(rank, world, launch.unique_id(rank, world))
     print('Loading training data...')
     events = read_events(opts.path, opts, model_cls)
     if opts.sample_store_on_cpu:
@@ -106,6 +121,13 @@ def train(model_cls, opts):
     started = time.time()
     model.fit(events, sample_store=opts.sample_store_size, store_type='cpu' if opts.sample_store_on_cpu else 'gpu')
     print('Total training time: {:.2f}s'.format(time.time() - started))
+    if rank != 0:
+        # replicas are identical after the last reconciliation: rank 0 alone saves and evaluates
+        model.close()
+        sys.exit(0)
+    if world > 1:
+        from gru4rec_amd import launch
+        launch.cleanup(rank)
     if opts.save_model is not None:
         print('Saving trained model to: {}'.format(opts.save_model))
         model.savemodel(opts.save_model)
@@ -136,6 +158,10 @@ def main(argv=None):
         print('ERROR. Exactly one of the following parameters must be provided: --parameter_string, --parameter_file, --load_model')
         sys.exit(1)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    if opts.gpus > 1 and 'WORLD_SIZE' not in os.environ and not opts.load_model:
+        # become the launcher: N ranks of this very command line (rank 0 keeps stdout, the others' progress lines go to stderr)
+        from gru4rec_amd import launch
+        sys.exit(launch.spawn(__file__, sys.argv[1:] if argv is None else list(argv), opts.gpus))
     model_cls = importlib.import_module(opts.gru4rec_model).GRU4Rec
     if opts.load_model:
         print('Loading trained model from file: {}'.format(opts.path))

@@ -85,8 +85,9 @@ def test_reference_checkpoint_predicts_on_the_gpu():
 @pytest.mark.gpu
 @pytest.mark.parametrize('kw', [dict(momentum=0.2, dropout_p_hidden=0.2, dropout_p_embed=0.1),
                                 dict(adapt='adam', adapt_params=[0.9, 0.999], learning_rate=0.01, constrained_embedding=False, embedding=16),
-                                dict(constrained_embedding=False, layers=[24])],
-                         ids=['adagrad_momentum_dropout', 'adam_separate_embedding', 'onehot'])
+                                dict(constrained_embedding=False, layers=[24]),
+                                dict(train_random_order=True, momentum=0.1)],
+                         ids=['adagrad_momentum_dropout', 'adam_separate_embedding', 'onehot', 'random_session_order'])
 def test_resume_continues_bit_identically(tmp_path, kw):
     """SURVEY 8f rank 2, second half: 2 epochs == 1 epoch + savemodel(optimizer_state=True) + loadmodel + fit(resume=True).
     The sample store wraps around inside the epochs (its refill counter is part of the saved state), dropout masks are keyed by
@@ -113,11 +114,27 @@ def test_resume_continues_bit_identically(tmp_path, kw):
         np.testing.assert_array_equal(c.Wx[i], a.Wx[i])
         np.testing.assert_array_equal(c.Wh[i], a.Wh[i])
     assert c.loss_history == a.loss_history
+    if kw.get('train_random_order'):
+        # the session order of the resumed epoch is the uninterrupted run's second permutation (NumPy's global stream travels in
+        # the checkpoint), not a fresh draw
+        assert not np.array_equal(a.step_costs[0], a.step_costs[1][:len(a.step_costs[0])])
     # a checkpoint without optimizer state refuses to resume instead of silently restarting the accumulators
     b2 = GRU4Rec.loadmodel(f)
     b2.optimizer_state = None
     with pytest.raises(ValueError):
         b2.fit(data.copy(), sample_store=64 * 50, resume=True)
+    # ... and so does one whose optimizer state belongs to another configuration (the velocities would be dropped silently)
+    b3 = GRU4Rec.loadmodel(f)
+    b3.n_epochs = 2
+    b3.momentum = 0.0 if b3.momentum > 0 else 0.3
+    with pytest.raises(ValueError, match='momentum'):
+        b3.fit(data.copy(), sample_store=64 * 50, resume=True)
+    # the host sampler cannot resume, and says so before anything is built
+    b4 = GRU4Rec.loadmodel(f)
+    b4.n_epochs = 2
+    with pytest.raises(NotImplementedError):
+        b4.fit(data.copy(), sample_store=64 * 50, store_type='cpu', resume=True)
+    assert b4._model is None
 
 
 def test_checkpoint_with_optimizer_state_keeps_the_reference_layout(tmp_path):

@@ -2,7 +2,9 @@
 seconds: the item count changes neither a tile shape nor a code path) and on bench.py's own workload.
 
 Tolerances (fp32 HIP path vs the NumPy oracle; both fp32, different summation orders):
-  per-step cost   rtol 5e-4 + atol 5e-6        parameters / accumulators   atol 1e-4 + rtol 2e-3
+  per-step cost   rtol 5e-4 + atol 5e-6
+  parameters as updates (value - initial value) and accumulators against their own scale: test_gpu_parity.compare_params
+  (1e-3 |update| + 1e-4 max|update|; 2e-4 |acc| + 1e-5 max|acc|) -- a 1 % error of an accumulator or of a step fails.
 The long bench-plan run brackets its tolerance by the oracle's own fp32-vs-fp64 gap (stated in the test)."""
 import numpy as np
 import pytest
@@ -11,7 +13,7 @@ import bench
 from gru4rec_amd import _native
 from oracle.model import OracleGRU4Rec
 
-from test_gpu_parity import close, compare_params, make_pair, random_plan, report
+from test_gpu_parity import close, compare_params, make_pair, random_plan, report, snapshot
 
 pytestmark = pytest.mark.gpu
 
@@ -30,7 +32,7 @@ def _run(tag, I, B, ns, T, store_rows, dup=True, **kw):
     report('--- %s' % tag)
     close('loss curve', m.get_losses(0, T), np.array(want), atol=5e-6, rtol=5e-4, errs=errs)
     np.testing.assert_array_equal(m.get_sample_store(ns), o.ST)
-    compare_params(o, m, errs, tag, atol=1e-4, rtol=2e-3)
+    compare_params(o, m, errs, tag)
     m.close()
     assert not errs, errs
 
@@ -59,6 +61,9 @@ def test_cfg2_exact_shape_with_momentum():
          layers=(100,), learning_rate=0.1, bpreg=1.0, momentum=0.1)
 
 
+LOOSEN_240 = 40.0
+
+
 def _bench_pair(cfg, steps, store_rows):
     plan, support = bench.make_plan(cfg, steps, 0, 1)
     m = bench.create_model(cfg, support, 0, 1, 0, None, use_graph=True, sample_store=store_rows * cfg['n_sample'])
@@ -77,6 +82,7 @@ def _bench_pair(cfg, steps, store_rows):
         o.Wy = m.get_param('Wy', (cfg['n_items'], cfg['layers'][-1])).astype(dt)
         o.set_popularity(support)
         o.make_sample_store(store_rows * cfg['n_sample'])
+        o.init0 = snapshot(o)
         os_[dt] = o
     return plan, m, os_
 
@@ -108,6 +114,8 @@ def test_bench_plan_loss_curve_240_steps():
     assert (err <= tol).all(), (int(np.argmax(err / tol)), float((err / tol).max()))
     assert c32.max() < 0.75 and c32[-1] < c32[0]      # a sane curve: no blow-up inside bench.py's timed window
     errs = []
-    compare_params(os_[np.float32], m, errs, 'bench240', atol=2e-4, rtol=4e-3)
+    # 240 steps: the oracle's own fp32-vs-fp64 gap on Wy grows to ~1e-4 of an update over such a run (see the module docstring of
+    # test_gpu_e2e_recall.py); the bounds are widened accordingly
+    compare_params(os_[np.float32], m, errs, 'bench240', loosen=LOOSEN_240)
     m.close()
     assert not errs, errs

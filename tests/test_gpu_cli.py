@@ -18,8 +18,9 @@ PS = 'loss=bpr-max,final_act=elu-0.5,layers=48,batch_size=32,n_sample=256,constr
 LINE = re.compile(r'Recall@(\d+): ([0-9.]+) MRR@\d+: ([0-9.]+)')
 
 
-def run_cli(*args):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'run.py')] + list(args), capture_output=True, text=True, timeout=600)
+def run_cli(*args, env=None):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'run.py')] + list(args), capture_output=True, text=True, timeout=600,
+                       env=None if env is None else dict(os.environ, **env))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout
 
@@ -72,3 +73,29 @@ def test_host_sampler_flag(tsvs):
     assert 'WARNING! The sample store is set to be on the CPU' in out
     assert '(type=CPU)' in out
     assert metrics(out)[20][0] > 0.1
+
+
+def test_gpus_flag_rank_path_with_a_one_rank_communicator(tsvs):
+    """`run.py --gpus N` (not in the reference): every rank calls set_distributed, creates its communicator inside fit, takes part in
+    the per-chunk / per-epoch collectives and in the reconciliation of the item tables; rank 0 saves and evaluates.  A 1-GPU box runs
+    that path as ONE rank (G4R_FORCE_STAGED=1: staged dense gradients -> RCCL all-reduce captured in the step graph -> dense apply),
+    and the model it trains must evaluate like the fused single-GPU run (same math, other summation order in the dense apply)."""
+    train, test, d = tsvs
+    plain = metrics(run_cli(train, '-ps', PS, '-t', test, '-ss', str(256 * 64)))
+    out = run_cli(train, '-ps', PS, '-t', test, '-ss', str(256 * 64), '--gpus', '1', env={'G4R_FORCE_STAGED': '1', 'RANK': '0', 'WORLD_SIZE': '1', 'LOCAL_RANK': '0'})
+    got = metrics(out)
+    assert out.count('Epoch') == 2
+    assert abs(got[20][0] - plain[20][0]) <= 0.01 and abs(got[20][1] - plain[20][1]) <= 0.01
+
+
+def test_gpus_flag_spawns_its_ranks(tsvs):
+    """`run.py --gpus 2` on a box with one GPU: the launcher starts two ranks, rank 1 finds no second device and exits non-zero, the
+    launcher stops rank 0 (which would otherwise wait in RCCL forever) and returns a non-zero code -- no hang."""
+    from gru4rec_amd import _native
+    if _native.device_count() >= 2:
+        pytest.skip('needs a box with ONE GPU (on more, this is the real 2-GPU run)')
+    train, test, _ = tsvs
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'run.py'), train, '-ps', PS, '-ss', str(256 * 64), '--gpus', '2'],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert 'rank 1 exited' in r.stderr

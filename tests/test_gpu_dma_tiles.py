@@ -4,7 +4,8 @@ batch that is not a whole number of 64-row tiles, score rows that end inside a 6
 below B -- rows past M and the -1 items of finished sessions read the zero row instead of being masked.  Also the slab-count
 heuristic of k_score_bwd2 (tile count = whole rounds of CUs) at a shape where it picks something else than 17 slabs.
 
-Tolerances as in test_gpu_baseline_configs.py: per-step cost rtol 5e-4 + atol 5e-6, parameters atol 1e-4 + rtol 2e-3."""
+Tolerances as in test_gpu_baseline_configs.py: per-step cost rtol 5e-4 + atol 5e-6, parameters as updates / accumulators against
+their own scale (test_gpu_parity.compare_params)."""
 import numpy as np
 import pytest
 
@@ -27,7 +28,7 @@ def _run(tag, I, B, ns, T, store_rows, tail=True, **kw):
     errs = []
     report('--- %s (score_fwd on %s)' % (tag, 'gemm_tile3'))
     close('loss curve', m.get_losses(0, T), np.array(want), atol=5e-6, rtol=5e-4, errs=errs)
-    compare_params(o, m, errs, tag, atol=1e-4, rtol=2e-3, Mrows=int(plan['M'][-1]))
+    compare_params(o, m, errs, tag, Mrows=int(plan['M'][-1]))
     m.close()
     assert not errs, errs
 

@@ -1,0 +1,50 @@
+"""The parity suite must be able to FAIL.  Three deliberately wrong builds of the library (gru4rec_amd/build.py: build_mutants,
+-DG4R_MUTATE=k in g4r_device.cuh) are run through a handful of the parity tests in a child process with G4R_LIB pointing at the
+mutant; every one of those runs has to come back red, and the tensor it names has to be the one the mutation damages:
+
+  mutant 1  every per-occurrence sparse accumulator increment x 1.01   -> acc_Wy / acc_By (1 % of an accumulator of ~1e-7)
+  mutant 2  every sparse Adagrad step x 1.01                             -> dWy / dBy (1 % of a step)
+  mutant 3  every dense accumulator increment x 1.01                     -> acc_Wx / acc_Wh / ...
+
+(Round 2's `atol = 1e-4` on every tensor let an accumulator that is wrong by 100 x pass.)  The same selection runs green on the
+product library in the ordinary suite."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from gru4rec_amd import build as g4r_build
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SELECTION = ['tests/test_gpu_baseline_configs.py::test_cfg4_exact_shape',
+             'tests/test_gpu_parity.py::test_baseline_config2_shape_few_steps',
+             'tests/test_gpu_golden.py::test_product_reproduces_reference_run[bprmax_constrained]']
+EXPECT = {1: ('acc_Wy', 'acc_By'), 2: ('dWy', 'dBy'), 3: ('acc_Wx', 'acc_Wh', 'acc_Wrz', 'acc_Bh')}
+
+
+@pytest.fixture(scope='module')
+def mutants():
+    paths = g4r_build.build_mutants()
+    assert all(os.path.exists(p) for p in paths)
+    return dict(zip(sorted(g4r_build.MUTANTS), paths))
+
+
+@pytest.mark.parametrize('k', sorted(g4r_build.MUTANTS))
+def test_mutant_turns_the_parity_tests_red(mutants, k):
+    env = dict(os.environ, G4R_LIB=mutants[k])
+    for sel in SELECTION:
+        r = subprocess.run([sys.executable, '-m', 'pytest', sel, '-x', '-q', '-p', 'no:cacheprovider'], cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=900)
+        out = r.stdout + r.stderr
+        assert r.returncode == 1, 'mutant %d (%s) passed %s:\n%s' % (k, g4r_build.MUTANTS[k], sel, out[-3000:])
+        if 'golden' not in sel:
+            assert any(name in out for name in EXPECT[k]), 'mutant %d failed %s, but not on %s:\n%s' % (k, sel, EXPECT[k], out[-3000:])
+
+
+def test_product_library_is_not_a_mutant():
+    from gru4rec_amd import _native
+    assert 'G4R_LIB' not in os.environ or '_variants' not in os.environ['G4R_LIB']
+    assert '_variants' not in _native.LIB_PATH

@@ -2,7 +2,13 @@
 
 Floating point tolerance (fp32 path vs fp32 oracle; both accumulate in fp32 but in different orders):
   per-step cost            rtol 2e-4 (+ atol 2e-6)
-  intermediates / params   atol 3e-5 + rtol 3e-4 unless stated
+  intermediates            atol 3e-5 + rtol 3e-4 unless stated
+  parameters               compared as UPDATES (value - initial value): |err| <= 1e-3 |update| + 1e-4 max|update| of the tensor
+  optimizer accumulators   |err| <= 2e-4 |acc| + 1e-5 max|acc| of the tensor (a bias accumulator is the square of a column sum of
+                           512 signed terms: cancellation leaves 1e-4 relative on its smallest entries, measured at cfg4)
+(bounds relative to the tensor's own scale: an accumulator of 1e-7 that is off by 1 %, or an update that is off by 1 % of a
+step, fails -- tests/test_gpu_mutation.py builds such libraries and expects red; runs of dozens of steps widen the bounds by a
+stated factor, `loosen`, because the training dynamics amplify rounding differences.)
 Integer work (sample store, plan, occurrence lists) is bit-exact.
 """
 import os
@@ -43,6 +49,32 @@ def close(name, got, want, atol=3e-5, rtol=3e-4, errs=None):
     return not bad
 
 
+def close_rel(name, got, want, rtol, atol_frac, errs=None, floor=0.0):
+    """|got - want| <= rtol |want| + atol_frac max|want| (+ floor): a bound relative to the tensor's own scale."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    err = np.abs(got - want)
+    scale = float(np.abs(want).max()) if want.size else 0.0
+    tol = rtol * np.abs(want) + atol_frac * scale + floor
+    worst = float((err / np.maximum(tol, 1e-300)).max()) if err.size else 0.0
+    bad = not np.isfinite(got).all() or worst > 1.0
+    report('%-28s max_abs_err %.3e  max|want| %.3e  worst/tol %.3f %s' % (
+        name, float(err.max()) if err.size else 0.0, scale, worst, 'FAIL' if bad else 'ok'))
+    if bad and errs is not None:
+        errs.append(name)
+    return not bad
+
+
+def snapshot(o):
+    """Copies of every trainable array of the oracle (the initial values the updates are measured from)."""
+    d = {'Wy': o.Wy.copy(), 'By': o.By.copy()}
+    if o.E is not None:
+        d['E'] = o.E.copy()
+    for n in ('Wx', 'Wh', 'Wrz', 'Bh'):
+        d[n] = [a.copy() for a in getattr(o, n)]
+    return d
+
+
 def make_pair(I, B, ns, store_rows, seed=3, **kw):
     """An oracle and a device model with identical weights / popularity / sample store."""
     use_graph = kw.pop('use_graph', 0)
@@ -80,6 +112,7 @@ def make_pair(I, B, ns, store_rows, seed=3, **kw):
     if o.E is not None:
         m.set_param('E', o.E)
     m.set_popularity(o.P, o.lq_tgt if o.logq else None, o.lq_smp if o.logq else None)
+    o.init0 = snapshot(o)
     return o, m
 
 
@@ -95,25 +128,39 @@ def random_plan(I, B, T, seed, tail=False):
                 compact_steps=np.zeros(0, dtype=np.int64), compact_maps=np.zeros((0, B), dtype=np.int32))
 
 
-def compare_params(o, m, errs, tag, atol=3e-5, rtol=3e-4, Mrows=None):
+def compare_params(o, m, errs, tag, Mrows=None, loosen=1.0, init=None):
+    """Parameters as updates against their initial values (o.init0, taken by make_pair), accumulators / velocities against their
+    own scale.  loosen widens every bound by that factor (runs of many steps)."""
     I = o.n_items
     Mrows = o.batch_size if Mrows is None else Mrows
+    init = init if init is not None else o.init0
+    PR, PA, AR, AA = 1e-3 * loosen, 1e-4 * loosen, 2e-4 * loosen, 1e-5 * loosen
+
+    def upd(name, got, want, w0):
+        w0 = np.asarray(w0, dtype=np.float64)
+        # floor: a few ulps of the parameter itself (the update is the difference of two fp32 values)
+        floor = 4.0 * float(np.spacing(np.float32(max(np.abs(np.asarray(want)).max(), 1e-30))))
+        close_rel(name, np.asarray(got, dtype=np.float64) - w0, np.asarray(want, dtype=np.float64) - w0, PR, PA, errs, floor)
+
     for i, D in enumerate(o.layers):
         n_in = o.Wx[i].shape[0]
-        close('%s Wx%d' % (tag, i), m.get_param('Wx', (n_in, 3 * D), i), o.Wx[i], atol, rtol, errs)
-        close('%s Wh%d' % (tag, i), m.get_param('Wh', (D, D), i), o.Wh[i], atol, rtol, errs)
-        close('%s Wrz%d' % (tag, i), m.get_param('Wrz', (D, 2 * D), i), o.Wrz[i], atol, rtol, errs)
-        close('%s Bh%d' % (tag, i), m.get_param('Bh', (3 * D,), i), o.Bh[i], atol, rtol, errs)
-        close('%s H%d' % (tag, i), m.get_param('H', (o.batch_size, D), i)[:Mrows], o.H[i][:Mrows], atol, rtol, errs)
-        close('%s acc_Wx%d' % (tag, i), m.get_param('acc_Wx', (n_in, 3 * D), i), o.acc['Wx'][i], atol, rtol * 3, errs)
-    close('%s Wy' % tag, m.get_param('Wy', (I, o.layers[-1])), o.Wy, atol, rtol, errs)
-    close('%s By' % tag, m.get_param('By', (I,)), o.By, atol, rtol, errs)
-    close('%s acc_Wy' % tag, m.get_param('acc_Wy', (I, o.layers[-1])), o.acc['Wy'], atol, rtol * 3, errs)
-    close('%s acc_By' % tag, m.get_param('acc_By', (I,)), o.acc['By'], atol, rtol * 3, errs)
+        upd('%s dWx%d' % (tag, i), m.get_param('Wx', (n_in, 3 * D), i), o.Wx[i], init['Wx'][i])
+        upd('%s dWh%d' % (tag, i), m.get_param('Wh', (D, D), i), o.Wh[i], init['Wh'][i])
+        upd('%s dWrz%d' % (tag, i), m.get_param('Wrz', (D, 2 * D), i), o.Wrz[i], init['Wrz'][i])
+        upd('%s dBh%d' % (tag, i), m.get_param('Bh', (3 * D,), i), o.Bh[i], init['Bh'][i])
+        close_rel('%s H%d' % (tag, i), m.get_param('H', (o.batch_size, D), i)[:Mrows], o.H[i][:Mrows], 3e-4 * loosen, 1e-4 * loosen, errs)
+        for n in ('Wx', 'Wh', 'Wrz', 'Bh'):
+            shape = {'Wx': (n_in, 3 * D), 'Wh': (D, D), 'Wrz': (D, 2 * D), 'Bh': (3 * D,)}[n]
+            close_rel('%s acc_%s%d' % (tag, n, i), m.get_param('acc_' + n, shape, i), o.acc[n][i], AR, AA, errs)
+    upd('%s dWy' % tag, m.get_param('Wy', (I, o.layers[-1])), o.Wy, init['Wy'])
+    upd('%s dBy' % tag, m.get_param('By', (I,)), o.By, init['By'])
+    close_rel('%s acc_Wy' % tag, m.get_param('acc_Wy', (I, o.layers[-1])), o.acc['Wy'], AR, AA, errs)
+    close_rel('%s acc_By' % tag, m.get_param('acc_By', (I,)), o.acc['By'], AR, AA, errs)
     if o.E is not None:
-        close('%s E' % tag, m.get_param('E', (I, o.embedding)), o.E, atol, rtol, errs)
+        upd('%s dE' % tag, m.get_param('E', (I, o.embedding)), o.E, init['E'])
+        close_rel('%s acc_E' % tag, m.get_param('acc_E', (I, o.embedding)), o.acc['E'], AR, AA, errs)
     if o.momentum > 0:
-        close('%s vel_Wy' % tag, m.get_param('vel_Wy', (I, o.layers[-1])), o.vel['Wy'], atol, rtol, errs)
+        close_rel('%s vel_Wy' % tag, m.get_param('vel_Wy', (I, o.layers[-1])), o.vel['Wy'], PR, PA, errs)
 
 
 def test_mfma_layout_selftest():
@@ -125,6 +172,8 @@ def test_sample_store_bit_exact():
     st = m.get_sample_store(64)
     np.testing.assert_array_equal(st, o.ST)
 
+
+LOOSEN_60 = 20.0      # 60 steps on an 80-item catalogue: every row is rewritten dozens of times, rounding differences compound
 
 CASES = {
     'bprmax_elu': dict(loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(12,), bpreg=0.7),
@@ -230,7 +279,7 @@ def test_loss_curve_and_weights_after_many_steps(name):
     report('--- curve %s' % name)
     close('loss curve', got, np.array(want), atol=5e-6, rtol=5e-4, errs=errs)
     np.testing.assert_array_equal(m.get_sample_store(ns), o.ST)
-    compare_params(o, m, errs, 'p60', atol=1e-4, rtol=2e-3, Mrows=int(plan['M'][-1]))
+    compare_params(o, m, errs, 'p60', Mrows=int(plan['M'][-1]), loosen=LOOSEN_60)
     assert not errs, errs
 
 
@@ -361,7 +410,7 @@ def test_baseline_config2_shape_few_steps():
     errs = []
     report('--- config #2 shape')
     close('loss curve', m.get_losses(0, T), np.array(want), atol=5e-6, rtol=5e-4, errs=errs)
-    compare_params(o, m, errs, 'cfg2', atol=1e-4, rtol=2e-3)
+    compare_params(o, m, errs, 'cfg2')
     assert not errs, errs
 
 
@@ -377,7 +426,7 @@ def test_wide_layer_and_big_batch():
     errs = []
     report('--- wide layer')
     close('loss curve', m.get_losses(0, T), np.array(want), atol=5e-6, rtol=5e-4, errs=errs)
-    compare_params(o, m, errs, 'wide', atol=1e-4, rtol=2e-3)
+    compare_params(o, m, errs, 'wide')
     assert not errs, errs
 
 
@@ -394,7 +443,7 @@ def test_many_negatives_big_batch():
     errs = []
     report('--- many negatives')
     close('loss curve', m.get_losses(0, T), np.array(want), atol=5e-6, rtol=5e-4, errs=errs)
-    compare_params(o, m, errs, 'manyneg', atol=1e-4, rtol=2e-3)
+    compare_params(o, m, errs, 'manyneg')
     assert not errs, errs
 
 
@@ -412,7 +461,7 @@ def test_more_split_k_slabs_than_one_batch():
     errs = []
     report('--- 13 slabs')
     close('loss curve', m.get_losses(0, T), np.array(want), atol=5e-6, rtol=5e-4, errs=errs)
-    compare_params(o, m, errs, 'slabs13', atol=1e-4, rtol=2e-3)
+    compare_params(o, m, errs, 'slabs13')
     assert not errs, errs
 
 
