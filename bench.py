@@ -217,7 +217,7 @@ def main():
     # per-kernel durations behind the timed region: every rank runs those steps (the all-reduce is collective), rank 0 reports
     n_profile = args.profile_steps
     n_long = args.long_steps if (0 < args.steps < args.long_steps) else 0
-    total_steps = args.warmup + args.steps + n_long + n_profile + 8
+    total_steps = args.warmup + args.steps + n_long + n_profile + 8 + 64
     plan, support = make_plan(cfg, total_steps, rank, world)
     assert plan['T'] >= total_steps, 'synthetic plan too short: %d < %d' % (plan['T'], total_steps)
     assert (plan['M'][:total_steps] == cfg['batch_size']).all()
@@ -287,6 +287,36 @@ def main():
         m.train_steps(args.warmup + args.steps + n_long, n_profile)
         m.profile(False)
         kt = m.kernel_times()
+    staged = world > 1 or bool(os.environ.get('G4R_FORCE_STAGED'))
+    reconcile = None
+    if staged:
+        # The timed region is the training step north_star defines for N > 1 (dense-gradient all-reduce every step, item rows
+        # GPU-local).  GRU4Rec.fit also reconciles the item tables every `sync_every` steps (without it the
+        # replicas drift apart); that cost is measured here, separately, over the rows the next `sync_every` steps touch, and
+        # reported next to `value` -- never inside it, never hidden.
+        from gru4rec_amd.gru4rec import GRU4Rec
+        K = GRU4Rec().sync_every
+        try:
+            t_sync = []
+            base_t = args.warmup + args.steps + n_long + n_profile
+            spare = total_steps - base_t - 1
+            reps = max(0, min(3, spare // max(K, 1)))
+            m.comm_sync_sparse()                      # rows of the whole run so far: not timed
+            for r in range(reps):
+                m.train_steps(base_t + r * K, K)
+                barrier()
+                t2 = time.perf_counter()
+                m.comm_sync_sparse()
+                t_sync.append(time.perf_counter() - t2)
+            if t_sync:
+                ms = 1000.0 * (launch.max_over_ranks_us(m, min(t_sync)) if world > 1 else min(t_sync))
+                step_ms = 1000.0 * dt / args.steps
+                reconcile = {'sync_every': K, 'ms_per_reconciliation': ms, 'ms_per_step_amortised': ms / K,
+                             'value_with_reconciliation': args.steps * world / (dt + args.steps * ms / K / 1000.0),
+                             'note': 'g4r_comm_sync_sparse over the item rows %d steps touch (best of %d, max over ranks); fit() runs one every %d '
+                                     'steps: step %.4f ms + %.4f ms amortised' % (K, len(t_sync), K, step_ms, ms / K)}
+        except Exception as e:      # the reconciliation must not take the step measurement down with it
+            reconcile = {'error': str(e)}
     if world > 1:
         def us(name):
             return 1000.0 * kt[name][0] / max(kt[name][1], 1) if name in kt else None
@@ -295,10 +325,12 @@ def main():
             'rccl_allreduce_us': us('rccl_allreduce'), 'k_dense_apply_us': us('k_dense_apply'),
             'dense_gradient_bytes': 4 * int(m.get_debug('dense_count', (1,))[0]),
             'step_graph_holds_allreduce': bool(m.get_debug('graph_mode', (1,))[0] == 1.0),
-            'kernel_us_rank0': {k: 1000.0 * v[0] / max(v[1], 1) for k, v in kt.items()},
+            'kernel_us_rank0': {k: 1000.0 * v[0] / max(v[1], 1) for k, v in kt.items()}, 'reconciliation': reconcile,
             'note': 'rank_ms_per_step: every rank\'s own wall time of the timed region / steps (value uses the max); all-reduce / dense '
                     'apply: HIP events around the eager launches of %d profile steps on rank 0 (every step synchronises there, so the '
                     'all-reduce time includes the skew between ranks)' % n_profile}
+    if world == 1 and reconcile is not None:
+        out['reconciliation_one_rank_communicator'] = reconcile
     if rank == 0 and world == 1 and n_profile > 0:
         alg = algorithmic_cost(cfg)
         kern = {}

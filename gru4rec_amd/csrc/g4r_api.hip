@@ -80,6 +80,11 @@ struct g4r_model {
     int dt = 32;                                 // edge of the dense-gradient tiles (64 for wide layers)
     int ntiles = 0, nblkA = 0, nblkB = 0, ndtA = 0, ndtB = 0, nrtB = 0, nblk_occ = 0;
     size_t smem_score = 0, smem_loss = 0, smem_sparse = 0;
+    // persistent stream-K scoring forward (k_score_fwd_sk): workers, tile grid, column tiles a worker may touch, scratch
+    int sk_W = 0, sk_nrt = 0, sk_nct = 0, sk_maxct = 0;
+    float* sk_ws = nullptr;
+    unsigned* sk_flags = nullptr;
+    size_t smem_sk = 0;
     bool loss_long = false;      // k_loss_rows<true>: score rows too long for two LDS copies
     float* d_tmpH = nullptr;
     // graph
@@ -111,9 +116,11 @@ struct g4r_model {
     float* d_vsum = nullptr;                     // scratch of that sum (first member of the group)
     // reconciliation of the GPU-local item tables (g4r_sync_kernels.cuh): per table group (0: Wy / By rows, 1: E rows) the
     // planes (current values, common base, row width) and scratch
-    struct SyncPlane { float* cur; float* base; int W; };
+    struct SyncPlane { float* cur; float* base; int W; int kind; };      // kind: 0 parameter / velocity, 1 optimizer statistic
     std::vector<SyncPlane> planes[2];
+    int sync_rule[2] = {G4R_SYNC_MEAN, G4R_SYNC_SUM};      // combine rule of the parameter planes / of the statistic planes
     unsigned char* d_touched = nullptr;
+    unsigned char* d_rowcnt = nullptr;           // [n_items] scratch: number of parts that hold a row (MEAN rule)
     bool sync_on = false;
 };
 
@@ -356,6 +363,23 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     }
     if (ns > 0) DA(m->d_ST, (size_t)gl * ns);
     d.ST = m->d_ST;
+    if (score_fwd_dma(d) && env_int("G4R_STREAMK", 1)) {
+        // stream-K scoring forward: two workers per CU (or one per tile when there are fewer tiles), every run >= one tile's K stages
+        const int nrt = cdiv(B, 64), nct = cdiv(d.ldSc, 64), KS = d.Dtop / 32, ntiles = nrt * nct;
+        const int W = std::min(env_int("G4R_SK_W", 2 * m->n_cu), ntiles);
+        const long long U = (long long)ntiles * KS;
+        int maxct = 1;
+        for (int w = 0; w < W; ++w) {
+            const long long u0 = U * w / W, u1 = U * (w + 1) / W;
+            maxct = std::max(maxct, (int)(((u1 - 1) / KS) / nrt - (u0 / KS) / nrt + 1));
+        }
+        m->smem_sk = (size_t)SK_NST * Tile3Cfg<SK_NST, 32>::STAGE * sizeof(float) + (size_t)maxct * 64 * (sizeof(int) + sizeof(float));
+        if (W >= 1 && U / W >= KS && m->smem_sk <= (size_t)(78 * 1024)) {
+            m->sk_W = W; m->sk_nrt = nrt; m->sk_nct = nct; m->sk_maxct = maxct;
+            DA(m->sk_ws, (size_t)(W + 1) * 4 * 256 * 4);
+            DA(m->sk_flags, (size_t)W + 1);
+        }
+    }
     // dense-gradient tile table
     {
         std::vector<DenseTile> tiles;
@@ -406,6 +430,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_k64, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_t2, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_t3, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_sk<SK_NST>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd_n, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_fwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -427,8 +452,9 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_store, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<false, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<true, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel"); }
     { float* z = nullptr; if (dalloc(m, &z, ZROW_FLOATS)) { g4r_destroy(m); return -1; } d.zrow = z; }
     if (getenv("G4R_CLK")) {
@@ -737,14 +763,16 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         end();
     }
     begin(KN_SCORE_FWD);
-    if (score_fwd_dma(d)) LK(k_score_fwd_t3, dim3(cdiv(d.ldSc, 64), cdiv(B, 64)), dim3(GT_NTH), SMEM_SF3, s, dmp, stp);
+    if (m->sk_W > 0) LK(k_score_fwd_sk<SK_NST>, dim3(m->sk_W), dim3(GT_NTH), m->smem_sk, s, dmp, stp, m->sk_ws, m->sk_flags, m->sk_W, m->sk_nrt, m->sk_nct, m->sk_maxct);
+    else if (score_fwd_dma(d)) LK(k_score_fwd_t3, dim3(cdiv(d.ldSc, 64), cdiv(B, 64)), dim3(GT_NTH), SMEM_SF3, s, dmp, stp);
     else if (wide_scores(d) && score_tile2() && d.Dtop % T2_BK == 0) LK(k_score_fwd_t2, dim3(cdiv(d.ldSc, 64), cdiv(B, 64)), dim3(GT_NTH), SMEM_SF2, s, dmp, stp);
     else if (wide_scores(d)) LK(k_score_fwd_k64, dim3(cdiv(d.ldSc, SFW_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF64, s, dmp, stp);
     else LK(k_score_fwd_k128, dim3(cdiv(d.ldSc, GT_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF, s, dmp, stp);
     end();
     begin(KN_LOSS);
-    if (m->loss_long) LK(k_loss_rows<true>, dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
-    else LK(k_loss_rows<false>, dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
+    if (m->loss_long) LK((k_loss_rows<true, 10>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
+    else if (d.ldSc > 4096) LK((k_loss_rows<false, 10>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
+    else LK((k_loss_rows<false, 4>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
     end();
     begin(KN_SCORE_BWD);
     if (score_bwd2(d)) {
@@ -1440,19 +1468,23 @@ int g4r_sync_enable(g4r_model* m) {
     DevModel& d = m->dm;
     const size_t I = d.n_items;
     const int tables = d.E ? 2 : 1;
-    auto add = [&](int g, float* cur, int W) -> int {
+    auto add = [&](int g, float* cur, int W, int kind) -> int {
         if (!cur) return 0;
         float* base = nullptr;
         if (dalloc(m, &base, I * (size_t)W, false)) return -1;
         if (hipMemcpyAsync(base, cur, I * (size_t)W * sizeof(float), hipMemcpyDeviceToDevice, m->stream) != hipSuccess) return fail("base snapshot");
-        m->planes[g].push_back({cur, base, W});
+        m->planes[g].push_back({cur, base, W, kind});
         return 0;
     };
-    if (add(0, d.Wy, d.Dtop) || add(0, d.accWy, d.Dtop) || add(0, d.velWy, d.Dtop) || add(0, d.acc2Wy, d.Dtop) || add(0, d.cntWy, d.Dtop) ||
-        add(0, d.By, 1) || add(0, d.accBy, 1) || add(0, d.velBy, 1) || add(0, d.acc2By, 1) || add(0, d.cntBy, 1))
+    if (add(0, d.Wy, d.Dtop, 0) || add(0, d.accWy, d.Dtop, 1) || add(0, d.velWy, d.Dtop, 0) || add(0, d.acc2Wy, d.Dtop, 1) || add(0, d.cntWy, d.Dtop, 1) ||
+        add(0, d.By, 1, 0) || add(0, d.accBy, 1, 1) || add(0, d.velBy, 1, 0) || add(0, d.acc2By, 1, 1) || add(0, d.cntBy, 1, 1))
         return -1;
-    if (d.E && (add(1, d.E, d.Ein) || add(1, d.accE, d.Ein) || add(1, d.velE, d.Ein) || add(1, d.acc2E, d.Ein) || add(1, d.cntE, d.Ein))) return -1;
-    if (dalloc(m, &m->d_touched, (size_t)tables * I, true)) return -1;
+    if (d.E && (add(1, d.E, d.Ein, 0) || add(1, d.accE, d.Ein, 1) || add(1, d.velE, d.Ein, 0) || add(1, d.acc2E, d.Ein, 1) || add(1, d.cntE, d.Ein, 1))) return -1;
+    if (dalloc(m, &m->d_touched, (size_t)tables * I, true) || dalloc(m, &m->d_rowcnt, I, true)) return -1;
+    if (const char* e = getenv("G4R_SYNC_RULE")) {      // "<param><stat>", s = sum, m = mean: experiments (tools/virtual_ranks_study.py)
+        if (e[0]) m->sync_rule[0] = e[0] == 's' ? G4R_SYNC_SUM : G4R_SYNC_MEAN;
+        if (e[0] && e[1]) m->sync_rule[1] = e[1] == 's' ? G4R_SYNC_SUM : G4R_SYNC_MEAN;
+    }
     d.touched = m->d_touched;
     m->sync_on = true;
     return sync_dm(m);
@@ -1508,14 +1540,26 @@ int64_t g4r_sync_export(g4r_model* m, int32_t group, int32_t* ids_out, float* ro
 }
 // rows of this rank in [lo, hi) of its own sorted list `d_loc` go back to the base, then every part (rank order) is added and
 // the rows of every part become the new base.  All pointers are device pointers; part q has cnt[q] rows.
+// rowcnt (sync_count below) holds, for the rows of these parts, the number of parts each row occurs in
 static void sync_apply(g4r_model* m, const g4r_model::SyncPlane& pl, const int* d_loc, long long n_loc, int nparts,
                        const int* const* d_ids, const long long* cnt, const float* const* d_delta) {
     hipStream_t s = m->stream;
+    const unsigned char* rc = (m->sync_rule[pl.kind] == G4R_SYNC_MEAN) ? m->d_rowcnt : nullptr;
     if (n_loc > 0) hipLaunchKernelGGL(k_sync_reset, dim3(nblk256(n_loc * pl.W)), dim3(256), 0, s, pl.cur, (const float*)pl.base, pl.W, d_loc, n_loc);
     for (int q = 0; q < nparts; ++q)
-        if (cnt[q] > 0) hipLaunchKernelGGL(k_sync_add, dim3(nblk256(cnt[q] * pl.W)), dim3(256), 0, s, pl.cur, pl.W, d_ids[q], cnt[q], d_delta[q]);
+        if (cnt[q] > 0) hipLaunchKernelGGL(k_sync_add, dim3(nblk256(cnt[q] * pl.W)), dim3(256), 0, s, pl.cur, pl.W, d_ids[q], cnt[q], d_delta[q], rc);
     for (int q = 0; q < nparts; ++q)
         if (cnt[q] > 0) hipLaunchKernelGGL(k_sync_rebase, dim3(nblk256(cnt[q] * pl.W)), dim3(256), 0, s, (const float*)pl.cur, pl.base, pl.W, d_ids[q], cnt[q]);
+}
+// rows-per-part counts of a set of parts (clear = 1: back to zero, after every plane has been applied)
+static void sync_count(g4r_model* m, int nparts, const int* const* d_ids, const long long* cnt, int clear) {
+    for (int q = 0; q < nparts; ++q)
+        if (cnt[q] > 0) hipLaunchKernelGGL(k_sync_count, dim3(nblk256(cnt[q])), dim3(256), 0, m->stream, m->d_rowcnt, d_ids[q], cnt[q], clear);
+}
+int g4r_sync_set_rule(g4r_model* m, int32_t param_rule, int32_t stat_rule) {
+    if (!m || param_rule < 0 || param_rule > G4R_SYNC_MEAN || stat_rule < 0 || stat_rule > G4R_SYNC_MEAN) return fail("bad argument");
+    m->sync_rule[0] = param_rule; m->sync_rule[1] = stat_rule;
+    return 0;
 }
 // test hook: apply the parts of all ranks (in rank order; this rank's own part included) as g4r_comm_sync_sparse does after its
 // all-gather.  ids[q]: counts[q] sorted item ids; rows[q]: g4r_sync_export layout.
@@ -1549,11 +1593,13 @@ int g4r_sync_import(g4r_model* m, int32_t group, int32_t nparts, const int64_t* 
     }
     std::vector<const float*> dl(nparts);
     std::vector<size_t> off(nparts, 0);
+    sync_count(m, nparts, (const int* const*)d_ids.data(), cnt.data(), 0);
     for (auto& pl : m->planes[group]) {
         for (int q = 0; q < nparts; ++q) dl[q] = d_rows[q] ? d_rows[q] + off[q] : nullptr;
         sync_apply(m, pl, d_loc, (long long)loc.size(), nparts, (const int* const*)d_ids.data(), cnt.data(), dl.data());
         for (int q = 0; q < nparts; ++q) off[q] += (size_t)std::max<long long>(cnt[q], 0) * pl.W;
     }
+    sync_count(m, nparts, (const int* const*)d_ids.data(), cnt.data(), 1);
     (void)hipMemsetAsync(m->d_touched + (size_t)group * I, 0, I, m->stream);
     hipError_t e = hipStreamSynchronize(m->stream);
     cleanup();
@@ -1635,6 +1681,7 @@ int g4r_comm_sync_sparse(g4r_model* m) {
                 pid[q] = d_all + (size_t)q * maxn + lo[q];
             }
             if (cmax > 0) {
+                sync_count(m, nr, pid.data(), c.data(), 0);
                 for (auto& pl : m->planes[group]) {
                     if (c[me] > 0)
                         hipLaunchKernelGGL(k_sync_pack, dim3(nblk256(c[me] * pl.W)), dim3(256), 0, s, (const float*)pl.cur, (const float*)pl.base, pl.W,
@@ -1643,6 +1690,7 @@ int g4r_comm_sync_sparse(g4r_model* m) {
                     for (int q = 0; q < nr; ++q) pdl[q] = d_recv + (size_t)q * cmax * pl.W;
                     sync_apply(m, pl, pid[me], c[me], nr, pid.data(), c.data(), pdl.data());
                 }
+                sync_count(m, nr, pid.data(), c.data(), 1);
                 if (hipStreamSynchronize(s) != hipSuccess) ok = false;
             }
             for (int q = 0; q < nr; ++q) lo[q] = hi[q];
@@ -1690,6 +1738,7 @@ int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
     else if (s == "ntiles") { if (count < 1) return fail("count"); host[0] = (float)m->ntiles; return 0; }
     else if (s == "ldSc") { if (count < 1) return fail("count"); host[0] = (float)d.ldSc; return 0; }
     else if (s == "ksplit") { if (count < 1) return fail("count"); host[0] = (float)d.ksplit; return 0; }
+    else if (s == "streamk_workers") { if (count < 1) return fail("count"); host[0] = (float)m->sk_W; return 0; }
     else if (s == "dense_count") { if (count < 1) return fail("count"); host[0] = (float)d.dense_count; return 0; }
     else if (s == "occ_score_tile") {      // resident workgroups per CU the runtime reports for the gemm_tile2 scoring kernel
         if (count < 1) return fail("count");

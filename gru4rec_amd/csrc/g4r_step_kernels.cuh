@@ -625,6 +625,205 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// The scoring GEMM as a PERSISTENT stream-K launch (long score rows: B = 512, N = 8704, D = 256 is 1088 tiles of 64 x 64 x 256).
+// One workgroup per CU slot -- exactly two per CU: 64 KiB of LDS each, grid = 2 x #CU, so every CU holds two and all of them are
+// resident from start to end -- and the work, cut into units of (tile, one 32-deep K stage), is dealt out in equal contiguous
+// runs: worker w owns units [U w / W, U (w + 1) / W) in column-tile-major order.  Every CU therefore gets the same number of
+// MFMAs (the plain tile launch gave 4 or 5 tiles of a 4.25 average to a CU and ran its last round at a third of the chip's
+// occupancy: 31 us against 14.5 us of MFMA time), the LDS-DMA ring runs THROUGH tile boundaries (the first stages of the next
+// tile are in flight while this one finishes and stores: no per-tile start-up bubble), and the gathered rows of a column tile are
+// shared by the consecutive row tiles of one worker / one XCD.
+// A run starts and ends inside a tile.  The tile's HEAD (its first K stages) is computed by the worker that reaches it LAST in
+// its own run, its TAIL by the next worker FIRST in its run -- so the tail's partial sum is in memory ~15 us before the head's
+// owner needs it: the owner adds it (fixed order: head + tail, bit-reproducible) and stores the tile.  Partials travel as
+// write-through 16-byte stores and L1-bypassing loads (`sc1` on both sides) behind a drained, step-stamped flag
+// (MI355X_MICROARCH.md, inter-workgroup visibility: form R1); the owner's poll is bounded and reports through nan_flag instead
+// of hanging should the co-residency assumption ever fail.
+#define SK_NST 4
+__device__ __forceinline__ void st4_sc1(GAS float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ f32x4 ld4_sc1(const GAS float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int NST>
+__global__ __launch_bounds__(256, 2) void k_score_fwd_sk(const DevModel* __restrict__ mp, StepState* st, float* ws_, unsigned* flags_, int W,
+                                                         int nrt, int nct, int maxct) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevModel& m = *mp;
+    constexpr int BKS = 32, STAGE = 2 * 64 * BKS, QPR = BKS / 4, RPP = 64 / QPR, NP = 64 / RPP / 4, FSH = 1, FMASK = QPR - 1, LPS = 2 * NP;
+    constexpr unsigned BOFF = 64 * BKS * 4;
+    GAS float* ws = (GAS float*)ws_;
+    GAS unsigned* flags = (GAS unsigned*)flags_;
+    int* sItem = reinterpret_cast<int*>(smem + NST * STAGE);      // [maxct][64] items of the column tiles this worker touches
+    float* sBias = reinterpret_cast<float*>(sItem + maxct * 64);  // [maxct][64] bias - logQ correction of those columns
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1, l32 = lane & 31, lh = lane >> 5;
+    const StepCtx c = load_ctx(st);
+    const int M = c.M, B = m.B, D = m.Dtop, N = m.N, ld = m.ldSc;
+    const int KS = D / BKS;
+    const long long U = (long long)nrt * nct * KS;
+    const int w = G4R_XCD_TILE(blockIdx.x, W);
+    const int u0 = (int)(U * w / W), u1 = (int)(U * (w + 1) / W), S = u1 - u0;
+    if (S <= 0) return;
+    const int t0 = u0 / KS, ks0 = u0 - t0 * KS, tl = (u1 - 1) / KS;
+    const int ct0 = t0 / nrt, ctl = tl / nrt;
+    const unsigned stamp = (unsigned)(c.g + 1);
+    {   // items / biases of the worker's column tiles; the worker whose run holds unit (column tile, row tile 0, stage 0) publishes
+        // the column -> item map and the occurrence entries of that column tile (as the tile launch's row-tile-0 workgroups do)
+        const GAS float *By = m.By, *lq_tgt = m.lq_tgt, *lq_smp = m.lq_smp;
+        const float logq = m.logq;
+        for (int i = tid; i < (ctl - ct0 + 1) * 64; i += 256) {
+            const int ct = ct0 + (i >> 6), n = ct * 64 + (i & 63);
+            const int item = (n < ld) ? m.cur_col[min(n, ld - 1)] : -1;
+            const bool ok = item >= 0 && n < N;
+            float x = ldf_at(By, max(item, 0), ok);
+            const bool lq = ok && logq != 0.f;
+            x -= logq * ldf_at(lq ? (n < B ? lq_tgt : lq_smp) : By, max(item, 0), lq);
+            sItem[i] = item;
+            sBias[i] = ok ? x : 0.f;
+            const long long uf = (long long)ct * nrt * KS;
+            if (uf >= u0 && uf < u1 && n < ld) {
+                m.col_item[n] = item;
+                if (n < N) {
+                    m.occ_idx[B + n] = item;
+                    if (item >= 0) {
+                        int* fl = (int*)m.occ_fl + 4 * (size_t)item;
+                        atomicMax(fl, B + n + 1);
+                        atomicMax(fl + 1, m.R - (B + n));
+                        atomicAdd(fl + 2, 1);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const GAS float* hsrc = m.hd[m.n_layers - 1];
+    const GAS float* Wy = m.Wy;
+    const GAS float* zrow = m.zrow;
+    GAS float* Sc = m.Sc;
+    // ---- issue side: stage `issued` of the run goes to ring buffer issued % NST
+    int cti = ct0, rti = t0 - ct0 * nrt, ksi = ks0, issued = 0, ibuf = 0;
+    const GAS float* pa[NP];
+    const GAS float* pb[NP];
+    auto setptr = [&]() {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int row = RPP * (NP * wid + j) + lane / QPR;
+            const int quad = (lane & FMASK) ^ ((row >> FSH) & FMASK);
+            const int item = sItem[(cti - ct0) * 64 + row];
+            const GAS float* a = (rti * 64 + row < M) ? hsrc + (size_t)(rti * 64 + row) * D : zrow;
+            const GAS float* b = (item >= 0) ? Wy + (size_t)item * D : zrow;
+            pa[j] = a + 4 * quad + ksi * BKS;
+            pb[j] = b + 4 * quad + ksi * BKS;
+        }
+    };
+    setptr();
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    const unsigned piece = lds0 + 1024u * (NP * wid);
+    auto issue = [&]() {
+        const unsigned base = piece + (unsigned)ibuf * (STAGE * 4);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) glds16(pa[j], base + 1024u * j);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) glds16(pb[j], base + BOFF + 1024u * j);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { pa[j] += BKS; pb[j] += BKS; }
+        ++issued;
+        ibuf = (ibuf + 1 == NST) ? 0 : ibuf + 1;
+        if (++ksi == KS && issued < S) {      // the run goes on in the next tile (row tiles of a column tile first)
+            ksi = 0;
+            if (++rti == nrt) { rti = 0; ++cti; }
+            setptr();
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) if (s < S) issue();
+    // ---- consume side
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    const int fsw = (l32 >> FSH) & FMASK;
+    const float* fa0 = smem + (wm * 32 + l32) * BKS;
+    const float* fb0 = smem + 64 * BKS + (wn * 32 + l32) * BKS;
+    int ctc = ct0, rtc = t0 - ct0 * nrt, ksc = ks0, kbeg = ks0, cbuf = 0;
+    for (int i = 0; i < S; ++i) {
+        // the pieces of stages i + 1 .. i + NST - 2 may stay in flight (LPS each).  Epilogue stores in between only make the
+        // counted wait conservative: loads return in order, so "at most `behind` x LPS operations outstanding" implies stage i landed
+        const int behind = min(NST - 2, S - 1 - i);
+        if (NST >= 5 && behind == 3) wait_vm_barrier<3 * LPS>();
+        else if (NST >= 4 && behind == 2) wait_vm_barrier<2 * LPS>();
+        else if (behind == 1) wait_vm_barrier<LPS>();
+        else wait_vm_barrier<0>();
+        if (i + NST - 1 < S) issue();
+        const float* fa = fa0 + cbuf * STAGE;
+        const float* fb = fb0 + cbuf * STAGE;
+        constexpr int NG = BKS / 8;
+        float4 qa[NG], qb[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            qa[j] = *reinterpret_cast<const float4*>(fa + 4 * ((2 * j + lh) ^ fsw));
+            qb[j] = *reinterpret_cast<const float4*>(fb + 4 * ((2 * j + lh) ^ fsw));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            acc = mfma32(qa[j].x, qb[j].x, acc);
+            acc = mfma32(qa[j].y, qb[j].y, acc);
+            acc = mfma32(qa[j].z, qb[j].z, acc);
+            acc = mfma32(qa[j].w, qb[j].w, acc);
+        }
+        cbuf = (cbuf + 1 == NST) ? 0 : cbuf + 1;
+        ++ksc;
+        if (ksc != KS && i != S - 1) continue;
+        // ---- a segment [kbeg, ksc) of tile (ctc, rtc) is complete
+        if (kbeg > 0) {
+            // TAIL of a tile whose head belongs to worker w - 1: publish the partial sum (slot w), write-through, then the flag
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4)
+                st4_sc1(ws + ((size_t)(w * 4 + j4) * 256 + tid) * 4, (f32x4){acc[4 * j4], acc[4 * j4 + 1], acc[4 * j4 + 2], acc[4 * j4 + 3]});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flags + w, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (ksc != KS) {
+                // HEAD of a tile that worker w + 1 finished at the start of its run: add its partial (head + tail, fixed order)
+                if (tid == 0) {
+                    int spin = 0;
+                    while (__hip_atomic_load(flags + w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != stamp) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spin > (1 << 16)) { ((GAS StepState*)st)->nan_flag = 1; break; }      // ~0.1 s; never observed; no hang
+                    }
+                }
+                __syncthreads();
+                f32x4 o[4];
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) o[j4] = ld4_sc1(ws + ((size_t)((w + 1) * 4 + j4) * 256 + tid) * 4);
+                // (the loaded registers are operands of the wait: the compiler does not know the asm loads are asynchronous and
+                // must not move their uses above it)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]) :: "memory");
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] += o[j >> 2][j & 3];
+            }
+            const int n = ctc * 64 + wn * 32 + l32;
+            const float bias = sBias[(ctc - ct0) * 64 + wn * 32 + l32];
+            if (n < N) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int row = rtc * 64 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3);
+                    if (row < M) Sc[(size_t)row * ld + n] = acc[j] + bias;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        kbeg = 0; ksc = 0;
+        if (++rtc == nrt) { rtc = 0; ++ctc; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Per-row final activation, loss and d cost / d s, in place in Sc.  One 1024-thread workgroup per batch row; the row's
 // yhat and softmax numerators live in LDS (every thread only revisits the columns it wrote itself, so the passes need
 // no barriers besides the three block reductions); row statistics via DPP wave reductions.
@@ -661,7 +860,7 @@ __device__ __forceinline__ float softplusf_(float x) {      // log(1 + e^x), sta
 
 // LONG_ROW (score rows whose two copies do not fit the LDS, > ~19 K columns): `se` lives in the row's own memory instead -- a thread
 // has read its columns' scores before it writes anything there, and only ever revisits its own columns.
-template <bool LONG_ROW>
+template <bool LONG_ROW, int PRE>
 __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict__ mp, StepState* st) {
     const DevModel& m = *mp;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -676,7 +875,11 @@ __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict
     float* red = smem + (LONG_ROW ? 1 : 2) * ldSc;      // [8][3 * LOSS_NW] one region per reduction
     // The first LOSS_PRE scores of every thread are requested TOGETHER with the step state (row i exists for every i < B), so
     // the kernel starts with one memory round trip instead of two (state -> M -> predicated row loads); M only masks them.
-    constexpr int LOSS_PRE = 4;
+    // LOSS_PRE x 1024 columns covers the whole row at every BASELINE shape (B = 512 with 8192 negatives: 8704 columns = 8.5 per
+    // thread): with 4, the other 4.5 scores of a thread came one dependent load per loop trip -- 32 waves x 256 B in flight per CU
+    // against ~1.5 us of memory latency is 1.4 TB/s chip-wide, which is exactly what the kernel measured (35.6 MB in 17 us).
+    // (PRE = 4 for rows of up to 4096 columns: the extra, masked loads would only lengthen the RSC15-sized launch)
+    constexpr int LOSS_PRE = PRE;
     const StepCtx c = load_ctx(st);
     float pre_s[LOSS_PRE];
 #pragma unroll

@@ -1,10 +1,14 @@
 // Multi-rank reconciliation of the GPU-local item tables (Wy / By / E and their optimizer state).  New: the reference is
-// single-GPU; north_star keeps the sparse rows GPU-local between synchronisation points.  Rule: every replica of a table ends at
-//     base + sum over ranks q (in rank order) of (value_q - base)
-// for the rows some rank touched since the last synchronisation (`base` = the common value at that point), i.e. every rank's
-// updates are kept in full (a row only one rank trained receives exactly that rank's update; averaging the replicas would
-// keep 1/nranks of it).  Rows are exchanged as packed (id list, delta rows) parts; the kernels below are shared by the RCCL
-// path (g4r_comm_sync_sparse) and by the host-driven test hooks (g4r_sync_export / g4r_sync_import).
+// single-GPU; north_star keeps the sparse rows GPU-local between synchronisation points.  For the rows some rank touched since
+// the last synchronisation (`base` = the common value at that point) every replica of a table ends at
+//     G4R_SYNC_SUM    base + sum  over the ranks q that touched the row, in rank order, of (value_q - base)
+//     G4R_SYNC_MEAN   base + mean over the ranks q that touched the row               of (value_q - base)
+// Under either rule a row only one rank trained receives exactly that rank's update (averaging whole replicas would keep 1 / nranks
+// of it).  SUM keeps every rank's update in full -- right for additive statistics (Adagrad's sum of squared gradients) -- but on
+// PARAMETERS it applies N independent full-size steps from the same starting point: measured with virtual ranks (DESIGN.md
+// section 7) Recall@20 falls from 0.41 to 0.17 at two ranks and the loss diverges at eight; MEAN is the local-SGD rule.  Rows are
+// exchanged as packed (id list, delta rows) parts; the kernels below are shared by the RCCL path (g4r_comm_sync_sparse) and by the
+// host-driven test hooks (g4r_sync_export / g4r_sync_import).
 #pragma once
 #include "g4r_device.cuh"
 
@@ -25,13 +29,22 @@ __global__ __launch_bounds__(256) void k_sync_reset(float* cur, const float* bas
     const size_t o = (size_t)ids[j] * W + (int)(e - j * W);
     cur[o] = base[o];
 }
-// cur[ids[j]] += delta[j]   (ids of one part are distinct: no two threads meet on an element)
-__global__ __launch_bounds__(256) void k_sync_add(float* cur, int W, const int* ids, long long n, const float* delta) {
+// cur[ids[j]] += delta[j] (rowcnt == nullptr: SUM) or delta[j] / (number of parts that hold the row) (MEAN)
+// (ids of one part are distinct: no two threads meet on an element)
+__global__ __launch_bounds__(256) void k_sync_add(float* cur, int W, const int* ids, long long n, const float* delta, const unsigned char* rowcnt) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= n * W) return;
     const long long j = e / W;
     const size_t o = (size_t)ids[j] * W + (int)(e - j * W);
-    cur[o] += delta[e];
+    float dlt = delta[e];
+    if (rowcnt) { const int c = rowcnt[ids[j]]; if (c > 1) dlt = dlt / (float)c; }
+    cur[o] += dlt;
+}
+// rowcnt[ids[j]] += 1 (one launch per part, in stream order: the ids of a part are distinct) / = 0
+__global__ __launch_bounds__(256) void k_sync_count(unsigned char* rowcnt, const int* ids, long long n, int clear) {
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    rowcnt[ids[j]] = clear ? 0 : (unsigned char)(rowcnt[ids[j]] + 1);
 }
 // base[ids[j]] = cur[ids[j]]
 __global__ __launch_bounds__(256) void k_sync_rebase(const float* cur, float* base, int W, const int* ids, long long n) {

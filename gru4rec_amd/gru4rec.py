@@ -119,6 +119,10 @@ class GRU4Rec:
         self.device = 0
         self.use_graph = True
         self.steps_per_call = 16384  # plan steps per C-ABI call (NaN check granularity)
+        # multi-GPU runs: the GPU-local item tables are reconciled every `sync_every` steps and at the end of every epoch.  Measured
+        # with virtual ranks (profiles/r03_virtual_ranks.json): reconciling only per epoch lets the replicas'
+        # embedding spaces drift apart under the shared (all-reduced) GRU weights -- Recall@20 0.41 -> 0.15 at two ranks
+        self.sync_every = 16
         self._model = None
         self._dist = None
         self._cpu_store = False
@@ -549,8 +553,11 @@ class GRU4Rec:
         T = plan['T'] if max_steps is None else min(plan['T'], max_steps)
         costs = np.empty(T, dtype=np.float32)
         done = 0
+        since_sync = 0
         while done < T:
             n = min(self.steps_per_call, T - done)
+            if self._dist and self.sync_every:
+                n = min(n, int(self.sync_every) - since_sync)      # every rank cuts at the same steps: plans have one common length
             if self._cpu_store:
                 # host sample store: the row pointer is the global step modulo the store length; a new store is drawn when it
                 # wraps (gru4rec.py:609-613), so no device call runs across that point
@@ -569,6 +576,10 @@ class GRU4Rec:
                 self.error_during_train = True
                 return None
             done += n
+            since_sync += n
+            if self._dist and self.sync_every and since_sync >= int(self.sync_every) and done < T:
+                m.comm_sync_sparse()
+                since_sync = 0
         cc = plan['M'][:T]
         avgc = np.sum(costs * cc) / max(np.sum(cc), 1)
         bad = bool(np.isnan(avgc))
@@ -641,7 +652,7 @@ class GRU4Rec:
                                   'exposes the same computation through gru4rec_amd.evaluation.evaluate_gpu')
 
     # ------------------------------------------------------------------ (de)serialisation (gru4rec.py:742-781)
-    _EXTRAS = dict(seed=12345, device=0, use_graph=True, steps_per_call=16384)     # attributes the reference does not have
+    _EXTRAS = dict(seed=12345, device=0, use_graph=True, steps_per_call=16384, sync_every=16)     # attributes the reference does not have
 
     def __getstate__(self):
         st = dict(self.__dict__)

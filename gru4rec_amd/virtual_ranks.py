@@ -29,23 +29,34 @@ def reconcile(models, groups=(0,)):
     return rows
 
 
-def fit_virtual_ranks(params, data, nranks, sample_store=10000000, sync_every=None, chunk=64, on_chunk=None):
+def fit_virtual_ranks(params, data, nranks, sample_store=10000000, sync_every='default', chunk=64, on_chunk=None, rule=None, replicate=False):
     """Train `params['n_epochs']` epochs as `nranks` virtual ranks.  Returns (the rank objects -- rank 0 holds the reconciled weights
     on the host, ready for evaluate_gpu / predict_next_batch --, stats dict).  sync_every: reconcile the item tables every that
-    many steps (None: only at the end of each epoch, what fit() does)."""
+    many steps ('default': GRU4Rec.sync_every, what fit() does; None: only at the end of each epoch).  rule: (parameter rule, statistic rule) of the reconciliation,
+    'sum' / 'mean' each (None: the library's default, g4r_sync_set_rule).  replicate: every rank gets ALL sessions and rank 0's
+    sample stream instead of its shard -- N identical ranks must then reproduce the single-rank run (a check of this machinery)."""
     grus = []
     for r in range(nranks):
         g = GRU4Rec(**params)
         g.set_distributed(r, nranks, None)
+        if replicate:
+            g.seed -= 7919 * r      # _create_model adds 7919 * rank
         g.prepare(data.copy(), sample_store=sample_store)
         if nranks > 1:
             g._model.sync_enable()
+            if rule is not None:
+                g._model.sync_set_rule(*rule)
         grus.append(g)
+    if sync_every == 'default':
+        sync_every = grus[0].sync_every
+    if nranks <= 1:
+        sync_every = None      # nothing to reconcile
     models = [g._model for g in grus]
     groups = (0,) if grus[0].constrained_embedding or not grus[0].embedding else (0, 1)
     stats = dict(steps=[], events=[], loss=[], sync_rows=0, syncs=0)
     for epoch in range(grus[0].n_epochs):
-        plans = [build_rank_plan(g._offsets, g._base_order, g._data_items, g.batch_size, g.n_sample, r, nranks) for r, g in enumerate(grus)]
+        plans = [build_rank_plan(g._offsets, g._base_order, g._data_items, g.batch_size, g.n_sample, 0 if replicate else r, 1 if replicate else nranks)
+                 for r, g in enumerate(grus)]
         T = max(p['T'] for p in plans)
         plans = [pad_plan(p, T) for p in plans]
         for g, p in zip(grus, plans):
@@ -55,7 +66,7 @@ def fit_virtual_ranks(params, data, nranks, sample_store=10000000, sync_every=No
         while done < T:
             n = min(chunk, T - done)
             if sync_every:
-                n = min(n, sync_every - since)
+                n = max(1, min(n, sync_every - since))
             if nranks > 1:
                 _native.virtual_train_steps(models, done, n)
             else:
@@ -69,6 +80,7 @@ def fit_virtual_ranks(params, data, nranks, sample_store=10000000, sync_every=No
             if on_chunk is not None:
                 on_chunk(epoch, done, T)
         costs = [m.get_losses(0, T) for m in models]
+        stats.setdefault('step_costs', []).append(costs)
         if any(np.isnan(c).any() for c in costs):
             raise FloatingPointError('NaN cost in a virtual-rank epoch')
         if nranks > 1:

@@ -185,6 +185,13 @@ int g4r_comm_init(g4r_model* m, const char* id128, int32_t nranks, int32_t rank)
  * replicas are bit-identical afterwards.  Packed (id list, delta rows) parts are
  * all-gathered in item-id ranges: the traffic follows the number of touched rows.  Called by fit() at the end of an epoch. */
 int g4r_comm_sync_sparse(g4r_model* m);
+/* combine rule of the reconciliation, per kind of plane: parameters (Wy / By / E and their velocities) and optimizer statistics
+ * (Adagrad / RMSprop accumulators, Adam moments and counters).  G4R_SYNC_SUM: base + sum of the deltas of the ranks that touched
+ * the row; G4R_SYNC_MEAN: base + their mean.  Default: parameters MEAN (N full-size steps from one starting point must not add up:
+ * measured), statistics SUM (squared gradients of all ranks' events add up as they would on one GPU). */
+#define G4R_SYNC_SUM 0
+#define G4R_SYNC_MEAN 1
+int g4r_sync_set_rule(g4r_model* m, int32_t param_rule, int32_t stat_rule);
 /* allocates the touched-row bitmap and the base copies, base = the tables as they are now (g4r_comm_init calls it;
  * g4r_set_param of an item table afterwards also sets its base) */
 int g4r_sync_enable(g4r_model* m);

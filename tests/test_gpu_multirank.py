@@ -64,12 +64,14 @@ def test_staged_path_replays_from_a_graph_that_holds_the_allreduce(monkeypatch):
         np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize('rule', [('sum', 'sum'), ('mean', 'sum'), None], ids=['sum_sum', 'mean_sum', 'default'])
 @pytest.mark.parametrize('name', ['bprmax_mom_drop', 'xe_sep_embed'])
-def test_item_table_reconciliation_with_two_handles(name):
+def test_item_table_reconciliation_with_two_handles(name, rule):
     """Two handles = two ranks.  After training on different shards, exporting both parts and importing [part0, part1] on both:
-    replicas are bit-identical, every row equals base + delta0 + delta1 (fp32, in that order), a row only one rank trained keeps
-    that rank's value (up to the fp32 rounding of base + (value - base)), optimizer state follows the same rule, untouched rows keep their bits; a second round starts
-    from the new base."""
+    replicas are bit-identical, every row equals base + delta0 / c + delta1 / c (fp32, in that order; c = 1 under the SUM rule, the
+    number of ranks that touched the row under MEAN), a row only one rank trained keeps that rank's value under either rule (up to
+    the fp32 rounding of base + (value - base)), untouched rows keep their bits; a second round starts from the new base.  The
+    default (None) is parameters / velocities MEAN, optimizer statistics SUM (g4r_sync_set_rule)."""
     kw = dict(CASES[name])
     I, B, ns, T = 120, 12, 24, 30
     D = kw['layers'][-1]
@@ -77,7 +79,10 @@ def test_item_table_reconciliation_with_two_handles(name):
     for r in range(2):
         _, m = make_pair(I, B, ns, store_rows=200, use_graph=1, **dict(kw))      # identical initial weights on both
         m.sync_enable()
+        if rule is not None:
+            m.sync_set_rule(*rule)
         ms.append(m)
+    prule, srule = rule if rule is not None else ('mean', 'sum')
     names = [('Wy', (I, D)), ('acc_Wy', (I, D)), ('By', (I,)), ('acc_By', (I,))]
     if kw.get('momentum', 0) > 0:
         names += [('vel_Wy', (I, D))]
@@ -98,8 +103,10 @@ def test_item_table_reconciliation_with_two_handles(name):
             m.set_plan(plan)
             m.train_steps(0, T)
             local.append({n: m.get_param(n, sh) for n, sh in names})
+        parts_by_group = {}
         for g in groups:
             parts = [m.sync_export(g) for m in ms]
+            parts_by_group[g] = parts
             assert all(len(p[0]) > 0 and (np.diff(p[0]) > 0).all() for p in parts)
             for m in ms:
                 m.sync_import(parts, g)
@@ -107,8 +114,18 @@ def test_item_table_reconciliation_with_two_handles(name):
             a, b = ms[0].get_param(n, sh), ms[1].get_param(n, sh)
             np.testing.assert_array_equal(a, b)
             d0, d1 = local[0][n] - base[n], local[1][n] - base[n]
-            np.testing.assert_array_equal(a, (base[n] + d0) + d1)
             rows = lambda x: np.abs(x.reshape(I, -1)).max(axis=1)
+            mean = (prule if not n.startswith('acc') else srule) == 'mean'
+            if mean:      # rows both ranks rewrote (their ids are in both exported parts) take half of each delta
+                pg = parts_by_group[1 if n.split('_')[-1] == 'E' else 0]
+                both = np.zeros(I, dtype=bool)
+                both[np.intersect1d(pg[0][0], pg[1][0])] = True
+                shp = (I,) + (1,) * (base[n].ndim - 1)
+                c = np.where(both.reshape(shp), np.float32(2), np.float32(1))
+                np.testing.assert_array_equal(a, (base[n] + d0 / c) + d1 / c)
+                assert both.any()
+            else:
+                np.testing.assert_array_equal(a, (base[n] + d0) + d1)
             only0 = (rows(d0) > 0) & (rows(d1) == 0)
             if n in ('Wy', 'E'):
                 assert only0.any()

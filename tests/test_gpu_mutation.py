@@ -19,10 +19,14 @@ from gru4rec_amd import build as g4r_build
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SELECTION = ['tests/test_gpu_baseline_configs.py::test_cfg4_exact_shape',
+SELECTION = ['tests/test_gpu_parity.py::test_first_step_intermediates[bprmax_elu]',
+             'tests/test_gpu_baseline_configs.py::test_cfg4_exact_shape',
              'tests/test_gpu_parity.py::test_baseline_config2_shape_few_steps',
              'tests/test_gpu_golden.py::test_product_reproduces_reference_run[bprmax_constrained]']
-EXPECT = {1: ('acc_Wy', 'acc_By'), 2: ('dWy', 'dBy'), 3: ('acc_Wx', 'acc_Wh', 'acc_Wrz', 'acc_Bh')}
+# one step from zero accumulators: what must fail and what must still pass (p1 = the first-step test's tag)
+FIRST_STEP = {1: (('p1 acc_Wy', 'p1 acc_By'), ('p1 acc_Wx0', 'p1 acc_Wh0', 'p1 dWx0')),
+              2: (('p1 dWy', 'p1 dBy'), ('p1 acc_Wy', 'p1 acc_By', 'p1 acc_Wx0', 'p1 dWx0')),
+              3: (('p1 acc_Wx0', 'p1 acc_Wh0', 'p1 acc_Wrz0', 'p1 acc_Bh0'), ('p1 acc_Wy', 'p1 acc_By', 'p1 dWy'))}
 
 
 @pytest.fixture(scope='module')
@@ -33,15 +37,21 @@ def mutants():
 
 
 @pytest.mark.parametrize('k', sorted(g4r_build.MUTANTS))
-def test_mutant_turns_the_parity_tests_red(mutants, k):
-    env = dict(os.environ, G4R_LIB=mutants[k])
-    for sel in SELECTION:
+def test_mutant_turns_the_parity_tests_red(mutants, k, tmp_path):
+    for i, sel in enumerate(SELECTION):
+        rep = str(tmp_path / ('report%d.txt' % i))
+        env = dict(os.environ, G4R_LIB=mutants[k], G4R_PARITY_REPORT=rep)
         r = subprocess.run([sys.executable, '-m', 'pytest', sel, '-x', '-q', '-p', 'no:cacheprovider'], cwd=ROOT, env=env,
                            capture_output=True, text=True, timeout=900)
         out = r.stdout + r.stderr
         assert r.returncode == 1, 'mutant %d (%s) passed %s:\n%s' % (k, g4r_build.MUTANTS[k], sel, out[-3000:])
-        if 'golden' not in sel:
-            assert any(name in out for name in EXPECT[k]), 'mutant %d failed %s, but not on %s:\n%s' % (k, sel, EXPECT[k], out[-3000:])
+        if i == 0:
+            # the per-tensor report of the child: the damaged tensors are red, the others still green
+            lines = open(rep).read().splitlines()
+            state = {ln[:28].strip(): ln.rstrip().endswith('FAIL') for ln in lines if 'worst/tol' in ln}
+            must_fail, must_pass = FIRST_STEP[k]
+            assert all(state[n] for n in must_fail), (k, {n: state[n] for n in must_fail})
+            assert not any(state[n] for n in must_pass), (k, {n: state[n] for n in must_pass})
 
 
 def test_product_library_is_not_a_mutant():

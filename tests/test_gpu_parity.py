@@ -22,7 +22,7 @@ from oracle.scheduler import fit_schedule
 
 pytestmark = pytest.mark.gpu
 
-REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'parity_report.txt')
+REPORT = os.environ.get('G4R_PARITY_REPORT') or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'parity_report.txt')
 
 
 def report(line):

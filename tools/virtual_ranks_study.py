@@ -25,31 +25,32 @@ def main():
     train, test = synth.train_test_split(data, test_frac=0.1)
     rows = []
 
-    def run(tag, n, sync_every=None, **over):
+    def run(tag, n, sync_every=None, rule=None, **over):
         p = dict(PARAMS, **over)
         t0 = time.time()
-        grus, st = fit_virtual_ranks(p, train, n, sample_store=STORE, sync_every=sync_every)
+        grus, st = fit_virtual_ranks(p, train, n, sample_store=STORE, sync_every=sync_every, rule=rule)
         rec, mrr = evaluation.evaluate_gpu(grus[0], test.copy(), cut_off=[5, 20], batch_size=100, mode='standard')
         for g in grus:
             g.close()
-        r = dict(tag=tag, nranks=n, batch_per_rank=p['batch_size'], epochs=p['n_epochs'], sync_every=sync_every, steps=st['steps'],
+        r = dict(tag=tag, nranks=n, batch_per_rank=p['batch_size'], epochs=p['n_epochs'], sync_every=sync_every, rule=rule, steps=st['steps'],
                  events=st['events'], loss=st['loss'], recall20=float(rec[1]), mrr20=float(mrr[1]), recall5=float(rec[0]), mrr5=float(mrr[0]),
                  reconciled_rows=st['sync_rows'], reconciliations=st['syncs'], seconds=time.time() - t0)
         rows.append(r)
         print(json.dumps(r), flush=True)
 
     run('1 rank, B=128 (the bar)', 1)
-    for n in (2, 4, 8):
-        run('%d ranks, reconcile at epoch end' % n, n)
-    for n in (2, 8):
-        for k in (64, 16):
-            run('%d ranks, reconcile every %d steps' % (n, k), n, sync_every=k)
+    for b in (256, 512, 1024):
+        run('1 rank at the global batch B=%d' % b, 1, batch_size=b)
+    # rule = (parameters, optimizer statistics) of the reconciliation: sum / mean of the deltas of the ranks that touched a row
+    for rule in (('sum', 'sum'), ('mean', 'sum'), ('mean', 'mean')):
+        for n in (2, 4, 8):
+            for k in (None, 64, 16, 4):
+                run('%d ranks, P %s / A %s, reconcile %s' % (n, rule[0], rule[1], 'at epoch end' if k is None else 'every %d steps' % k), n, sync_every=k, rule=rule)
     if not quick:
-        for b in (256, 1024):
-            run('1 rank at the global batch B=%d' % b, 1, batch_size=b)
         run('1 rank, 3 epochs', 1, n_epochs=3)
-        run('8 ranks, 3 epochs, reconcile at epoch end', 8, n_epochs=3)
-        run('8 ranks, 3 epochs, reconcile every 16 steps', 8, sync_every=16, n_epochs=3)
+        for rule in (('mean', 'sum'), ('mean', 'mean')):
+            for k in (None, 16):
+                run('8 ranks, 3 epochs, P %s / A %s, reconcile %s' % (rule[0], rule[1], 'at epoch end' if k is None else 'every %d steps' % k), 8, sync_every=k, rule=rule, n_epochs=3)
     base = rows[0]
     for r in rows:
         r['d_recall20'] = r['recall20'] - base['recall20']
@@ -57,9 +58,9 @@ def main():
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     with open(os.path.join(ROOT, 'gpurun_out', 'r03_virtual_ranks.json'), 'w') as f:
         json.dump(dict(workload='synth.make_sessions(24000, n_items=2500, seed=17), 10 % test split; BASELINE configs[1] model', rows=rows), f, indent=1)
-    print('%-46s %8s %8s %9s %9s' % ('run', 'R@20', 'MRR@20', 'dR@20', 'dMRR@20'))
+    print('%-62s %8s %8s %9s %9s %9s' % ('run', 'R@20', 'MRR@20', 'dR@20', 'dMRR@20', 'loss'))
     for r in rows:
-        print('%-46s %8.4f %8.4f %+9.4f %+9.4f' % (r['tag'], r['recall20'], r['mrr20'], r['d_recall20'], r['d_mrr20']))
+        print('%-62s %8.4f %8.4f %+9.4f %+9.4f %9.4f' % (r['tag'], r['recall20'], r['mrr20'], r['d_recall20'], r['d_mrr20'], r['loss'][-1]))
 
 
 if __name__ == '__main__':
