@@ -81,7 +81,7 @@ struct g4r_model {
     int ntiles = 0, nblkA = 0, nblkB = 0, ndtA = 0, ndtB = 0, nrtB = 0, nblk_occ = 0;
     size_t smem_score = 0, smem_loss = 0, smem_sparse = 0;
     // persistent stream-K scoring forward (k_score_fwd_sk): workers, tile grid, column tiles a worker may touch, scratch
-    int sk_W = 0, sk_nrt = 0, sk_nct = 0, sk_maxct = 0;
+    int sk_W = 0, sk_nrt = 0, sk_nct = 0, sk_maxct = 0, sk_nst = 3;
     float* sk_ws = nullptr;
     unsigned* sk_flags = nullptr;
     size_t smem_sk = 0;
@@ -366,15 +366,22 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     if (score_fwd_dma(d) && env_int("G4R_STREAMK", 1)) {
         // stream-K scoring forward: two workers per CU (or one per tile when there are fewer tiles), every run >= one tile's K stages
         const int nrt = cdiv(B, 64), nct = cdiv(d.ldSc, 64), KS = d.Dtop / 32, ntiles = nrt * nct;
-        const int W = std::min(env_int("G4R_SK_W", 2 * m->n_cu), ntiles);
+        // ring depth 3 (48 KiB): three workers per CU -- three waves per SIMD cover each other's DMA issue, fragment reads and
+        // barrier waits (measured at B = 512, N = 8704, D = 256: two workers per CU with a 4-deep ring left the MFMA pipe 45 % busy)
+        m->sk_nst = env_int("G4R_SK_NST", 3) >= 4 ? 4 : 3;
+        const int per_cu = m->sk_nst == 3 ? 3 : 2;
+        const int W = std::min(env_int("G4R_SK_W", per_cu * m->n_cu), ntiles);
         const long long U = (long long)ntiles * KS;
         int maxct = 1;
         for (int w = 0; w < W; ++w) {
             const long long u0 = U * w / W, u1 = U * (w + 1) / W;
             maxct = std::max(maxct, (int)(((u1 - 1) / KS) / nrt - (u0 / KS) / nrt + 1));
         }
-        m->smem_sk = (size_t)SK_NST * Tile3Cfg<SK_NST, 32>::STAGE * sizeof(float) + (size_t)maxct * 64 * (sizeof(int) + sizeof(float));
-        if (W >= 1 && U / W >= KS && m->smem_sk <= (size_t)(78 * 1024)) {
+        m->smem_sk = (size_t)m->sk_nst * Tile3Cfg<3, 32>::STAGE * sizeof(float) + (size_t)maxct * 64 * (sizeof(int) + sizeof(float));
+        // (fewer tiles than worker slots -- B = 240, N = 2288: 144 tiles -- leave CUs idle either way and the tile launch measured
+        // 1 us better there; G4R_STREAMK=2 takes the persistent launch regardless, for tests)
+        const bool enough = ntiles >= per_cu * m->n_cu || env_int("G4R_STREAMK", 1) == 2;
+        if (W >= 1 && U / W >= KS && enough && m->smem_sk <= (size_t)(78 * 1024)) {
             m->sk_W = W; m->sk_nrt = nrt; m->sk_nct = nct; m->sk_maxct = maxct;
             DA(m->sk_ws, (size_t)(W + 1) * 4 * 256 * 4);
             DA(m->sk_flags, (size_t)W + 1);
@@ -430,7 +437,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_k64, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_t2, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_t3, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_sk<SK_NST>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_sk<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_sk<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd_n, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_fwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -452,10 +460,10 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_store, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<false, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<true, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel"); }
+    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel (one copy of a score row must fit the 160 KB of LDS)"); }
+    if (m->smem_sparse > (size_t)big) { g4r_destroy(m); return fail("2 * batch_size + n_sample too large for the sparse update (the step's list of gathered rows must fit the 160 KB of LDS)"); }
     { float* z = nullptr; if (dalloc(m, &z, ZROW_FLOATS)) { g4r_destroy(m); return -1; } d.zrow = z; }
     if (getenv("G4R_CLK")) {
         if (dalloc(m, &d.dbgclk, 64 + 8 * (size_t)d.R) || dalloc(m, &d.dbgtile, 8 * (size_t)(4096 + 4096))) { g4r_destroy(m); return -1; }
@@ -763,16 +771,16 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         end();
     }
     begin(KN_SCORE_FWD);
-    if (m->sk_W > 0) LK(k_score_fwd_sk<SK_NST>, dim3(m->sk_W), dim3(GT_NTH), m->smem_sk, s, dmp, stp, m->sk_ws, m->sk_flags, m->sk_W, m->sk_nrt, m->sk_nct, m->sk_maxct);
+    if (m->sk_W > 0 && m->sk_nst == 3) LK(k_score_fwd_sk<3>, dim3(m->sk_W), dim3(GT_NTH), m->smem_sk, s, dmp, stp, m->sk_ws, m->sk_flags, m->sk_W, m->sk_nrt, m->sk_nct, m->sk_maxct);
+    else if (m->sk_W > 0) LK(k_score_fwd_sk<4>, dim3(m->sk_W), dim3(GT_NTH), m->smem_sk, s, dmp, stp, m->sk_ws, m->sk_flags, m->sk_W, m->sk_nrt, m->sk_nct, m->sk_maxct);
     else if (score_fwd_dma(d)) LK(k_score_fwd_t3, dim3(cdiv(d.ldSc, 64), cdiv(B, 64)), dim3(GT_NTH), SMEM_SF3, s, dmp, stp);
     else if (wide_scores(d) && score_tile2() && d.Dtop % T2_BK == 0) LK(k_score_fwd_t2, dim3(cdiv(d.ldSc, 64), cdiv(B, 64)), dim3(GT_NTH), SMEM_SF2, s, dmp, stp);
     else if (wide_scores(d)) LK(k_score_fwd_k64, dim3(cdiv(d.ldSc, SFW_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF64, s, dmp, stp);
     else LK(k_score_fwd_k128, dim3(cdiv(d.ldSc, GT_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF, s, dmp, stp);
     end();
     begin(KN_LOSS);
-    if (m->loss_long) LK((k_loss_rows<true, 10>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
-    else if (d.ldSc > 4096) LK((k_loss_rows<false, 10>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
-    else LK((k_loss_rows<false, 4>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
+    if (m->loss_long) LK(k_loss_rows<true>, dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
+    else LK(k_loss_rows<false>, dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
     end();
     begin(KN_SCORE_BWD);
     if (score_bwd2(d)) {

@@ -241,9 +241,8 @@ template __global__ void k_sparse_update<1>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update<2>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update_generic<1>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update_generic<2>(const DevModel*, StepState*, int);
-template __global__ void k_loss_rows<false, 4>(const DevModel*, StepState*);
-template __global__ void k_loss_rows<false, 10>(const DevModel*, StepState*);
-template __global__ void k_loss_rows<true, 10>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<false>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<true>(const DevModel*, StepState*);
 template __global__ void k_sparse_update<4>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update_generic<4>(const DevModel*, StepState*, int);
 template __global__ void k_update<1, 32>(const DevModel*, StepState*, const DenseTile*, int, int);
@@ -256,7 +255,8 @@ template __global__ void k_score_fwd<GT_BN, GT_BK>(const DevModel*, StepState*);
 template __global__ void k_score_fwd<32, 64>(const DevModel*, StepState*);
 template __global__ void k_score_fwd<64, 32, T2_BK>(const DevModel*, StepState*);
 template __global__ void k_score_fwd<64, 32, 3>(const DevModel*, StepState*);
-template __global__ void k_score_fwd_sk<SK_NST>(const DevModel*, StepState*, float*, unsigned*, int, int, int, int);
+template __global__ void k_score_fwd_sk<3>(const DevModel*, StepState*, float*, unsigned*, int, int, int, int);
+template __global__ void k_score_fwd_sk<4>(const DevModel*, StepState*, float*, unsigned*, int, int, int, int);
 template __global__ void k_score_bwd<32, GT_BK>(const DevModel*, StepState*, int, int, int, int);
 template __global__ void k_score_bwd<64, 64>(const DevModel*, StepState*, int, int, int, int);
 template __global__ void k_gru_p1<GT_BN, P1_BK>(const DevModel*, StepState*, int, int, int, GruFwdPredict);

@@ -639,7 +639,6 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
 // write-through 16-byte stores and L1-bypassing loads (`sc1` on both sides) behind a drained, step-stamped flag
 // (MI355X_MICROARCH.md, inter-workgroup visibility: form R1); the owner's poll is bounded and reports through nan_flag instead
 // of hanging should the co-residency assumption ever fail.
-#define SK_NST 4
 __device__ __forceinline__ void st4_sc1(GAS float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ f32x4 ld4_sc1(const GAS float* p) {
     f32x4 v;
@@ -647,7 +646,7 @@ __device__ __forceinline__ f32x4 ld4_sc1(const GAS float* p) {
     return v;
 }
 template <int NST>
-__global__ __launch_bounds__(256, 2) void k_score_fwd_sk(const DevModel* __restrict__ mp, StepState* st, float* ws_, unsigned* flags_, int W,
+__global__ __launch_bounds__(256, NST <= 3 ? 3 : 2) void k_score_fwd_sk(const DevModel* __restrict__ mp, StepState* st, float* ws_, unsigned* flags_, int W,
                                                          int nrt, int nct, int maxct) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
@@ -660,6 +659,8 @@ __global__ __launch_bounds__(256, 2) void k_score_fwd_sk(const DevModel* __restr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1, l32 = lane & 31, lh = lane >> 5;
+    GAS long long* trc = (G4R_DBGTILE(m) && blockIdx.x < 2048) ? G4R_DBGTILE(m) + 8 * (size_t)(4096 + blockIdx.x) : nullptr;      // tools/clk_score.py
+    if (trc && tid == 0) trc[0] = wall_clock64();
     const StepCtx c = load_ctx(st);
     const int M = c.M, B = m.B, D = m.Dtop, N = m.N, ld = m.ldSc;
     const int KS = D / BKS;
@@ -699,10 +700,12 @@ __global__ __launch_bounds__(256, 2) void k_score_fwd_sk(const DevModel* __restr
         }
     }
     __syncthreads();
+    if (trc && tid == 0) { trc[1] = wall_clock64(); trc[5] = c.t; trc[6] = (long long)__builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4) | ((long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) << 16); trc[7] = S; }      // HW_ID: wave / simd / cu / sh / se
     const GAS float* hsrc = m.hd[m.n_layers - 1];
     const GAS float* Wy = m.Wy;
     const GAS float* zrow = m.zrow;
     GAS float* Sc = m.Sc;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
     // ---- issue side: stage `issued` of the run goes to ring buffer issued % NST
     int cti = ct0, rti = t0 - ct0 * nrt, ksi = ks0, issued = 0, ibuf = 0;
     const GAS float* pa[NP];
@@ -720,7 +723,6 @@ __global__ __launch_bounds__(256, 2) void k_score_fwd_sk(const DevModel* __restr
         }
     };
     setptr();
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
     const unsigned piece = lds0 + 1024u * (NP * wid);
     auto issue = [&]() {
         const unsigned base = piece + (unsigned)ibuf * (STAGE * 4);
@@ -756,6 +758,7 @@ __global__ __launch_bounds__(256, 2) void k_score_fwd_sk(const DevModel* __restr
         else if (NST >= 4 && behind == 2) wait_vm_barrier<2 * LPS>();
         else if (behind == 1) wait_vm_barrier<LPS>();
         else wait_vm_barrier<0>();
+        if (trc && tid == 0 && i == 0) trc[2] = wall_clock64();
         if (i + NST - 1 < S) issue();
         const float* fa = fa0 + cbuf * STAGE;
         const float* fb = fb0 + cbuf * STAGE;
@@ -776,6 +779,7 @@ __global__ __launch_bounds__(256, 2) void k_score_fwd_sk(const DevModel* __restr
         }
         cbuf = (cbuf + 1 == NST) ? 0 : cbuf + 1;
         ++ksc;
+        if (trc && tid == 0 && i == S - 1) trc[3] = wall_clock64();
         if (ksc != KS && i != S - 1) continue;
         // ---- a segment [kbeg, ksc) of tile (ctc, rtc) is complete
         if (kbeg > 0) {
@@ -821,6 +825,7 @@ __global__ __launch_bounds__(256, 2) void k_score_fwd_sk(const DevModel* __restr
         kbeg = 0; ksc = 0;
         if (++rtc == nrt) { rtc = 0; ++ctc; }
     }
+    if (trc && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[4] = wall_clock64(); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -860,7 +865,7 @@ __device__ __forceinline__ float softplusf_(float x) {      // log(1 + e^x), sta
 
 // LONG_ROW (score rows whose two copies do not fit the LDS, > ~19 K columns): `se` lives in the row's own memory instead -- a thread
 // has read its columns' scores before it writes anything there, and only ever revisits its own columns.
-template <bool LONG_ROW, int PRE>
+template <bool LONG_ROW>
 __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict__ mp, StepState* st) {
     const DevModel& m = *mp;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -875,11 +880,9 @@ __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict
     float* red = smem + (LONG_ROW ? 1 : 2) * ldSc;      // [8][3 * LOSS_NW] one region per reduction
     // The first LOSS_PRE scores of every thread are requested TOGETHER with the step state (row i exists for every i < B), so
     // the kernel starts with one memory round trip instead of two (state -> M -> predicated row loads); M only masks them.
-    // LOSS_PRE x 1024 columns covers the whole row at every BASELINE shape (B = 512 with 8192 negatives: 8704 columns = 8.5 per
-    // thread): with 4, the other 4.5 scores of a thread came one dependent load per loop trip -- 32 waves x 256 B in flight per CU
-    // against ~1.5 us of memory latency is 1.4 TB/s chip-wide, which is exactly what the kernel measured (35.6 MB in 17 us).
-    // (PRE = 4 for rows of up to 4096 columns: the extra, masked loads would only lengthen the RSC15-sized launch)
-    constexpr int LOSS_PRE = PRE;
+    // (measured, round 3: requesting the WHOLE row up front -- 10 scores per thread at B = 512 with 8192 negatives -- does not move
+    // the kernel, 17.0 vs 17.1 us; neither do 512- or 256-thread workgroups, 18.7 / 29.5 us: the row is not waiting for its loads)
+    constexpr int LOSS_PRE = 4;
     const StepCtx c = load_ctx(st);
     float pre_s[LOSS_PRE];
 #pragma unroll

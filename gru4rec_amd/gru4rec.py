@@ -229,6 +229,34 @@ class GRU4Rec:
         if self.embedding == 'layersize':
             self.embedding = self.layers[0]
             show('embedding')
+        self._check_limits()      # shapes the MI355X path does not serve are refused here, with the limit, not deep inside fit()
+
+    # Shape limits of the HIP path (the reference has none of them; DESIGN.md section 5 "Limits" says where each comes from)
+    MAX_WIDTH = 1024            # units of a GRU layer / of the item embedding: one gathered row = at most four 16-byte quads per lane
+    LDS_BYTES = 156 * 1024      # what a workgroup of the step kernels may take of a CU's 160 KB
+
+    def _check_limits(self):
+        """NotImplementedError (the reference's way of refusing a configuration, gru4rec.py:143-177) naming the limit."""
+        for D in self.layers:
+            if _pad4(int(D)) > self.MAX_WIDTH:
+                raise NotImplementedError('layers={}: the MI355X path serves GRU layers of up to {} units'.format(self.layers, self.MAX_WIDTH))
+        if self.embedding and self.embedding != 'layersize' and _pad4(int(self.embedding)) > self.MAX_WIDTH:
+            raise NotImplementedError('embedding={}: the MI355X path serves item embeddings of up to {} units'.format(self.embedding, self.MAX_WIDTH))
+        if not self.constrained_embedding and not self.embedding and 3 * _pad4(int(self.layers[0])) > self.MAX_WIDTH:
+            raise NotImplementedError('one-hot input (embedding=0, constrained_embedding=False) with layers[0]={}: the rows of Wx[0] are 3 * layers[0] wide '
+                                      'and the MI355X path serves rows of up to {} floats (layers[0] <= {}); use constrained_embedding=True or '
+                                      'embedding=<size> for wider first layers'.format(self.layers[0], self.MAX_WIDTH, self.MAX_WIDTH // 3 // 4 * 4))
+        # one copy of a score row (k_loss_rows) and the step's occurrence list + partial rows (sparse update) live in LDS
+        B, ns = int(self.batch_size), int(self.n_sample)
+        ld = (B + ns + 15) // 16 * 16
+        width = max([_pad4(int(self.layers[-1]))] + ([_pad4(int(self.embedding))] if (self.embedding and self.embedding != 'layersize') else [])
+                    + ([3 * _pad4(int(self.layers[0]))] if (not self.constrained_embedding and not self.embedding) else []))
+        rpad = ((2 * B + ns + 255) // 256) * 256 + 256
+        need = max(4 * (ld + 288), 4 * rpad + 2112 + 32 * (width + 4))
+        if need > self.LDS_BYTES:
+            raise NotImplementedError('batch_size={} with n_sample={}: the MI355X path keeps a score row ({} columns) and the step\'s list of '
+                                      '{} gathered rows in the 160 KB of LDS of a compute unit; that holds about 38,000 rows / columns '
+                                      '(e.g. batch_size 512 with n_sample 36,000), fewer with rows wider than 512 units'.format(B, ns, B + ns, 2 * B + ns))
 
     # ------------------------------------------------------------------ weights (gru4rec.py:252-294)
     def _init_matrix(self, shape):
@@ -267,9 +295,7 @@ class GRU4Rec:
             raise IndexError('adapt={} needs {} value(s) in adapt_params'.format(self.adapt, need))     # the reference indexes adapt_params[0..1]
         if self.smoothing and self.loss not in ('cross-entropy', 'xe_logit'):
             raise NotImplementedError('smoothing is only defined for cross-entropy / xe_logit (gru4rec.py:226-235)')
-        if not self.constrained_embedding and not self.embedding and 3 * _pad4(self.layers[0]) > 1024:
-            raise NotImplementedError('one-hot input (embedding=0, constrained_embedding=False) needs 3 * layers[0] <= 1024 '
-                                      'in the MI355X path; use constrained_embedding=True or embedding=<size> for wider layers')
+        self._check_limits()
 
     def _create_model(self, sample_store, batch_size=None):
         self._check_supported()

@@ -61,3 +61,22 @@ def test_score_rows_longer_than_two_lds_copies(loss, fa):
     k_loss_rows<true> keeps the second one in the score row itself.  Same tolerances as the other shapes."""
     _run('long rows %s' % loss, I=40000, B=32, ns=20000, T=4, store_rows=6, tail=False, loss=loss, final_act=fa, constrained_embedding=True,
          layers=(32,), learning_rate=0.05, logq=1.0 if loss == 'cross-entropy' else 0.0, bpreg=0.5)
+
+
+@pytest.mark.parametrize('W,D', [(7, 96), (37, 96), (96, 96), (61, 256), (340, 32)])
+def test_stream_k_scoring_forward_split_positions(monkeypatch, W, D):
+    """The persistent stream-K scoring forward (k_score_fwd_sk: W workers, each a contiguous run of (tile, K stage) units; a tile
+    cut between two workers is finished by the head's owner in the fixed order head + tail) at worker counts that put the cuts at
+    every kind of position: inside the first stage pair (W = 96, D = 96: runs of 10.6 units, three stages per tile), many tiles
+    per worker (W = 7), one tile per worker with no cut at all (W = 340 = number of tiles), eight stages per tile (D = 256).
+    G4R_STREAMK=2 takes the persistent launch whatever the tile count (by default it only serves launches of >= 3 tiles per CU).
+    The ragged batch tail (M below a 64-row tile) and inactive columns run through the same code."""
+    monkeypatch.setenv('G4R_STREAMK', '2')
+    monkeypatch.setenv('G4R_SK_W', str(W))
+    from gru4rec_amd import _native
+    o, m = make_pair(12000, 300, 4000, store_rows=8, loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(D,),
+                     learning_rate=0.1, bpreg=0.5)
+    assert int(m.get_debug('streamk_workers', (1,))[0]) == W
+    m.close()
+    _run('stream-K W=%d D=%d' % (W, D), I=12000, B=300, ns=4000, T=6, store_rows=8, loss='bpr-max', final_act='elu-0.5',
+         constrained_embedding=True, layers=(D,), learning_rate=0.1, bpreg=0.5)

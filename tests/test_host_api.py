@@ -70,6 +70,27 @@ def test_out_of_scope_options_fail_loudly_at_fit():
             g._check_supported()
 
 
+@pytest.mark.parametrize('params,needle', [
+    (dict(layers='1100', constrained_embedding='True'), 'up to 1024 units'),
+    (dict(embedding='2000', constrained_embedding='False'), 'embeddings of up to 1024'),
+    (dict(layers='400', constrained_embedding='False', embedding='0'), 'layers[0] <= 340'),
+    (dict(batch_size='512', n_sample='40000'), 'about 38,000 rows / columns')])
+def test_shape_limits_are_refused_at_set_params_time_with_the_limit_in_the_message(params, needle):
+    """The reference has no such limits; the MI355X path names its own where the configuration is made (run.py -> set_params), in
+    the reference's way of refusing a configuration (NotImplementedError, gru4rec.py:143-177)."""
+    g = GRU4Rec()
+    with pytest.raises(NotImplementedError) as e:
+        g.set_params(**params)
+    assert needle in str(e.value)
+
+
+def test_shapes_inside_the_limits_pass_set_params():
+    GRU4Rec().set_params(layers='1024', constrained_embedding='True', batch_size='512', n_sample='29000')
+    GRU4Rec().set_params(layers='100', constrained_embedding='True', batch_size='512', n_sample='36000')
+    GRU4Rec().set_params(layers='340', constrained_embedding='False', embedding='0', n_sample='2048')
+    GRU4Rec().set_params(layers='96/1024', embedding='1000')
+
+
 def test_unknown_adapt_means_plain_sgd_like_the_reference():
     """gru4rec.py:392-399,411-418: any `adapt` other than the four known names falls through to the unscaled gradient."""
     g = GRU4Rec(layers=[8], batch_size=4, adapt='sgd', constrained_embedding=True)

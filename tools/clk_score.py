@@ -26,6 +26,14 @@ for rep in range(3):
                 print('   %s: %d tiles, start median %.2f max %.2f, end median %.2f max %.2f | setup %.2f first chunk %.2f K loop %.2f epilogue %.2f' % (
                     name, len(r), np.median(r[:, 0] - t00) / 100, (r[:, 0] - t00).max() / 100, np.median(r[:, 4] - t00) / 100, (r[:, 4] - t00).max() / 100,
                     *np.median(php, axis=0)))
+    if which == 'fwd' and tr[:, 7].max() > 0:      # stream-K workers: placement (HW_ID: cu bits 8..11, sh 12, se 13..15 -> xcc in XCC_ID, not here)
+        hw = tr[:, 6]
+        cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+        key = se * 100 + sh * 20 + cu
+        xcd = (hw >> 16) & 0xF        # XCC_ID
+        uniq, cnt = np.unique(key * 10 + xcd, return_counts=True)
+        print('   stream-K: %d workers on %d distinct (xcd, se, sh, cu); workers per CU histogram %s; units per worker %d..%d' % (
+            len(tr), len(uniq), dict(zip(*np.unique(cnt, return_counts=True))), tr[:, 7].min(), tr[:, 7].max()))
     t0 = tr[:, 0].min()
     pc = lambda x: np.round(np.percentile(x, [0, 10, 50, 90, 100]), 2)
     ph = np.diff(tr[:, 0:5], axis=1) / 100.0
