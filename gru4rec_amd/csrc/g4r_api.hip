@@ -363,7 +363,10 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     }
     if (ns > 0) DA(m->d_ST, (size_t)gl * ns);
     d.ST = m->d_ST;
-    if (score_fwd_dma(d) && env_int("G4R_STREAMK", 1)) {
+    // Persistent stream-K scoring forward: OPT-IN (G4R_STREAMK=1; 2 = whatever the tile count).  Built in round 3 as the round-2 review
+    // asked, parity green, and measured no faster than the tile launch at B = 512, N = 8704, D = 256 (31.2 vs 31.5 us; rocprofv3
+    // 34.4 vs 33.7) while moving 54 MB instead of 33 MB (partial sums, re-read rows): DESIGN.md section 5 has the traces.
+    if (score_fwd_dma(d) && env_int("G4R_STREAMK", 0)) {
         // stream-K scoring forward: two workers per CU (or one per tile when there are fewer tiles), every run >= one tile's K stages
         const int nrt = cdiv(B, 64), nct = cdiv(d.ldSc, 64), KS = d.Dtop / 32, ntiles = nrt * nct;
         // ring depth 3 (48 KiB): three workers per CU -- three waves per SIMD cover each other's DMA issue, fragment reads and
@@ -380,7 +383,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         m->smem_sk = (size_t)m->sk_nst * Tile3Cfg<3, 32>::STAGE * sizeof(float) + (size_t)maxct * 64 * (sizeof(int) + sizeof(float));
         // (fewer tiles than worker slots -- B = 240, N = 2288: 144 tiles -- leave CUs idle either way and the tile launch measured
         // 1 us better there; G4R_STREAMK=2 takes the persistent launch regardless, for tests)
-        const bool enough = ntiles >= per_cu * m->n_cu || env_int("G4R_STREAMK", 1) == 2;
+        const bool enough = ntiles >= per_cu * m->n_cu || env_int("G4R_STREAMK", 0) == 2;
         if (W >= 1 && U / W >= KS && enough && m->smem_sk <= (size_t)(78 * 1024)) {
             m->sk_W = W; m->sk_nrt = nrt; m->sk_nct = nct; m->sk_maxct = maxct;
             DA(m->sk_ws, (size_t)(W + 1) * 4 * 256 * 4);

@@ -307,9 +307,12 @@ __global__ __launch_bounds__(512) void k_gru_fwd_fused(const DevModel* __restric
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = m.D[l], IN = m.IN[l], D3 = 3 * D, D2 = 2 * D, KA = IN + D, Dq = D >> 2, INq = IN >> 2;
-    const StepCtx c = first ? load_ctx_first(st) : load_ctx(st);
-    const long long t = c.t, g = c.g;
-    const int M = c.M, B = m.B;
+    // step context: the loads are issued here, the values are first USED behind the requests that do not depend on them (weights
+    // by LDS-DMA and registers, row items, biases) -- a use up here would put the state's memory round trip (the previous launch
+    // wrote it) in front of everything
+    const GAS StepState* sgc = (const GAS StepState*)st;
+    const long long t = first ? sgc->t_a : sgc->t_b, g = first ? sgc->g_a : sgc->g_b;
+    const int M = first ? sgc->M_a : sgc->M_b, B = m.B;
     const int m0 = blockIdx.y * FF_ROWS, n0 = blockIdx.x * 32;
     const FwdFusedLds L = fwd_fused_lds(IN, D);
     float* sA = smem + L.sA;       // [16][LDA]   [y | H] rows
@@ -323,13 +326,11 @@ __global__ __launch_bounds__(512) void k_gru_fwd_fused(const DevModel* __restric
     int* sRow = reinterpret_cast<int*>(smem + L.sRow);
     f32x4* sJ = reinterpret_cast<f32x4*>(smem + L.sJoin);
     const int LDA = L.LDA, LDH = L.LDH;
-    const GAS float* Hcur = m.H[l][g & 1];
     GAS long long* clk = (G4R_DBGCLK(m) && blockIdx.x == 1 && blockIdx.y == 1) ? G4R_DBGCLK(m) + 0 : nullptr;      // kernel 0 of tools/clk.py
     if (clk && tid == 0) clk[0] = wall_clock64();
     // ---- row items first (the gathers wait for them), then everything that does not depend on them
     const int rrow = m0 + (tid & 15);
     int item = (l == 0) ? m.cur_in[min(rrow, B - 1)] : 0;      // staged by the previous step's bookkeeping: no wait for t
-    if (!(l == 0 && rrow < M)) item = -1;
     const GAS float* Wx = m.dense_p + m.offWx[l];
     const GAS float* Wrz = m.dense_p + m.offWrz[l];
     const GAS float* Wh = m.dense_p + m.offWh[l];
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(512) void k_gru_fwd_fused(const DevModel* __restric
     // at D = 100 -- the phase is bound by the first-touch latency of weights another XCD rewrote a few microseconds ago, not by the
     // copy).  Columns of the 32-column tiles past the matrix edge read clamped addresses: they only feed output columns that are
     // never stored.
-    if (m0 < M) {      // (a row block past the batch leaves below: it must not leave DMA writes behind)
+    {      // (unconditional: a row block past the batch waits for its pieces before it leaves, below)
         const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
         dma_rows<FF_LDR / 4, 8>(lds0 + 4u * L.sWr, D, Dq, wid, lane, [&](int k, int q) { return Wrz + (size_t)k * D2 + 4 * q; });
         dma_rows<FF_LDT / 4, 8>(lds0 + 4u * L.sWz, KA, 8, wid, lane, [&](int k, int q) {
@@ -355,15 +356,19 @@ __global__ __launch_bounds__(512) void k_gru_fwd_fused(const DevModel* __restric
         dma_rows<FF_LDT / 4, 8>(lds0 + 4u * L.sWc, IN, 8, wid, lane, [&](int k, int q) { return Wx + (size_t)k * D3 + min(n0 + 4 * q, D - 4); });
         dma_rows<FF_LDT / 4, 8>(lds0 + 4u * L.sWh, D, 8, wid, lane, [&](int k, int q) { return Wh + (size_t)k * D + min(n0 + 4 * q, D - 4); });
     }
-    // hidden part of the A rows: 16 rows x 32 quad slots
-    const int ar = tid >> 5, aq = tid & 31;
-    const int arow = min(m0 + ar, max(M - 1, 0));
-    const float4 ah = ld4(Hcur + (size_t)max(arow, 0) * D + 4 * min(aq, Dq - 1));
     // epilogue operands of this wave's sub-tiles: biases of the r columns (16 wid + li), of the tile's z / c columns
     const int nr = wid * 16 + li;
     const float b_r = ldf_at(Bh, D + nr, nr < D);
     const int nt = n0 + (wid & 1) * 16 + li;
     const float b_z = ldf_at(Bh, D2 + nt, nt < D), b_c = ldf_at(Bh, nt, nt < D);
+    // ---- first uses of the step context
+    if (first && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { GAS StepState* sw = (GAS StepState*)st; sw->t_b = t; sw->g_b = g; sw->M_b = M; }
+    if (!(l == 0 && rrow < M)) item = -1;
+    const GAS float* Hcur = m.H[l][g & 1];
+    // hidden part of the A rows: 16 rows x 32 quad slots
+    const int ar = tid >> 5, aq = tid & 31;
+    const int arow = min(m0 + ar, max(M - 1, 0));
+    const float4 ah = ld4(Hcur + (size_t)max(arow, 0) * D + 4 * min(aq, Dq - 1));
     unsigned rst4 = 0;      // reset flags of rows 4 lg .. 4 lg + 3 (stage-B epilogue: waves 0 and 1)
     if (wid < 2) {
 #pragma unroll
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(512) void k_gru_fwd_fused(const DevModel* __restric
             }
         }
     }
-    if (m0 >= M) return;
+    if (m0 >= M) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }      // its DMA pieces must not land in a later workgroup's LDS
     // ---- everything that does not wait for the gather goes to LDS now ([k][n] tiles, 16-byte stores): the hidden-part
     // weights of V_r (the input part follows into the same buffer after stage A1), the 32-column tiles, the H part of the rows
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1403,7 +1408,6 @@ __global__ __launch_bounds__(512) void k_gru_bwd_fused(const DevModel* __restric
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = c.M, B = m.B, D = m.D[l], IN = m.IN[l], D3 = 3 * D, Dq = D >> 2, D3q = D3 >> 2;
     const int m0 = blockIdx.y * BF_ROWS, n0 = blockIdx.x * 32;
-    if (m0 >= M) return;
     GAS long long* clk = (G4R_DBGCLK(m) && blockIdx.x == 1 && blockIdx.y == 1) ? G4R_DBGCLK(m) + 16 : nullptr;     // kernel 1 of tools/clk.py
     if (clk && tid == 0) clk[0] = wall_clock64();
     const int LDV = D3 + 2, LDW = D + 2;      // row strides with ld / 2 odd: MFMA fragment reads are conflict-free
@@ -1415,12 +1419,10 @@ __global__ __launch_bounds__(512) void k_gru_bwd_fused(const DevModel* __restric
     const bool top = (l == m.n_layers - 1), writer = (blockIdx.x == 0);
     const GAS float* Wh = m.dense_p + m.offWh[l];
     const GAS float* Wx = m.dense_p + m.offWx[l];
-    const GAS float* Hcur = m.H[l][c.g & 1];
     const GAS float *zl = m.z[l], *cl = m.c[l], *rl = m.r[l];
     GAS float* dV = m.dV[l];
-    // ---- requests (clamped addresses, no branches in between)
-    int myrow = m.occ_idx[min(m0 + (tid & 15), max(M - 1, 0))];
-    if (!(l == 0 && m0 + (tid & 15) < M)) myrow = -1;
+    // ---- requests (clamped addresses, no branches in between).  The weight tiles do not depend on the step context: they are
+    // requested before its first use, so that the state's memory round trip runs next to them instead of in front of them
     // Wh: 16 rows per pass, one quad of k per thread (32 quad slots per row, Dq <= 28 used)
     constexpr int NP_WH = (BF_MAXD + 15) / 16, NP_WX = (3 * BF_MAXD / 4 + 15) / 16;
     const int wr = tid >> 5, wq = min(tid & 31, Dq - 1);
@@ -1432,6 +1434,10 @@ __global__ __launch_bounds__(512) void k_gru_bwd_fused(const DevModel* __restric
     const GAS float* wxrow = Wx + (size_t)min(n0 + xr, IN - 1) * D3;
 #pragma unroll
     for (int p = 0; p < NP_WX; ++p) wx[p] = ld4(wxrow + 4 * min(xq + 16 * p, D3q - 1));
+    if (m0 >= M) return;      // (register loads: nothing is left behind)
+    const GAS float* Hcur = m.H[l][c.g & 1];
+    int myrow = m.occ_idx[min(m0 + (tid & 15), max(M - 1, 0))];
+    if (!(l == 0 && m0 + (tid & 15) < M)) myrow = -1;
     // stage-0 operands: 16 rows x 32 quad slots
     const int r0 = tid >> 5, q0 = tid & 31;
     const bool act0 = q0 < Dq;

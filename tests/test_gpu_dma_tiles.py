@@ -69,7 +69,8 @@ def test_stream_k_scoring_forward_split_positions(monkeypatch, W, D):
     cut between two workers is finished by the head's owner in the fixed order head + tail) at worker counts that put the cuts at
     every kind of position: inside the first stage pair (W = 96, D = 96: runs of 10.6 units, three stages per tile), many tiles
     per worker (W = 7), one tile per worker with no cut at all (W = 340 = number of tiles), eight stages per tile (D = 256).
-    G4R_STREAMK=2 takes the persistent launch whatever the tile count (by default it only serves launches of >= 3 tiles per CU).
+    The persistent launch is opt-in (it measured no faster than the tile launch): G4R_STREAMK=1 serves launches of >= 3 tiles per CU,
+    G4R_STREAMK=2 any tile count.
     The ragged batch tail (M below a 64-row tile) and inactive columns run through the same code."""
     monkeypatch.setenv('G4R_STREAMK', '2')
     monkeypatch.setenv('G4R_SK_W', str(W))
@@ -80,3 +81,14 @@ def test_stream_k_scoring_forward_split_positions(monkeypatch, W, D):
     m.close()
     _run('stream-K W=%d D=%d' % (W, D), I=12000, B=300, ns=4000, T=6, store_rows=8, loss='bpr-max', final_act='elu-0.5',
          constrained_embedding=True, layers=(D,), learning_rate=0.1, bpreg=0.5)
+
+
+def test_stream_k_at_the_cfg4_shape(monkeypatch):
+    """B = 512, 8192 negatives, D = 256 -- 1088 tiles, three workers per CU (768 on an MI355X), every worker's run cut inside tiles."""
+    monkeypatch.setenv('G4R_STREAMK', '1')
+    from gru4rec_amd import _native
+    kw = dict(loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(256,), learning_rate=0.1, bpreg=1.0)
+    o, m = make_pair(20000, 512, 8192, store_rows=6, **kw)
+    assert int(m.get_debug('streamk_workers', (1,))[0]) >= 512
+    m.close()
+    _run('stream-K cfg4 shape', I=20000, B=512, ns=8192, T=4, store_rows=6, tail=False, **kw)
