@@ -195,7 +195,8 @@ static inline bool wide_scores(const DevModel& d) {
     static const int minB = env_int("G4R_WIDE_B", 256), minN = env_int("G4R_WIDE_N", 4096);
     // (a top layer that is a multiple of 64 takes the 64 x 64 tiles of k_score_bwd2 from B = 192, 2048 columns on: B = 240, N = 2288,
     // D = 512 measured 22.2 vs 25.1 us against the 32 x 32 tiles)
-    return !off && ((d.B >= minB && d.ldSc >= minN) || (d.Dtop % 64 == 0 && d.B >= std::min(minB, 192) && d.ldSc >= std::min(minN, 2048)));
+    static const int d64 = env_int("G4R_WIDE_D64", 1);
+    return !off && ((d.B >= minB && d.ldSc >= minN) || (d64 && d.Dtop % 64 == 0 && d.B >= std::min(minB, 192) && d.ldSc >= std::min(minN, 2048)));
 }
 // LDS-DMA tiles (gemm_tile3, k_score_fwd_t3), D a multiple of 32: where gemm_tile2 served (long score rows / big batches), and
 // for a wide top layer (D >= 256) whenever the batch fills 64-row tiles -- there the launch is a few hundred tiles, fewer than

@@ -222,7 +222,7 @@ struct Tile2Cfg {
 // BK2 = 32: 32 KiB of LDS per workgroup; BK2 = 16: 16 KiB (the runtime reports 5 workgroups per CU for 32 KiB, but only 4 run:
 // with 16 KiB the register file sets the limit, 5).
 template <int BK2, bool PRE_COL, class ARow, class BRow, class Pre, class Epi>
-__device__ __forceinline__ void gemm_tile2(int m0, int n0, int K, ARow arow, BRow brow, Pre pre, Epi epi, float* smem, GAS long long* trc = nullptr) {
+__device__ __forceinline__ void gemm_tile2(int m0, int n0, int K, ARow arow, BRow brow, const GAS float* zrow, Pre pre, Epi epi, float* smem, GAS long long* trc = nullptr) {
     using C = Tile2Cfg<BK2>;
     static_assert(BK2 == 16 || BK2 == 32, "chunk depth");
     constexpr int LDK = C::LDK, BUF = 64 * LDK;
@@ -241,8 +241,8 @@ __device__ __forceinline__ void gemm_tile2(int m0, int n0, int K, ARow arow, BRo
         const GAS float* a = arow(sr + RPP * q);
         const GAS float* b = brow(sr + RPP * q);
         oka[q] = a != nullptr; okb[q] = b != nullptr;
-        pa[q] = (oka[q] ? a : arow(0)) + sc;          // rows outside the matrix re-read a valid row; their quads are zeroed at commit
-        pb[q] = (okb[q] ? b : brow(0)) + sc;
+        pa[q] = (oka[q] ? a : zrow) + sc;             // rows outside the matrix / inactive gathered rows walk the zero row (>= K floats);
+        pb[q] = (okb[q] ? b : zrow) + sc;             // row 0 of the tile is no substitute: it may be inactive itself (null)
     }
     float4 ra[NQ], rb[NQ];
     auto issue = [&]() {
@@ -455,8 +455,11 @@ __device__ __forceinline__ void gemm_tile3(int m0, int n0, int K, ARow arow, BRo
 //   * its provider is called per chunk, `ptr(kk, kr, c)` -> address of element (k = kk + kr, column c) or nullptr (outside the
 //     matrix / inactive gathered row): rows of a gathered operand change from chunk to chunk.
 // A_KM = false: A is K-contiguous ([m][k], row pointers `arow(r)` as in gemm_tile2, XOR-swizzled rows of 16 floats).
+// `safe`: >= 16 readable bytes (DevModel::zrow): what a masked slot loads instead of its operand.  (Round 2 re-read the provider's
+// element (0, 0, 0) there, which is itself a null pointer when the FIRST column of a dh slab is an inactive in-batch column -- a slab
+// boundary inside [M, B) at the tail of an epoch: a GPU fault at address 0 once B = 240 took these tiles.)
 template <bool A_KM, bool PRE_COL, class AProv, class BProv, class Pre, class Epi>
-__device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, BProv bprov, Pre pre, Epi epi, float* smem, GAS long long* trc = nullptr) {
+__device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, BProv bprov, const GAS float* safe, Pre pre, Epi epi, float* smem, GAS long long* trc = nullptr) {
     constexpr int BK = 16;
     constexpr int BUF = 64 * BK;                        // floats per operand buffer, either layout
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -473,7 +476,7 @@ __device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, 
     if constexpr (!A_KM) {
         const GAS float* a = aprov(sr);
         oka = a != nullptr;
-        pa = (oka ? a : aprov(0)) + sc;
+        pa = oka ? a + sc : safe;
     }
     // (measured and rejected: (a) an LDS-DMA ring like gemm_tile3's for these operands (3 stages of 32 k: K-major stages need no
     // swizzle, the K-contiguous A is read as quads and the K-major B follows its k order) -- results identical, k_score_bwd2 at
@@ -484,10 +487,10 @@ __device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, 
     const GAS float* qa = nullptr;
     const GAS float* qb = nullptr;
     auto issue = [&](int kk) {
-        if constexpr (A_KM) { qa = aprov(kk, kr, kc); ra = ld4(qa ? qa : aprov(0, 0, 0)); }
-        else { ra = ld4(pa); pa += BK; }
+        if constexpr (A_KM) { qa = aprov(kk, kr, kc); ra = ld4(qa ? qa : safe); }
+        else { ra = ld4(pa); if (oka) pa += BK; }
         qb = bprov(kk, kr, kc);
-        rb = ld4(qb ? qb : bprov(0, 0, 0));
+        rb = ld4(qb ? qb : safe);
     };
     // (component-wise selects: a ternary on the float4 struct was compiled to a select between two scratch copies)
     auto mask4 = [](float4 v, bool ok) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); };

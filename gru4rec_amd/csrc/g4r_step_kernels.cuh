@@ -625,7 +625,7 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
             return make_float4(x, 0.f, 0.f, 0.f);
         };
         if constexpr (T2 == 3) gemm_tile3<T3_NST, T3_BKS, true>(m0, n0, D, arow, brow, m.zrow, pre2, epi, smem, trc);
-        else gemm_tile2<(T2 > 3) ? T2 : 16, true>(m0, n0, D, arow, brow, pre2, epi, smem, trc);
+        else gemm_tile2<(T2 > 3) ? T2 : 16, true>(m0, n0, D, arow, brow, m.zrow, pre2, epi, smem, trc);
     } else gemm_tile<SF_BM, TBN, TBK, false, true, GT_NTH>(m0, n0, D, aload, bload, pre, epi, smem);
 }
 
@@ -1222,7 +1222,7 @@ __global__ __launch_bounds__(256) void k_score_bwd2(const DevModel* __restrict__
             dSy[(size_t)n * D + d] = step; dAy[(size_t)n * D + d] = an;
         };
         if (trc && tid == 0) trc[1] = wall_clock64();
-        gemm_tile2k<true, false>(n0, d0, M, aptr, bptr, pre, epi, smem, trc);
+        gemm_tile2k<true, false>(n0, d0, M, aptr, bptr, m.zrow, pre, epi, smem, trc);
         return;
     }
     if ((int)blockIdx.x < nblkA + nblkB) {
@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(256) void k_score_bwd2(const DevModel* __restrict__
             if (b < M) dhpart[((size_t)kc * B + b) * D + d] = v;
         };
         if (trc && tid == 0) trc[1] = wall_clock64();
-        gemm_tile2k<false, true>(m0, d0, min(kch, ld - kbeg), arow, bptr, NoPre(), epi, smem, trc);
+        gemm_tile2k<false, true>(m0, d0, min(kch, ld - kbeg), arow, bptr, m.zrow, NoPre(), epi, smem, trc);
         return;
     }
     // ---- role C: 64 columns, thread (column tid & 63, row group tid >> 6)

@@ -92,3 +92,14 @@ def test_stream_k_at_the_cfg4_shape(monkeypatch):
     assert int(m.get_debug('streamk_workers', (1,))[0]) >= 512
     m.close()
     _run('stream-K cfg4 shape', I=20000, B=512, ns=8192, T=4, store_rows=6, tail=False, **kw)
+
+
+@pytest.mark.parametrize('B,ns,D', [(240, 2048, 128), (300, 4000, 48), (256, 3840, 64)])
+def test_tile_or_slab_that_starts_on_an_inactive_in_batch_column(B, ns, D):
+    """The tail of an epoch (M < B): the in-batch columns [M, B) are inactive (-1 items).  A 64-column tile of the scoring forward
+    (`gemm_tile2`, D = 48) or a split-K slab of dh in `k_score_bwd2` (`gemm_tile2k`, D a multiple of 64 from B = 192 on) that STARTS
+    inside that range used its own first row as the address masked slots load from -- a null pointer there: round 3's first
+    `fit` at B = 240 faulted at address 0 (the exact-shape tests always ran full batches).  M = 5 puts every boundary below B
+    into the inactive range."""
+    _run('inactive head B=%d D=%d' % (B, D), I=9000, B=B, ns=ns, T=8, store_rows=10, loss='bpr-max', final_act='elu-0.5',
+         constrained_embedding=True, layers=(D,), learning_rate=0.1, bpreg=0.5)
