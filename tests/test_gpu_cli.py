@@ -99,3 +99,15 @@ def test_gpus_flag_spawns_its_ranks(tsvs):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert 'rank 1 exited' in r.stderr
+
+
+def test_bench_gpus_flag_on_a_one_gpu_box_fails_fast_and_loud():
+    """`python bench.py --gpus 2` where only one GPU exists: rank 1 refuses (LOCAL_RANK 1, one device), the launcher stops rank 0 and
+    returns non-zero -- no JSON line that claims two GPUs, no hang in RCCL."""
+    from gru4rec_amd import _native
+    if _native.device_count() >= 2:
+        pytest.skip('needs a box with ONE GPU')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--no-micro'],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert 'rank 1' in r.stderr and '"n_gpus": 2' not in r.stdout
