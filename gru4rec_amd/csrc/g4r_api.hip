@@ -121,6 +121,7 @@ struct g4r_model {
     int sync_rule[2] = {G4R_SYNC_MEAN, G4R_SYNC_SUM};      // combine rule of the parameter planes / of the statistic planes
     unsigned char* d_touched = nullptr;
     unsigned char* d_rowcnt = nullptr;           // [n_items] scratch: number of parts that hold a row (MEAN rule)
+    float* d_dense[2] = {nullptr, nullptr};      // dense reconciliation buffers [n_items][sum of plane widths + 1] per table group (small catalogues)
     bool sync_on = false;
 };
 
@@ -1495,6 +1496,14 @@ int g4r_sync_enable(g4r_model* m) {
         return -1;
     if (d.E && (add(1, d.E, d.Ein, 0) || add(1, d.accE, d.Ein, 1) || add(1, d.velE, d.Ein, 0) || add(1, d.acc2E, d.Ein, 1) || add(1, d.cntE, d.Ein, 1))) return -1;
     if (dalloc(m, &m->d_touched, (size_t)tables * I, true) || dalloc(m, &m->d_rowcnt, I, true)) return -1;
+    // small item tables: the dense, all-device form of the reconciliation (one all-reduce of [n_items][widths + 1] per table group)
+    for (int g = 0; g < tables; ++g) {
+        size_t w = 1;
+        for (auto& pl : m->planes[g]) w += pl.W;
+        const size_t bytes = I * w * sizeof(float);
+        if (m->planes[g].size() <= 12 && bytes <= (size_t)env_int("G4R_SYNC_DENSE_MB", 64) * 1024 * 1024 && env_int("G4R_SYNC_DENSE", 1))
+            if (dalloc(m, &m->d_dense[g], I * w, false)) return -1;
+    }
     if (const char* e = getenv("G4R_SYNC_RULE")) {      // "<param><stat>", s = sum, m = mean: experiments (tools/virtual_ranks_study.py)
         if (e[0]) m->sync_rule[0] = e[0] == 's' ? G4R_SYNC_SUM : G4R_SYNC_MEAN;
         if (e[0] && e[1]) m->sync_rule[1] = e[1] == 's' ? G4R_SYNC_SUM : G4R_SYNC_MEAN;
@@ -1621,6 +1630,55 @@ int g4r_sync_import(g4r_model* m, int32_t group, int32_t nparts, const int64_t* 
     return 0;
 }
 
+static SyncPlanes sync_planes_of(g4r_model* m, int group) {
+    SyncPlanes p;
+    memset(&p, 0, sizeof(p));
+    int off = 0;
+    for (auto& pl : m->planes[group]) {
+        p.cur[p.n] = pl.cur; p.base[p.n] = pl.base; p.W[p.n] = pl.W; p.off[p.n] = off; p.mean[p.n] = m->sync_rule[pl.kind] == G4R_SYNC_MEAN;
+        off += pl.W; ++p.n;
+    }
+    p.wsum = off;
+    return p;
+}
+static void sync_dense_pack(g4r_model* m, int group) {
+    const SyncPlanes p = sync_planes_of(m, group);
+    const long long I = m->dm.n_items, n = I * (p.wsum + 1);
+    hipLaunchKernelGGL(k_sync_dense_pack, dim3(nblk256(n)), dim3(256), 0, m->stream, p, (const unsigned char*)(m->d_touched + (size_t)group * I), I, m->d_dense[group]);
+}
+static void sync_dense_apply(g4r_model* m, int group) {
+    const SyncPlanes p = sync_planes_of(m, group);
+    const long long I = m->dm.n_items, n = I * (p.wsum + 1);
+    hipLaunchKernelGGL(k_sync_dense_apply, dim3(nblk256(n)), dim3(256), 0, m->stream, p, m->d_touched + (size_t)group * I, I, (const float*)m->d_dense[group]);
+}
+// The dense reconciliation with the ranks' buffers summed in process (handles of one device standing in for ranks, as in
+// g4r_virtual_train_steps): what g4r_comm_sync_sparse does around its ncclAllReduce when the item tables are small.
+int g4r_virtual_sync_dense(g4r_model* const* ms, int32_t n) {
+    if (!ms || n < 1 || n > 16) return fail("virtual ranks: 1..16 handles");
+    for (int q = 0; q < n; ++q) if (!ms[q] || !ms[q]->sync_on || !ms[q]->d_dense[0]) return fail("virtual dense sync: g4r_sync_enable first (and a table small enough for the dense form)");
+    HIPCHK(hipSetDevice(ms[0]->cfg.device));
+    for (int g = 0; g < 2; ++g) {
+        if (ms[0]->planes[g].empty()) continue;
+        if (!ms[0]->d_dense[g]) return fail("virtual dense sync: table group too large for the dense form");
+        const SyncPlanes p = sync_planes_of(ms[0], g);
+        const long long cnt = (long long)ms[0]->dm.n_items * (p.wsum + 1);
+        if (cnt > 0x7fffffffLL) return fail("virtual dense sync: buffer too large");
+        VSumArgs va;
+        memset(&va, 0, sizeof(va));
+        for (int q = 0; q < n; ++q) { sync_dense_pack(ms[q], g); va.src[q] = ms[q]->d_dense[g]; va.dst[q] = ms[q]->d_dense[g]; }
+        for (int q = 0; q < n; ++q) HIPCHK(hipStreamSynchronize(ms[q]->stream));
+        float* tmp = nullptr;
+        HIPCHK(hipMalloc((void**)&tmp, (size_t)cnt * sizeof(float)));
+        hipLaunchKernelGGL(k_virtual_sum, dim3(nblk256(cnt)), dim3(256), 0, ms[0]->stream, va, n, (int)cnt, tmp);
+        hipLaunchKernelGGL(k_virtual_bcast, dim3(nblk256(cnt)), dim3(256), 0, ms[0]->stream, va, n, (int)cnt, (const float*)tmp);
+        HIPCHK(hipStreamSynchronize(ms[0]->stream));
+        (void)hipFree(tmp);
+        for (int q = 0; q < n; ++q) sync_dense_apply(ms[q], g);
+        for (int q = 0; q < n; ++q) HIPCHK(hipStreamSynchronize(ms[q]->stream));
+    }
+    return 0;
+}
+
 // RCCL path: id lists all-gathered once per group, then the table is walked in item-id ranges; per range every rank packs its
 // delta rows, one all-gather (padded to the largest part of the range) brings all parts, sync_apply adds them in rank order.
 // The traffic follows the number of touched rows, not the table size.
@@ -1638,6 +1696,15 @@ int g4r_comm_sync_sparse(g4r_model* m) {
     hipStream_t s = m->stream;
     for (int group = 0; group < 2; ++group) {
         if (m->planes[group].empty()) continue;
+        if (m->d_dense[group]) {
+            // small table: pack -> one all-reduce -> apply, all on the stream, no host round trip (the sum's order is RCCL's: every
+            // rank receives the same bits, so the replicas still end bit-identical)
+            const SyncPlanes p = sync_planes_of(m, group);
+            sync_dense_pack(m, group);
+            NCCLCHK(ncclAllReduce(m->d_dense[group], m->d_dense[group], (size_t)I * (p.wsum + 1), ncclFloat, ncclSum, m->comm, s));
+            sync_dense_apply(m, group);
+            continue;
+        }
         std::vector<int> loc;
         if (sync_local_ids(m, group, loc)) return -1;
         // counts

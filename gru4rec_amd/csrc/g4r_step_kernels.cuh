@@ -2055,8 +2055,14 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     // the wave of the item's last occurrence owns the row (and clears the item's entry for the next step)
     const bool owner = item >= 0 && fl.x == k + 1;
     const int first_j = max(lo, R - fl.y);
-    const bool dup = owner && fl.z > 1;
-    const bool hot = owner && fl.z - 1 > UB;
+    // An item ALL of whose occurrences are sampled negatives of this step (first occurrence >= 2B: the common kind of repeat, the
+    // popularity sampler draws the head of the catalogue several times per row): its score columns are copies of one another --
+    // same item row, same bias, no column of them is anybody's positive -- so k_loss_rows / k_score_bwd produced bit-identical
+    // step rows for them and the sum over the earlier occurrences is (count - 1) x this wave's own row, added one at a time in
+    // the order the list walk would have used: no occurrence list, no second round trip for the step rows.
+    const bool allsmp = owner && fl.z > 1 && first_j >= 2 * B;
+    const bool dup = owner && fl.z > 1 && !allsmp;
+    const bool hot = owner && fl.z - 1 > UB && !allsmp;
     if (owner && lane == 0) {
         *(GAS int4*)flp = make_int4(0, 0, 0, 0);
         if (m.touched) m.touched[(tableE ? (size_t)nI : 0) + item] = 1;
@@ -2231,6 +2237,14 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
             __syncthreads();
             if (G4R_DBGCLK(m)) t_h[4] = wall_clock64();
         }
+    }
+    if (allsmp) {
+        for (int cdup = 1; cdup < fl.z; ++cdup) {      // wave-uniform trip count
+#pragma unroll
+            for (int q = 0; q < MAXCH; ++q) { S[q].x += sk[q].x; S[q].y += sk[q].y; S[q].z += sk[q].z; S[q].w += sk[q].w; }
+            Sb += bsk;
+        }
+        n_e = fl.z - 1; nb_e = fl.z - 1;
     }
     // ---- final row values from S + s_k (sum over all occurrences) and the last occurrence's rows, and the stores
     if (owner) {

@@ -55,6 +55,41 @@ __global__ __launch_bounds__(256) void k_sync_rebase(const float* cur, float* ba
     base[o] = cur[o];
 }
 
+// ---- dense form of the reconciliation (item tables of up to a few tens of MB: all device side, no host round trip) -----------
+// One buffer row per item: [delta of plane 0 | delta of plane 1 | ... | touched (1 / 0)], zero for rows this rank did not rewrite;
+// the buffer is all-reduced (sum) as it stands, then every rank applies  cur = base + sum / count  (MEAN planes) or  base + sum
+// (SUM planes) to the rows whose count is > 0, takes the result as the new base and clears its touched byte.
+struct SyncPlanes { float* cur[12]; float* base[12]; int W[12]; int off[12]; int mean[12]; int n; int wsum; };
+__global__ __launch_bounds__(256) void k_sync_dense_pack(SyncPlanes p, const unsigned char* touched, long long n_items, float* buf) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int ld = p.wsum + 1;
+    if (e >= n_items * ld) return;
+    const long long i = e / ld;
+    const int c = (int)(e - i * ld);
+    const bool t = touched[i] != 0;
+    if (c == p.wsum) { buf[e] = t ? 1.f : 0.f; return; }
+    int q = 0;
+    while (q + 1 < p.n && c >= p.off[q + 1]) ++q;
+    const size_t o = (size_t)i * p.W[q] + (c - p.off[q]);
+    buf[e] = t ? p.cur[q][o] - p.base[q][o] : 0.f;
+}
+__global__ __launch_bounds__(256) void k_sync_dense_apply(SyncPlanes p, unsigned char* touched, long long n_items, const float* buf) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int ld = p.wsum + 1;
+    if (e >= n_items * ld) return;
+    const long long i = e / ld;
+    const int c = (int)(e - i * ld);
+    const float cnt = buf[i * ld + p.wsum];
+    if (cnt <= 0.f) return;
+    if (c == p.wsum) { touched[i] = 0; return; }
+    int q = 0;
+    while (q + 1 < p.n && c >= p.off[q + 1]) ++q;
+    const size_t o = (size_t)i * p.W[q] + (c - p.off[q]);
+    const float v = p.base[q][o] + (p.mean[q] && cnt > 1.f ? buf[e] / cnt : buf[e]);
+    p.cur[q][o] = v;
+    p.base[q][o] = v;
+}
+
 // ---- virtual ranks (g4r_virtual_train_steps): the dense-gradient buffers of n handles on one device summed in rank order -- what
 // the RCCL all-reduce of a real n-GPU run delivers -- and handed back to every handle
 struct VSumArgs { const float* src[16]; float* dst[16]; };

@@ -17,9 +17,13 @@ from .gru4rec import GRU4Rec
 from .plan import build_rank_plan, pad_plan
 
 
-def reconcile(models, groups=(0,)):
+def reconcile(models, groups=(0,), dense=False):
     """g4r_comm_sync_sparse without RCCL: every handle exports the rows it rewrote since the last call, every handle imports all
-    parts in rank order; the replicas are bit-identical afterwards."""
+    parts in rank order; the replicas are bit-identical afterwards.  dense=True: the all-device form the library uses for small item
+    tables (g4r_virtual_sync_dense; returns 0 rows, it never counts them)."""
+    if dense:
+        _native.virtual_sync_dense(models)
+        return 0
     rows = 0
     for g in groups:
         parts = [m.sync_export(g) for m in models]

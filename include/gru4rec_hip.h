@@ -210,6 +210,9 @@ int g4r_sync_import(g4r_model* m, int32_t group, int32_t nparts, const int64_t* 
  * are reconciled by the caller (g4r_sync_export / g4r_sync_import).  For validating the N > 1 training semantics -- e.g.
  * Recall@20 of 2 / 8 ranks against 1 (evaluation.py:62-75) -- on a one-GPU box; not a fast path. */
 int g4r_virtual_train_steps(g4r_model* const* ms, int32_t n, int64_t t0, int64_t n_steps);
+/* the dense form of g4r_comm_sync_sparse (item tables of up to G4R_SYNC_DENSE_MB = 64 MB per group: [n_items][plane widths + 1]
+ * delta buffers packed, summed and applied on the device) with the sum taken in process over n handles of one device */
+int g4r_virtual_sync_dense(g4r_model* const* ms, int32_t n);
 int g4r_comm_min_i64(g4r_model* m, int64_t* value);            /* in-place min over ranks */
 int g4r_comm_max_i64(g4r_model* m, int64_t* value);            /* in-place max over ranks: the common plan length (shorter plans are
                                                                   padded with M = 0 steps so that every rank issues the same all-reduces) */

@@ -134,3 +134,62 @@ def test_item_table_reconciliation_with_two_handles(name, rule):
             assert all(len(m.sync_export(g)[0]) == 0 for m in ms)
     for m in ms:
         m.close()
+
+
+@pytest.mark.parametrize('name', ['bprmax_mom_drop', 'xe_sep_embed'])
+def test_dense_reconciliation_equals_the_part_exchange(name):
+    """Small item tables are reconciled entirely on the device (g4r_comm_sync_sparse: pack [n_items][plane widths + 1] deltas -> one
+    all-reduce -> apply; here the all-reduce is the in-process sum of g4r_virtual_sync_dense).  Against the packed-parts exchange of
+    the same two ranks: the same values up to the rounding of base + (d0 + d1) / c vs (base + d0 / c) + d1 / c, replicas bit-identical,
+    untouched rows keep their bits, the touched bytes are cleared (nothing left to export), a second round starts from the new base."""
+    kw = dict(CASES[name])
+    I, B, ns, T = 900, 12, 24, 30      # 1440 negative draws over 900 items: some rows stay untouched
+    D = kw['layers'][-1]
+    pairs = {}
+    for way in ('parts', 'dense'):
+        ms = []
+        for r in range(2):
+            _, m = make_pair(I, B, ns, store_rows=200, use_graph=1, **dict(kw))
+            m.sync_enable()
+            ms.append(m)
+        pairs[way] = ms
+    names = [('Wy', (I, D)), ('acc_Wy', (I, D)), ('By', (I,)), ('acc_By', (I,))]
+    if kw.get('momentum', 0) > 0:
+        names += [('vel_Wy', (I, D))]
+    groups = [0]
+    if not kw.get('constrained_embedding', False):
+        names += [('E', (I, kw['embedding'])), ('acc_E', (I, kw['embedding']))]
+        groups = [0, 1]
+    for rnd in range(2):
+        before = {n: pairs['dense'][0].get_param(n, sh) for n, sh in names}
+        for way, ms in pairs.items():
+            for r, m in enumerate(ms):
+                plan = random_plan(I // 2, B, T, seed=100 + 10 * rnd + r)
+                if r == 1:
+                    plan['in_idx'] += I // 3
+                    plan['out_idx'] += I // 3
+                m.set_plan(plan)
+                m.train_steps(0, T)
+        touched = np.zeros(I, dtype=bool)
+        for g in groups:
+            parts = [m.sync_export(g) for m in pairs['parts']]
+            if g == 0:
+                for p in parts:
+                    touched[p[0]] = True
+            for m in pairs['parts']:
+                m.sync_import(parts, g)
+        _native.virtual_sync_dense(pairs['dense'])
+        for n, sh in names:
+            a, b = pairs['dense'][0].get_param(n, sh), pairs['dense'][1].get_param(n, sh)
+            np.testing.assert_array_equal(a, b)
+            want = pairs['parts'][0].get_param(n, sh)
+            # round 0: one rounding of the combine; round 1 starts from bases that differ by that rounding and trains 30 more steps on it
+            np.testing.assert_allclose(a, want, rtol=2e-6, atol=1e-7 if rnd == 0 else 2e-5)
+            if n in ('Wy', 'acc_Wy', 'By', 'acc_By'):
+                np.testing.assert_array_equal(a.reshape(I, -1)[~touched], before[n].reshape(I, -1)[~touched])
+                assert touched.any() and (~touched).any()
+        for g in groups:
+            assert all(len(m.sync_export(g)[0]) == 0 for m in pairs['dense'])
+    for ms in pairs.values():
+        for m in ms:
+            m.close()
