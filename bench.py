@@ -217,7 +217,7 @@ def main():
     # per-kernel durations behind the timed region: every rank runs those steps (the all-reduce is collective), rank 0 reports
     n_profile = args.profile_steps
     n_long = args.long_steps if (0 < args.steps < args.long_steps) else 0
-    total_steps = args.warmup + args.steps + n_long + n_profile + 8 + 64
+    total_steps = args.warmup + args.steps + n_long + n_profile + 8 + 64 + (min(args.steps, 2000) if (world > 1 or os.environ.get('G4R_FORCE_STAGED')) else 0)
     plan, support = make_plan(cfg, total_steps, rank, world)
     assert plan['T'] >= total_steps, 'synthetic plan too short: %d < %d' % (plan['T'], total_steps)
     assert (plan['M'][:total_steps] == cfg['batch_size']).all()
@@ -308,11 +308,27 @@ def main():
                 t2 = time.perf_counter()
                 m.comm_sync_sparse()
                 t_sync.append(time.perf_counter() - t2)
+            measured = None
+            n_rec = min(args.steps, 2000) // K * K
+            if t_sync and n_rec >= K and spare - reps * K >= n_rec and m.set_sync_every(K):
+                # small item tables: the library reconciles inside g4r_train_steps (every K steps, on the stream) -- time that directly
+                t_rec0 = base_t + reps * K
+                barrier()
+                t3 = time.perf_counter()
+                m.train_steps(t_rec0, n_rec)
+                d_rec = time.perf_counter() - t3
+                barrier()
+                if world > 1:
+                    d_rec = launch.max_over_ranks_us(m, d_rec)
+                m.set_sync_every(0)
+                measured = {'steps': n_rec, 'value': n_rec * world / d_rec, 'ms_per_step': 1000.0 * d_rec / n_rec,
+                            'reconciliations_inside': int(m.get_debug('dev_syncs', (1,))[0])}
             if t_sync:
                 ms = 1000.0 * (launch.max_over_ranks_us(m, min(t_sync)) if world > 1 else min(t_sync))
                 step_ms = 1000.0 * dt / args.steps
                 reconcile = {'sync_every': K, 'ms_per_reconciliation': ms, 'ms_per_step_amortised': ms / K,
                              'value_with_reconciliation': args.steps * world / (dt + args.steps * ms / K / 1000.0),
+                             'measured_with_reconciliation_inside_train_steps': measured,
                              'note': 'g4r_comm_sync_sparse over the item rows %d steps touch (best of %d, max over ranks); fit() runs one every %d '
                                      'steps: step %.4f ms + %.4f ms amortised' % (K, len(t_sync), K, step_ms, ms / K)}
         except Exception as e:      # the reconciliation must not take the step measurement down with it

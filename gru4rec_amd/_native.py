@@ -43,7 +43,7 @@ SYMBOLS = [
     'g4r_sample_store_rows', 'g4r_build_plan', 'g4r_set_plan', 'g4r_train_steps', 'g4r_get_losses',
     'g4r_synchronize', 'g4r_global_step', 'g4r_refills', 'g4r_set_step_counters', 'g4r_kernel_time', 'g4r_profile', 'g4r_reset_hidden',
     'g4r_predict_begin', 'g4r_predict_hidden', 'g4r_predict_step', 'g4r_rank_targets', 'g4r_evaluate', 'g4r_comm_unique_id',
-    'g4r_comm_init', 'g4r_virtual_train_steps', 'g4r_virtual_sync_dense', 'g4r_comm_sync_sparse', 'g4r_sync_set_rule', 'g4r_comm_min_i64', 'g4r_comm_max_i64', 'g4r_comm_nranks', 'g4r_sync_enable', 'g4r_sync_row_floats', 'g4r_sync_export', 'g4r_sync_import', 'g4r_get_debug', 'g4r_selftest_mfma', 'g4r_bench_rows',
+    'g4r_comm_init', 'g4r_virtual_train_steps', 'g4r_virtual_sync_dense', 'g4r_comm_sync_sparse', 'g4r_sync_set_rule', 'g4r_set_sync_every', 'g4r_comm_min_i64', 'g4r_comm_max_i64', 'g4r_comm_nranks', 'g4r_sync_enable', 'g4r_sync_row_floats', 'g4r_sync_export', 'g4r_sync_import', 'g4r_get_debug', 'g4r_selftest_mfma', 'g4r_bench_rows',
     'g4r_events_load', 'g4r_events_rows', 'g4r_events_items', 'g4r_events_item_bytes', 'g4r_events_time_kind',
     'g4r_events_copy', 'g4r_events_free',
 ]
@@ -104,6 +104,7 @@ def lib():
     L.g4r_virtual_train_steps.argtypes = [C.POINTER(vp), i32, i64, i64]
     L.g4r_virtual_sync_dense.argtypes = [C.POINTER(vp), i32]
     L.g4r_sync_set_rule.argtypes = [vp, i32, i32]
+    L.g4r_set_sync_every.argtypes = [vp, i32]
     L.g4r_comm_min_i64.argtypes = [vp, i64p]
     L.g4r_comm_max_i64.argtypes = [vp, i64p]
     L.g4r_comm_nranks.argtypes = [vp]
@@ -390,6 +391,14 @@ class Model:
 
     def sync_enable(self):
         _chk(lib().g4r_sync_enable(self.h))
+
+    def set_sync_every(self, k):
+        """True when g4r_train_steps reconciles the item tables itself every k steps (small tables, g4r_set_sync_every); False when
+        the caller has to call comm_sync_sparse."""
+        rc = lib().g4r_set_sync_every(self.h, int(k))
+        if rc < 0:
+            raise NativeError(lib().g4r_last_error().decode())
+        return rc == 1
 
     def sync_set_rule(self, param_rule, stat_rule):
         """'sum' / 'mean' for the parameter planes and for the optimizer-statistic planes of the reconciliation (g4r_sync_set_rule)."""

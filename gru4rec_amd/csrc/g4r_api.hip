@@ -121,6 +121,8 @@ struct g4r_model {
     int sync_rule[2] = {G4R_SYNC_MEAN, G4R_SYNC_SUM};      // combine rule of the parameter planes / of the statistic planes
     unsigned char* d_touched = nullptr;
     unsigned char* d_rowcnt = nullptr;           // [n_items] scratch: number of parts that hold a row (MEAN rule)
+    int sync_every_dev = 0;                      // > 0: g4r_train_steps reconciles the (dense-form) item tables itself every that many steps
+    int64_t since_sync = 0, n_dev_syncs = 0;
     float* d_dense[2] = {nullptr, nullptr};      // dense reconciliation buffers [n_items][sum of plane widths + 1] per table group (small catalogues)
     bool sync_on = false;
 };
@@ -666,6 +668,7 @@ int64_t g4r_build_plan(const int32_t* off, int64_t n_sessions, const int64_t* or
 
 static int ensure_graph(g4r_model* m);
 static int ensure_head_graph(g4r_model* m);
+static int sync_dense_enqueue(g4r_model* m);
 static int ensure_step_graph(g4r_model* m, bool* whole);
 
 int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, const uint8_t* reset, const int32_t* M,
@@ -1001,8 +1004,14 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
             if (refill_store(m)) return -1;      // gru4rec.py:618-620
             hipLaunchKernelGGL(k_restage_inputs, dim3(1), dim3(512), 0, m->stream, (const DevModel*)m->d_dm, (StepState*)m->dm.st);
         }
+        const bool devsync = m->sync_every_dev > 0 && m->comm_ready;
+        if (devsync && m->since_sync >= m->sync_every_dev) {
+            if (sync_dense_enqueue(m)) return -1;
+            ++m->n_dev_syncs;
+        }
         // steps until the next event
         int64_t run = tend - t;
+        if (devsync) run = std::min<int64_t>(run, m->sync_every_dev - m->since_sync);
         if (ci < m->compact_steps.size()) run = std::min(run, m->compact_steps[ci] - t);
         if (m->dm.ns > 0 && !m->store_frozen) run = std::min<int64_t>(run, m->gl - (m->gstep % m->gl));
         if (run <= 0) return fail("internal: empty run");
@@ -1034,6 +1043,7 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
         }
         t += run;
         m->gstep += run;
+        m->since_sync += run;
     }
     HIPCHK(hipStreamSynchronize(m->stream));
     return 0;
@@ -1679,6 +1689,36 @@ int g4r_virtual_sync_dense(g4r_model* const* ms, int32_t n) {
     return 0;
 }
 
+// every table group of this model takes the dense form
+static bool sync_all_dense(const g4r_model* m) {
+    if (!m->sync_on) return false;
+    for (int g = 0; g < 2; ++g) if (!m->planes[g].empty() && !m->d_dense[g]) return false;
+    return true;
+}
+// pack -> all-reduce -> apply for every group, enqueued on the model's stream (no host synchronisation)
+static int sync_dense_enqueue(g4r_model* m) {
+    for (int g = 0; g < 2; ++g) {
+        if (m->planes[g].empty()) continue;
+        const SyncPlanes p = sync_planes_of(m, g);
+        sync_dense_pack(m, g);
+        NCCLCHK(ncclAllReduce(m->d_dense[g], m->d_dense[g], (size_t)m->dm.n_items * (p.wsum + 1), ncclFloat, ncclSum, m->comm, m->stream));
+        sync_dense_apply(m, g);
+    }
+    m->since_sync = 0;
+    return 0;
+}
+// k > 0: g4r_train_steps itself reconciles the item tables every k steps (counted across calls), between two steps, without leaving
+// the stream -- only where every table takes the dense form and a communicator exists.  Returns 1 when accepted, 0 when the caller has
+// to call g4r_comm_sync_sparse itself (large tables), < 0 on error.  k = 0 switches it off.
+int g4r_set_sync_every(g4r_model* m, int32_t k) {
+    if (!m || k < 0) return fail("bad argument");
+    m->sync_every_dev = 0;
+    if (k == 0) return 0;
+    if (!m->comm_ready || !sync_all_dense(m)) return 0;
+    m->sync_every_dev = k;
+    return 1;
+}
+
 // RCCL path: id lists all-gathered once per group, then the table is walked in item-id ranges; per range every rank packs its
 // delta rows, one all-gather (padded to the largest part of the range) brings all parts, sync_apply adds them in rank order.
 // The traffic follows the number of touched rows, not the table size.
@@ -1782,6 +1822,7 @@ int g4r_comm_sync_sparse(g4r_model* m) {
         HIPCHK(hipMemsetAsync(m->d_touched + (size_t)group * I, 0, I, s));
     }
     HIPCHK(hipStreamSynchronize(s));
+    m->since_sync = 0;
     return 0;
 }
 
@@ -1820,6 +1861,7 @@ int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
     else if (s == "ldSc") { if (count < 1) return fail("count"); host[0] = (float)d.ldSc; return 0; }
     else if (s == "ksplit") { if (count < 1) return fail("count"); host[0] = (float)d.ksplit; return 0; }
     else if (s == "streamk_workers") { if (count < 1) return fail("count"); host[0] = (float)m->sk_W; return 0; }
+    else if (s == "dev_syncs") { if (count < 1) return fail("count"); host[0] = (float)m->n_dev_syncs; return 0; }
     else if (s == "dense_count") { if (count < 1) return fail("count"); host[0] = (float)d.dense_count; return 0; }
     else if (s == "occ_score_tile") {      // resident workgroups per CU the runtime reports for the gemm_tile2 scoring kernel
         if (count < 1) return fail("count");

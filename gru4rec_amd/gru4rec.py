@@ -580,9 +580,12 @@ class GRU4Rec:
         costs = np.empty(T, dtype=np.float32)
         done = 0
         since_sync = 0
+        # small item tables are reconciled inside the library (every sync_every steps, between two steps, on the stream); otherwise
+        # the calls are cut at those points and g4r_comm_sync_sparse runs in between
+        host_sync = bool(self._dist and self.sync_every) and not m.set_sync_every(int(self.sync_every))
         while done < T:
             n = min(self.steps_per_call, T - done)
-            if self._dist and self.sync_every:
+            if host_sync:
                 n = min(n, int(self.sync_every) - since_sync)      # every rank cuts at the same steps: plans have one common length
             if self._cpu_store:
                 # host sample store: the row pointer is the global step modulo the store length; a new store is drawn when it
@@ -603,7 +606,7 @@ class GRU4Rec:
                 return None
             done += n
             since_sync += n
-            if self._dist and self.sync_every and since_sync >= int(self.sync_every) and done < T:
+            if host_sync and since_sync >= int(self.sync_every) and done < T:
                 m.comm_sync_sparse()
                 since_sync = 0
         cc = plan['M'][:T]

@@ -213,6 +213,10 @@ int g4r_virtual_train_steps(g4r_model* const* ms, int32_t n, int64_t t0, int64_t
 /* the dense form of g4r_comm_sync_sparse (item tables of up to G4R_SYNC_DENSE_MB = 64 MB per group: [n_items][plane widths + 1]
  * delta buffers packed, summed and applied on the device) with the sum taken in process over n handles of one device */
 int g4r_virtual_sync_dense(g4r_model* const* ms, int32_t n);
+/* k > 0: g4r_train_steps reconciles the item tables itself every k steps (counted across calls), between two steps and without
+ * leaving the stream -- where every table takes the dense form and a communicator exists: returns 1; returns 0 when the caller has to
+ * call g4r_comm_sync_sparse itself (tables too large for the dense form); k = 0 switches it off. */
+int g4r_set_sync_every(g4r_model* m, int32_t k);
 int g4r_comm_min_i64(g4r_model* m, int64_t* value);            /* in-place min over ranks */
 int g4r_comm_max_i64(g4r_model* m, int64_t* value);            /* in-place max over ranks: the common plan length (shorter plans are
                                                                   padded with M = 0 steps so that every rank issues the same all-reduces) */

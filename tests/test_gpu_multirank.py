@@ -193,3 +193,30 @@ def test_dense_reconciliation_equals_the_part_exchange(name):
     for ms in pairs.values():
         for m in ms:
             m.close()
+
+
+def test_reconciliation_inside_train_steps_with_a_one_rank_communicator(monkeypatch):
+    """g4r_set_sync_every: small item tables are reconciled by g4r_train_steps itself every k steps (pack -> all-reduce -> apply on the
+    stream, between two steps, counted across calls).  One rank: the reconciliation is the identity up to the rounding of
+    base + (value - base), so the run must track the one without it, the counter must show a reconciliation at every k-th step, and
+    nothing may be left to export afterwards."""
+    monkeypatch.setenv('G4R_FORCE_STAGED', '1')
+    kw = CASES['bprmax_mom_drop']
+    I, B, ns, T = 200, 12, 24, 40
+    plan = random_plan(I, B, T, seed=23)
+    outs = []
+    for k in (0, 8):
+        _, m = make_pair(I, B, ns, store_rows=200, use_graph=1, **dict(kw))
+        m.comm_init(_native.comm_unique_id(), 1, 0)
+        assert m.set_sync_every(k) == (k > 0)
+        m.set_plan(plan)
+        m.train_steps(0, 25)
+        m.train_steps(25, T - 25)          # the count runs across calls: 8, 16, 24 | 32 (the one due at 40 waits for the next step)
+        if k:
+            assert int(m.get_debug('dev_syncs', (1,))[0]) == 4
+            m.comm_sync_sparse()
+            assert len(m.sync_export(0)[0]) == 0
+        outs.append((m.get_losses(0, T), m.get_param('Wy', (I, 16)), m.get_param('acc_Wy', (I, 16)), m.get_param('Wx', (16, 48), 0)))
+        m.close()
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-6)

@@ -89,8 +89,9 @@ def test_epoch_loop_terminates_and_cuts_at_the_reconciliation_points(monkeypatch
         assert st['syncs'] == 0
 
 
+@pytest.mark.parametrize('dev', [False, True])
 @pytest.mark.parametrize('sync_every,steps_per_call,T', [(16, 16384, 50), (4, 7, 23), (0, 10, 23), (16, 5, 16)])
-def test_run_epoch_reconciles_every_sync_every_steps_on_every_rank(sync_every, steps_per_call, T):
+def test_run_epoch_reconciles_every_sync_every_steps_on_every_rank(sync_every, steps_per_call, T, dev):
     """GRU4Rec.run_epoch with a (fake) communicator: C-ABI calls are cut at the reconciliation points, g4r_comm_sync_sparse runs every
     `sync_every` steps (never behind the last step: fit() reconciles at the epoch end itself), the NaN exits stay collective."""
     from gru4rec_amd.gru4rec import GRU4Rec
@@ -107,6 +108,10 @@ def test_run_epoch_reconciles_every_sync_every_steps_on_every_rank(sync_every, s
         def comm_sync_sparse(self):
             self.syncs.append(sum(n for _, n in self.calls))
 
+        def set_sync_every(self, k):
+            self.dev_k = k
+            return dev
+
     g = GRU4Rec(layers=[8], batch_size=8, n_sample=0, constrained_embedding=True)
     g.sync_every, g.steps_per_call = sync_every, steps_per_call
     g._dist = dict(rank=0, nranks=2, unique_id=b'x')
@@ -118,6 +123,9 @@ def test_run_epoch_reconciles_every_sync_every_steps_on_every_rank(sync_every, s
     assert g.run_epoch(0) is not None
     m = g._model
     assert sum(n for _, n in m.calls) == T and all(n <= steps_per_call for _, n in m.calls)
-    want = [k for k in range(sync_every, T, sync_every)] if sync_every else []
+    # (dev: the library reconciles small tables itself inside g4r_train_steps -- the host then neither cuts its calls nor syncs)
+    want = [k for k in range(sync_every, T, sync_every)] if (sync_every and not dev) else []
     assert m.syncs == want
+    if sync_every:
+        assert m.dev_k == sync_every
     assert m.maxes == len(m.calls) + 1            # one collective NaN check per call + one for the epoch loss
