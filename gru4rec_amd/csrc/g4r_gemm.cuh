@@ -483,58 +483,76 @@ __device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, 
     // B = 512, N = 8704, D = 256 64.6 vs 64.2 us, with 1024 tiles 59.5 vs 60.6: each role alone is bound by how evenly its 64 x 64 x 512
     // tiles (7.8 us of MFMA each) spread over the CUs, not by the staging; (b) three register sets with the loads of chunk i + 2 issued in iteration i -- the compiler's waitcnt
     // placement still drains to the newest load before every commit, and the extra registers cost a workgroup per CU: 68.5 vs 64.5 us)
-    float4 ra, rb;
-    const GAS float* qa = nullptr;
-    const GAS float* qb = nullptr;
-    auto issue = [&](int kk) {
-        if constexpr (A_KM) { qa = aprov(kk, kr, kc); ra = ld4(qa ? qa : safe); }
-        else { ra = ld4(pa); if (oka) pa += BK; }
-        qb = bprov(kk, kr, kc);
-        rb = ld4(qb ? qb : safe);
+    // Operand chunks travel global -> registers -> LDS with the loads TWO chunks ahead of the MFMAs (round 3): two register sets, the
+    // loads written as asm so that the waits are ours -- `s_waitcnt vmcnt(2)` leaves the newest chunk's two loads in flight while the
+    // older chunk is written to LDS (loads return in order).  With compiler-issued loads every commit drained to the newest load
+    // (round 2, (b) above), i.e. the gathered rows of the dh slabs arrived one 16-deep chunk (~1 us of MFMAs) ahead of use, less than
+    // their latency.  The sets are addressed by compile-time constants (the K loop is unrolled by two): no register indexing.
+    f32x4 ra0, rb0, ra1, rb1;
+    bool oa0 = false, ob0 = false, oa1 = false, ob1 = false;
+    auto ldasm = [](const GAS float* p) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory"); return v; };
+    auto issue = [&](int kk, f32x4& ra, f32x4& rb, bool& oa, bool& ob) {
+        if constexpr (A_KM) { const GAS float* a_ = aprov(kk, kr, kc); oa = a_ != nullptr; ra = ldasm(a_ ? a_ : safe); }
+        else { oa = oka; ra = ldasm(pa); if (oka) pa += BK; }
+        const GAS float* b_ = bprov(kk, kr, kc);
+        ob = b_ != nullptr;
+        rb = ldasm(b_ ? b_ : safe);
     };
-    // (component-wise selects: a ternary on the float4 struct was compiled to a select between two scratch copies)
-    auto mask4 = [](float4 v, bool ok) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, const f32x4& ra, const f32x4& rb, bool oa, bool ob) {
+        const float4 va = make_float4(oa ? ra[0] : 0.f, oa ? ra[1] : 0.f, oa ? ra[2] : 0.f, oa ? ra[3] : 0.f);
+        const float4 vb = make_float4(ob ? rb[0] : 0.f, ob ? rb[1] : 0.f, ob ? rb[2] : 0.f, ob ? rb[3] : 0.f);
         if constexpr (A_KM) {
-            *reinterpret_cast<float4*>(smem + buf * BUF + kofs) = mask4(ra, qa != nullptr);
+            *reinterpret_cast<float4*>(smem + buf * BUF + kofs) = va;
         } else {
-            const float4 va = mask4(ra, oka);
             float2* da = reinterpret_cast<float2*>(smem + buf * BUF + sr * BK + (sc ^ (sw_st & ~3)));
             da[(sw_st >> 1) & 1] = make_float2(va.x, va.y); da[((sw_st >> 1) & 1) ^ 1] = make_float2(va.z, va.w);
         }
-        *reinterpret_cast<float4*>(smem + (2 + buf) * BUF + kofs) = mask4(rb, qb != nullptr);
+        *reinterpret_cast<float4*>(smem + (2 + buf) * BUF + kofs) = vb;
     };
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
     const int sw_fr = 2 * ((l32 >> 2) & 7);             // K-contiguous A: swizzle of this lane's fragment row
     const int nchunk = (K + BK - 1) / BK;
-    issue(0);
+    issue(0, ra0, rb0, oa0, ob0);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(rb0) :: "memory");      // chunk 0 (its latency is exposed either way)
+    if (nchunk > 1) issue(BK, ra1, rb1, oa1, ob1);
     const int n = n0 + wn * 32 + l32;
     constexpr int NPF = PRE_COL ? 1 : 16;
     float4 pf[NPF];
 #pragma unroll
     for (int j = 0; j < NPF; ++j) pf[j] = pre(m0 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3), n);
-    commit(0);
+    commit(0, ra0, rb0, oa0, ob0);
     if (trc && tid == 0) trc[2] = wall_clock64();
-    for (int i = 0; i < nchunk; ++i) {
+    // one K chunk out of LDS buffer `buf`: fragments, then the loads of the chunk after next, then the MFMAs
+    auto chunk = [&](int buf, int i, f32x4& ra, f32x4& rb, bool& oa, bool& ob) {
         __syncthreads();
-        const float* fa = A_KM ? smem + (i & 1) * BUF + lh * 64 + ((wm * 32 + l32) ^ (32 * lh))
-                               : smem + (i & 1) * BUF + (wm * 32 + l32) * BK + lh;
-        const float* fb = smem + (2 + (i & 1)) * BUF + lh * 64 + ((wn * 32 + l32) ^ (32 * lh));
+        const float* fa = A_KM ? smem + buf * BUF + lh * 64 + ((wm * 32 + l32) ^ (32 * lh))
+                               : smem + buf * BUF + (wm * 32 + l32) * BK + lh;
+        const float* fb = smem + (2 + buf) * BUF + lh * 64 + ((wn * 32 + l32) ^ (32 * lh));
         float av[8], bv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             av[u] = A_KM ? fa[128 * u] : fa[(2 * u) ^ sw_fr];
             bv[u] = fb[128 * u];
         }
-        const bool more = i + 1 < nchunk;
-        if (more) issue((i + 1) * BK);
+        if (i + 2 < nchunk) issue((i + 2) * BK, ra, rb, oa, ob);      // into the set chunk i was committed from
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc = mfma32(av[u], bv[u], acc);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) commit((i + 1) & 1);
+    };
+    for (int i = 0; i < nchunk; i += 2) {
+        chunk(0, i, ra0, rb0, oa0, ob0);
+        if (i + 1 >= nchunk) break;
+        if (i + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" : "+v"(ra1), "+v"(rb1) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra1), "+v"(rb1) :: "memory");
+        commit(1, ra1, rb1, oa1, ob1);
+        chunk(1, i + 1, ra1, rb1, oa1, ob1);
+        if (i + 2 >= nchunk) break;
+        if (i + 3 < nchunk) asm volatile("s_waitcnt vmcnt(2)" : "+v"(ra0), "+v"(rb0) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(rb0) :: "memory");
+        commit(0, ra0, rb0, oa0, ob0);
     }
     if (trc && tid == 0) trc[3] = wall_clock64();
 #pragma unroll

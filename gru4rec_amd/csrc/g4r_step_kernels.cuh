@@ -1181,7 +1181,10 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
 //   B  [nblkA, nblkA + nblkB)   split-K slab kc of dh = ds Sy (ds K-contiguous, gathered Wy rows K-major)
 //   C  the rest                 dSBy = column sums of ds over the batch for 64 columns (the ones column of k_score_bwd's role A
 //                               costs a fifth d tile at D = 256), Adagrad-scaled like role A's epilogue
-__global__ __launch_bounds__(256) void k_score_bwd2(const DevModel* __restrict__ mp, StepState* st, int nblkA, int nblkB, int ndt, int nrt) {
+#ifndef G4R_BWD2_WPE
+#define G4R_BWD2_WPE 4
+#endif
+__global__ __launch_bounds__(256, G4R_BWD2_WPE) void k_score_bwd2(const DevModel* __restrict__ mp, StepState* st, int nblkA, int nblkB, int ndt, int nrt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const StepCtx c = load_ctx(st);
