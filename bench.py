@@ -339,6 +339,7 @@ def main():
         out['multi_gpu'] = {
             'ncclCommCount': n_ranks, 'rank_ms_per_step': [1000.0 * x / args.steps for x in rank_dts],
             'rccl_allreduce_us': us('rccl_allreduce'), 'k_dense_apply_us': us('k_dense_apply'),
+            'allreduce': 'p2p one-shot (k_p2p_allreduce, G4R_P2P=1)' if m.p2p_active() else 'rccl',
             'dense_gradient_bytes': 4 * int(m.get_debug('dense_count', (1,))[0]),
             'step_graph_holds_allreduce': bool(m.get_debug('graph_mode', (1,))[0] == 1.0),
             'kernel_us_rank0': {k: 1000.0 * v[0] / max(v[1], 1) for k, v in kt.items()}, 'reconciliation': reconcile,

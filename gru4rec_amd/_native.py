@@ -43,7 +43,7 @@ SYMBOLS = [
     'g4r_sample_store_rows', 'g4r_build_plan', 'g4r_set_plan', 'g4r_train_steps', 'g4r_get_losses',
     'g4r_synchronize', 'g4r_global_step', 'g4r_refills', 'g4r_set_step_counters', 'g4r_kernel_time', 'g4r_profile', 'g4r_reset_hidden',
     'g4r_predict_begin', 'g4r_predict_hidden', 'g4r_predict_step', 'g4r_rank_targets', 'g4r_evaluate', 'g4r_comm_unique_id',
-    'g4r_comm_init', 'g4r_virtual_train_steps', 'g4r_virtual_sync_dense', 'g4r_comm_sync_sparse', 'g4r_sync_set_rule', 'g4r_set_sync_every', 'g4r_comm_min_i64', 'g4r_comm_max_i64', 'g4r_comm_nranks', 'g4r_sync_enable', 'g4r_sync_row_floats', 'g4r_sync_export', 'g4r_sync_import', 'g4r_get_debug', 'g4r_selftest_mfma', 'g4r_bench_rows',
+    'g4r_comm_init', 'g4r_virtual_train_steps', 'g4r_virtual_sync_dense', 'g4r_comm_sync_sparse', 'g4r_sync_set_rule', 'g4r_set_sync_every', 'g4r_comm_min_i64', 'g4r_comm_max_i64', 'g4r_comm_nranks', 'g4r_p2p_enable', 'g4r_p2p_export', 'g4r_p2p_attach', 'g4r_p2p_active', 'g4r_sync_enable', 'g4r_sync_row_floats', 'g4r_sync_export', 'g4r_sync_import', 'g4r_get_debug', 'g4r_selftest_mfma', 'g4r_bench_rows',
     'g4r_events_load', 'g4r_events_rows', 'g4r_events_items', 'g4r_events_item_bytes', 'g4r_events_time_kind',
     'g4r_events_copy', 'g4r_events_free',
 ]
@@ -108,6 +108,10 @@ def lib():
     L.g4r_comm_min_i64.argtypes = [vp, i64p]
     L.g4r_comm_max_i64.argtypes = [vp, i64p]
     L.g4r_comm_nranks.argtypes = [vp]
+    L.g4r_p2p_enable.argtypes = [vp]
+    L.g4r_p2p_export.argtypes = [vp, C.c_char_p]
+    L.g4r_p2p_attach.argtypes = [vp, C.c_char_p, i32, i32]
+    L.g4r_p2p_active.argtypes = [vp]
     L.g4r_sync_enable.argtypes = [vp]
     L.g4r_sync_row_floats.argtypes, L.g4r_sync_row_floats.restype = [vp, i32], i64
     L.g4r_sync_export.argtypes, L.g4r_sync_export.restype = [vp, i32, i32p, f32p, i64], i64
@@ -388,6 +392,26 @@ class Model:
 
     def comm_sync_sparse(self):
         _chk(lib().g4r_comm_sync_sparse(self.h))
+
+    def p2p_enable(self):
+        """The step's dense-gradient all-reduce through peer memory instead of RCCL (g4r_p2p_enable; collective)."""
+        _chk(lib().g4r_p2p_enable(self.h))
+
+    def p2p_export(self):
+        """This rank's 64-byte IPC handle of its exchange region (g4r_p2p_export)."""
+        buf = C.create_string_buffer(64)
+        _chk(lib().g4r_p2p_export(self.h, buf))
+        return buf.raw
+
+    def p2p_attach(self, handles, nranks, rank):
+        """handles: the ranks' 64-byte handles in rank order (g4r_p2p_attach)."""
+        blob = b''.join(handles)
+        if len(blob) != 64 * nranks:
+            raise ValueError('p2p_attach: %d handles of 64 bytes expected' % nranks)
+        _chk(lib().g4r_p2p_attach(self.h, blob, nranks, rank))
+
+    def p2p_active(self):
+        return bool(lib().g4r_p2p_active(self.h))
 
     def sync_enable(self):
         _chk(lib().g4r_sync_enable(self.h))

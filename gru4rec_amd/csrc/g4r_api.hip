@@ -112,6 +112,14 @@ struct g4r_model {
     // rccl
     ncclComm_t comm = nullptr;
     bool comm_ready = false;
+    // one-shot all-reduce of the dense gradients through peer memory (g4r_p2p_*): this rank's exchange region, the peers' regions
+    // as mapped here (IPC), the kernel's argument block
+    bool p2p_ready = false;
+    void* p2p_region = nullptr;
+    void* p2p_peer[G4R_P2P_MAX] = {nullptr};
+    unsigned* p2p_round = nullptr;
+    int p2p_nblk = 0, p2p_cap = 0;
+    P2PArgs p2p_args;
     bool virtual_ranks = false;                  // member of a g4r_virtual_train_steps group: the dense gradients are summed in process
     float* d_vsum = nullptr;                     // scratch of that sum (first member of the group)
     // reconciliation of the GPU-local item tables (g4r_sync_kernels.cuh): per table group (0: Wy / By rows, 1: E rows) the
@@ -491,6 +499,8 @@ void g4r_destroy(g4r_model* m) {
     if (m->gexec_small) (void)hipGraphExecDestroy(m->gexec_small);
     if (m->gexec_head) (void)hipGraphExecDestroy(m->gexec_head);
     if (m->comm_ready) (void)ncclCommDestroy(m->comm);
+    for (void* q : m->p2p_peer) if (q) (void)hipIpcCloseMemHandle(q);
+    if (m->p2p_region) (void)hipFree(m->p2p_region);
     for (auto e : m->evs) (void)hipEventDestroy(e);
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
@@ -708,7 +718,7 @@ int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
     if (sync_dm(m)) return -1;
     // capture + instantiate the step graph now (capturing executes nothing): the first timed steps of a short run must not
     // pay the ~10 ms of graph construction
-    if (m->cfg.use_graph && !m->profiling && !getenv("G4R_TRACE") && (m->dm.apply_dense_inplace || m->comm_ready)) {
+    if (m->cfg.use_graph && !m->profiling && !getenv("G4R_TRACE") && (m->dm.apply_dense_inplace || m->comm_ready || m->p2p_ready)) {
         bool whole = false;
         if (ensure_step_graph(m, &whole)) return -1;
         hipGraphExec_t ge = whole ? m->gexec : m->gexec_head;
@@ -849,17 +859,18 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     // (measured on one MI355X with a one-rank communicator: the two cross-stream event dependencies cost ~20 us per
     // step, more than the ~11 us of sparse update they can hide, so the overlap is opt-in: G4R_OVERLAP=1)
     static const bool want_overlap = getenv("G4R_OVERLAP") != nullptr;
-    const bool overlap = !d.apply_dense_inplace && !recs && !trace && want_overlap && !d.generic && !merged && (m->cfg.nranks > 1 || m->comm_ready);
+    const bool overlap = !d.apply_dense_inplace && !recs && !trace && want_overlap && !d.generic && !merged && !m->p2p_ready && (m->cfg.nranks > 1 || m->comm_ready);
     if (!d.apply_dense_inplace) {
         // staged dense path: (RCCL all-reduce when there are ranks) -> (global gradient norm -> clip factor, generic path with
         // grad_cap) -> dense rule on the flat gradient buffer
-        const bool dist = !m->virtual_ranks && (m->cfg.nranks > 1 || m->comm_ready);
-        if (m->cfg.nranks > 1 && !m->comm_ready && !m->virtual_ranks) return fail("nranks > 1 but g4r_comm_init was not called");
+        const bool dist = !m->virtual_ranks && (m->cfg.nranks > 1 || m->comm_ready || m->p2p_ready);
+        if (m->cfg.nranks > 1 && !m->comm_ready && !m->p2p_ready && !m->virtual_ranks) return fail("nranks > 1 but g4r_comm_init was not called");
         hipStream_t cs = overlap ? m->comm_stream : s;
         if (dist) {
             if (overlap) { HIPCHK(hipEventRecord(m->ev_fork, s)); HIPCHK(hipStreamWaitEvent(cs, m->ev_fork, 0)); }
             if (!overlap) { begin(KN_ALLREDUCE); if (recs) (void)hipEventRecord(cur_a, cs); }
-            NCCLCHK(ncclAllReduce(d.dense_g, d.dense_g, d.dense_count, ncclFloat, ncclSum, m->comm, cs));
+            if (m->p2p_ready) hipLaunchKernelGGL(k_p2p_allreduce, dim3(m->p2p_nblk), dim3(256), 0, cs, m->p2p_args, (float*)d.dense_g);
+            else NCCLCHK(ncclAllReduce(d.dense_g, d.dense_g, d.dense_count, ncclFloat, ncclSum, m->comm, cs));
             if (!overlap) { if (recs) (void)hipEventRecord(cur_b, cs); end(); }
         }
         if (d.generic && d.grad_cap > 0.f) {
@@ -914,18 +925,18 @@ static int apply_compaction(g4r_model* m, int64_t ci) {
 // (kernels, RCCL all-reduce, dense apply) with no host work in between; G4R_RCCL_EAGER=1 keeps RCCL out of the graph
 static inline bool dist_graph_wanted(const g4r_model* m) {
     static const bool eager = getenv("G4R_RCCL_EAGER") != nullptr;
-    return !m->dm.apply_dense_inplace && !eager && !m->dist_graph_failed && m->comm_ready && !getenv("G4R_OVERLAP");
+    return !m->dm.apply_dense_inplace && !m->dist_graph_failed && (m->p2p_ready || (m->comm_ready && !eager && !getenv("G4R_OVERLAP")));
 }
 static int ensure_graph(g4r_model* m) {
     if (m->gexec) return 0;
     const bool dist = !m->dm.apply_dense_inplace;
-    if (dist) {
+    if (dist && !m->p2p_ready) {
         // RCCL sets its channels up on first use: that must not happen inside a capture (dense_g is scratch between steps)
         NCCLCHK(ncclAllReduce(m->dm.dense_g, m->dm.dense_g, m->dm.dense_count, ncclFloat, ncclSum, m->comm, m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));
     }
     hipGraph_t graph = nullptr;
-    HIPCHK(hipStreamBeginCapture(m->stream, dist ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
+    HIPCHK(hipStreamBeginCapture(m->stream, dist && !m->p2p_ready ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
     int rc = 0;
     for (int i = 0; i < G4R_GRAPH_STEPS && !rc; ++i) rc = launch_step(m, nullptr);
     hipError_t e = hipStreamEndCapture(m->stream, &graph);
@@ -1046,6 +1057,11 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
         m->since_sync += run;
     }
     HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->p2p_ready) {
+        unsigned late = 0;
+        HIPCHK(hipMemcpy(&late, m->p2p_round + m->p2p_nblk, sizeof(late), hipMemcpyDeviceToHost));
+        if (late) return fail("p2p all-reduce: a peer did not publish its gradients within G4R_P2P_TIMEOUT_MS (dead rank?)");
+    }
     return 0;
 }
 
@@ -1062,7 +1078,7 @@ int g4r_virtual_train_steps(g4r_model* const* ms, int32_t n, int64_t t0, int64_t
         if (!m || !m->d_in) return fail("virtual ranks: null model / no plan uploaded");
         if (m->cfg.nranks != n || m->cfg.rank != q) return fail("virtual ranks: handle q must be created with rank = q, nranks = n");
         if (m->cfg.device != ms[0]->cfg.device || m->dm.dense_count != ms[0]->dm.dense_count) return fail("virtual ranks: handles differ");
-        if (m->comm_ready) return fail("virtual ranks: the handle already has an RCCL communicator");
+        if (m->comm_ready || m->p2p_ready) return fail("virtual ranks: the handle already has a communicator / peer mappings");
         if (t0 < 0 || n_steps < 0 || t0 + n_steps > m->T) return fail("step range outside the plan");
         if (m->dm.ns > 0 && !m->have_pop && !m->store_frozen) return fail("negative sampling needs g4r_set_popularity first");
         m->virtual_ranks = true;
@@ -1483,6 +1499,102 @@ int g4r_comm_nranks(g4r_model* m) {
     if (ncclCommCount(m->comm, &n) != ncclSuccess) { fail("ncclCommCount failed"); return -1; }
     return n;
 }
+
+// ---- one-shot all-reduce through peer memory (k_p2p_allreduce, g4r_sync_kernels.cuh) -------------------------------------------
+// The switch next to the RCCL all-reduce of the dense gradients: g4r_p2p_enable on a handle that has a communicator (the 64-byte
+// IPC handles travel through one ncclAllGather), or g4r_p2p_export / g4r_p2p_attach with the handles carried by the caller (no
+// RCCL at all: two processes on ONE device can be ranks of each other that way, which RCCL refuses -- the N > 1 test a one-GPU box
+// can run).  One node only: the handles are hipIpcMemHandle_t.
+static int p2p_timeout_ms() { const char* e = getenv("G4R_P2P_TIMEOUT_MS"); return e ? std::max(1, atoi(e)) : 20000; }
+int g4r_p2p_export(g4r_model* m, char* out_handle64) {
+    if (!m || !out_handle64) return fail("null argument");
+    if (m->dm.apply_dense_inplace) return fail("p2p: the handle was created as a single rank (nranks = 1 without G4R_FORCE_STAGED)");
+    if (m->p2p_ready) return fail("p2p: already attached");
+    if (m->cfg.nranks > G4R_P2P_MAX) return fail("p2p: at most 8 ranks (one node)");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    if (!m->p2p_region) {
+        m->p2p_nblk = cdiv(m->dm.dense_count, 1024);
+        m->p2p_cap = m->p2p_nblk * 1024;
+        const size_t flag_bytes = ((size_t)m->p2p_nblk * sizeof(unsigned) + 4095) & ~(size_t)4095;
+        const size_t bytes = flag_bytes + 2 * (size_t)m->p2p_cap * sizeof(float);
+        // uncached (fine-grained) device memory where the runtime exports it; plain device memory otherwise -- every access of
+        // the kernel is system scope either way
+        void* q = nullptr;
+        hipIpcMemHandle_t h;
+        bool ok = false;
+        if (!getenv("G4R_P2P_COARSE") && hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) == hipSuccess) {
+            ok = hipIpcGetMemHandle(&h, q) == hipSuccess;
+            if (!ok) { (void)hipFree(q); q = nullptr; }
+        }
+        (void)hipGetLastError();
+        if (!ok) {
+            HIPCHK(hipMalloc(&q, bytes));
+            if (hipIpcGetMemHandle(&h, q) != hipSuccess) { (void)hipFree(q); return fail("p2p: hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)"); }
+        }
+        HIPCHK(hipMemset(q, 0, bytes));
+        m->p2p_region = q;
+        if (dalloc(m, &m->p2p_round, (size_t)m->p2p_nblk + 1)) return -1;
+        HIPCHK(hipStreamSynchronize(m->stream));
+        memcpy(out_handle64, &h, 64);
+        return 0;
+    }
+    hipIpcMemHandle_t h;
+    HIPCHK(hipIpcGetMemHandle(&h, m->p2p_region));
+    memcpy(out_handle64, &h, 64);
+    return 0;
+}
+int g4r_p2p_attach(g4r_model* m, const char* handles, int32_t nranks, int32_t rank) {
+    if (!m || !handles) return fail("null argument");
+    if (!m->p2p_region) return fail("p2p: g4r_p2p_export first");
+    if (m->p2p_ready) return fail("p2p: already attached");
+    if (nranks != m->cfg.nranks || rank != m->cfg.rank) return fail("rank layout differs from g4r_config");
+    if (nranks < 1 || nranks > G4R_P2P_MAX) return fail("p2p: 1..8 ranks");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    const size_t flag_bytes = ((size_t)m->p2p_nblk * sizeof(unsigned) + 4095) & ~(size_t)4095;
+    P2PArgs& a = m->p2p_args;
+    memset(&a, 0, sizeof(a));
+    for (int q = 0; q < nranks; ++q) {
+        char* base = (char*)m->p2p_region;
+        if (q != rank) {
+            hipIpcMemHandle_t h;
+            memcpy(&h, handles + 64 * (size_t)q, 64);
+            void* ptr = nullptr;
+            hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) { (void)hipGetLastError(); return fail(std::string("p2p: hipIpcOpenMemHandle (rank ") + std::to_string(q) + "): " + hipGetErrorString(e)); }
+            m->p2p_peer[q] = ptr;
+            base = (char*)ptr;
+        }
+        a.flags[q] = (unsigned*)base;
+        a.data[q] = (float*)(base + flag_bytes);
+    }
+    a.own_flags = a.flags[rank]; a.own_data = a.data[rank];
+    a.round = m->p2p_round;
+    a.nranks = nranks; a.rank = rank; a.count = m->dm.dense_count; a.cap = m->p2p_cap; a.nblk = m->p2p_nblk;
+    a.spin_ticks = (long long)p2p_timeout_ms() * 100000;      // wall_clock64: 100 MHz
+    // a step graph captured with the RCCL node is stale now
+    if (m->gexec) { (void)hipGraphExecDestroy(m->gexec); m->gexec = nullptr; }
+    if (m->gexec_small) { (void)hipGraphExecDestroy(m->gexec_small); m->gexec_small = nullptr; }
+    m->p2p_ready = true;
+    return 0;
+}
+int g4r_p2p_enable(g4r_model* m) {
+    if (!m) return fail("null model");
+    if (!m->comm_ready) return fail("g4r_comm_init first (or carry the handles yourself: g4r_p2p_export / g4r_p2p_attach)");
+    const int n = m->cfg.nranks;
+    std::vector<char> all(64 * (size_t)n);
+    if (g4r_p2p_export(m, all.data() + 64 * (size_t)m->cfg.rank)) return -1;
+    char* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, 64 * (size_t)n));
+    HIPCHK(hipMemcpyAsync(d + 64 * (size_t)m->cfg.rank, all.data() + 64 * (size_t)m->cfg.rank, 64, hipMemcpyHostToDevice, m->stream));
+    ncclResult_t r = ncclAllGather(d + 64 * (size_t)m->cfg.rank, d, 64, ncclChar, m->comm, m->stream);
+    if (r != ncclSuccess) { (void)hipFree(d); return fail(std::string("ncclAllGather: ") + ncclGetErrorString(r)); }
+    HIPCHK(hipMemcpyAsync(all.data(), d, 64 * (size_t)n, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    (void)hipFree(d);
+    return g4r_p2p_attach(m, all.data(), n, m->cfg.rank);
+}
+int g4r_p2p_active(g4r_model* m) { return m && m->p2p_ready ? 1 : 0; }
 // ---- reconciliation of the GPU-local item tables ------------------------------------------------------------
 static inline int nblk256(long long n) { return (int)((n + 255) / 256); }
 

@@ -106,3 +106,82 @@ __global__ __launch_bounds__(256) void k_virtual_bcast(VSumArgs a, int n, int co
     const float s = tmp[i];
     for (int q = 0; q < n; ++q) a.dst[q][i] = s;
 }
+
+// ---- one-shot all-reduce of the dense gradients through peer memory (g4r_p2p_*; the switch next to the RCCL all-reduce) --------
+// The dense GRU gradients are a few hundred KB (cfg2: 60,600 floats): for that size a ring / tree collective is latency, not
+// bandwidth -- every rank can simply READ the other ranks' gradients over its point-to-point xGMI links (7 x 240 KB in parallel
+// at 8 ranks) and add them up itself, in rank order, so that every rank holds the same bits.  Every rank owns an exchange region
+// (IPC-mapped by all peers): nblk stamps + two gradient buffers of `cap` floats (steps alternate between them).  Workgroup b of
+// step s  (1) copies its 1024 floats of the local gradient to its own region, buffer s & 1, with system-scope write-through stores,
+// drains them, and publishes stamp s + 1 in its own flag b;  (2) waits until every peer's flag b carries that stamp;  (3) loads the
+// peers' 1024 floats (system-scope loads: no stale line of this GPU's L2 / L1) and sums own + peers in rank order into the local
+// gradient buffer.  Hand-offs are per workgroup: nothing waits for a whole buffer, nothing waits for another workgroup of the same
+// GPU (no residency assumption).  A buffer is rewritten two steps later, which needs every peer past step s + 1's wait, i.e. done
+// reading step s.  The step number is the workgroup's own counter (round[b], local memory): replays of a captured graph need no
+// host-side argument.  A peer that never arrives (a dead rank) ends the wait after `spin_ticks` of the 100 MHz wall clock and
+// raises round[nblk]; the gradient is left as it was and g4r_train_steps reports the failure.
+#define G4R_P2P_MAX 8
+struct P2PArgs {
+    float* data[G4R_P2P_MAX];          // [2][cap] of every rank as mapped in this process (own: the local pointer)
+    unsigned* flags[G4R_P2P_MAX];      // [nblk]
+    float* own_data;                   // = data[rank], flags[rank]: no dynamic index into the argument block
+    unsigned* own_flags;
+    unsigned* round;                   // local: [nblk] steps done by workgroup b, [nblk] = timeout marker
+    int nranks, rank, count, cap, nblk;
+    long long spin_ticks;
+};
+__device__ __forceinline__ void st4_sys(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ f32x4 ld4_sys_nowait(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__global__ __launch_bounds__(256) void k_p2p_allreduce(P2PArgs a, float* g) {
+    __shared__ int bad;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (a.round[a.nblk]) return;                 // an earlier step gave up on a peer: the run is over, do not wait again
+    const unsigned done = a.round[b];
+    const unsigned stamp = done + 1;
+    const size_t buf = (size_t)(done & 1) * a.cap;
+    const int i = (b * 256 + tid) * 4;
+    f32x4 mine = {0.f, 0.f, 0.f, 0.f};
+    if (i + 3 < a.count) mine = *reinterpret_cast<const f32x4*>(g + i);
+    else
+        for (int k = 0; k < 4; ++k) if (i + k < a.count) mine[k] = g[i + k];
+    if (tid == 0) bad = 0;
+    st4_sys(a.own_data + buf + i, mine);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // system scope (the stores above are write-through already)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.own_flags + b, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (tid < a.nranks && tid != a.rank) {
+        const long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load(a.flags[tid] + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - stamp) < 0) {
+            if (wall_clock64() - t0 > a.spin_ticks) { bad = 1; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    __syncthreads();
+    if (bad) {
+        if (tid == 0) a.round[a.nblk] = 1;
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    // every slot loads (slots past nranks and the own one read the own region): the results go from the load to the wait below
+    // without a branch in between, so the compiler has no reason to copy a register whose data is still in flight
+    f32x4 v[G4R_P2P_MAX];
+#pragma unroll
+    for (int q = 0; q < G4R_P2P_MAX; ++q) v[q] = ld4_sys_nowait((q < a.nranks ? a.data[q] : a.own_data) + buf + i);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < G4R_P2P_MAX; ++q)
+        if (q < a.nranks) s += (q == a.rank) ? mine : v[q];      // rank order, from 0.f like k_virtual_sum: the same bits on every rank
+    if (i + 3 < a.count) *reinterpret_cast<f32x4*>(g + i) = s;
+    else
+        for (int k = 0; k < 4; ++k) if (i + k < a.count) g[i + k] = s[k];
+    if (tid == 0) a.round[b] = stamp;
+}

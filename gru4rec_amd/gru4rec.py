@@ -8,6 +8,7 @@ lets the device run whole epochs without a host round trip (libgru4rec_hip.so th
 
 There is deliberately no CPU fallback.
 """
+import os
 import pickle
 import sys
 import time
@@ -321,6 +322,9 @@ class GRU4Rec:
             rank=rank, nranks=nranks, use_graph=1 if self.use_graph else 0)
         if self._dist and self._dist['unique_id'] is not None:
             m.comm_init(self._dist['unique_id'], nranks, rank)
+            if os.environ.get('G4R_P2P') == '1' and nranks <= 8:
+                # the switch next to the RCCL all-reduce: every rank reads its peers' gradients over xGMI itself (g4r_p2p_enable)
+                m.p2p_enable()
         return m
 
     # ---- device layout: the library wants layer / embedding widths that are multiples of 4 (16-byte rows).  Other widths are

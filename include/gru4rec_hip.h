@@ -221,6 +221,20 @@ int g4r_comm_min_i64(g4r_model* m, int64_t* value);            /* in-place min o
 int g4r_comm_max_i64(g4r_model* m, int64_t* value);            /* in-place max over ranks: the common plan length (shorter plans are
                                                                   padded with M = 0 steps so that every rank issues the same all-reduces) */
 int g4r_comm_nranks(g4r_model* m);                             /* ranks RCCL reports for the communicator (1 without one) */
+/* One-shot all-reduce of the dense GRU gradients through peer memory -- the switch next to the RCCL all-reduce (new: the reference
+ * is single-GPU; north_star asks for the gradients of gru4rec.py:383-384's dense parameters to be all-reduced every step).  The
+ * gradients are a few hundred KB, so instead of a ring every rank reads the other ranks' buffers over its point-to-point xGMI
+ * links and adds them in rank order itself (k_p2p_allreduce: per-workgroup stamped hand-offs, two alternating buffers, no
+ * host work per step, captured in the step graph).  One node, at most 8 ranks.
+ *   g4r_p2p_enable   on a handle with a communicator: allocates this rank's exchange region, all-gathers the 64-byte IPC handles
+ *                    through RCCL, maps the peers.  Collective.  GRU4Rec does this when G4R_P2P=1.
+ *   g4r_p2p_export / g4r_p2p_attach   the same with the handles carried by the caller (handles: nranks x 64 bytes in rank order);
+ *                    needs no RCCL, so two PROCESSES on one device can be each other's ranks (tests/test_gpu_p2p.py).
+ * A peer that does not publish within G4R_P2P_TIMEOUT_MS (default 20000) makes g4r_train_steps fail instead of hang. */
+int g4r_p2p_enable(g4r_model* m);
+int g4r_p2p_export(g4r_model* m, char* out_handle64);
+int g4r_p2p_attach(g4r_model* m, const char* handles, int32_t nranks, int32_t rank);
+int g4r_p2p_active(g4r_model* m);                              /* 1 when the step's all-reduce is the peer-memory one */
 
 /* ---- debugging / tests ---------------------------------------------------------------------- */
 /* copy a named intermediate of the most recent step (e.g. "scores", "dS", "dV0", "hd0") */
