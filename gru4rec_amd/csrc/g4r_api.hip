@@ -46,10 +46,10 @@ void g4r_set_error(const char* fmt, ...) {
     } while (0)
 
 enum { KN_GRU_P1 = 0, KN_GRU_P2, KN_SCORE_FWD, KN_LOSS, KN_SCORE_BWD, KN_BWD_PRE, KN_BWD_A, KN_BWD_B, KN_DENSE, KN_ALLREDUCE,
-       KN_DENSE_APPLY, KN_SPARSE, KN_UPDATE, KN_BWD_FUSED, KN_FWD_FUSED, KN_COUNT };
+       KN_DENSE_APPLY, KN_SPARSE, KN_UPDATE, KN_BWD_FUSED, KN_FWD_FUSED, KN_COMPACT, KN_COUNT };
 static const char* KN_NAMES[KN_COUNT] = {"k_gru_p1", "k_gru_p2", "k_score_fwd", "k_loss_rows", "k_score_bwd", "k_gru_bwd_pre",
                                          "k_gru_bwd_a", "k_gru_bwd_b", "k_dense_grad", "rccl_allreduce", "k_dense_apply",
-                                         "k_sparse_update", "k_update", "k_gru_bwd", "k_gru_fwd"};
+                                         "k_sparse_update", "k_update", "k_gru_bwd", "k_gru_fwd", "k_compact_sy"};
 
 struct EvRec { int kn; hipEvent_t a, b; };
 
@@ -61,6 +61,8 @@ struct g4r_model {
     hipStream_t stream = nullptr;
     hipStream_t comm_stream = nullptr;           // all-reduce + dense Adagrad next to the sparse update (nranks > 1)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;      // G4R_SYC=2: k_compact_sy on a branch next to the GRU forward
+    bool syc_forked = false;
     std::vector<void*> allocs;
     // plan
     int *d_in = nullptr, *d_out = nullptr, *d_M = nullptr, *d_cmaps = nullptr;
@@ -268,7 +270,9 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return fail("stream create"); }
     if (hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) { g4r_destroy(m); return fail("stream create"); }
+        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_fork2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_join2, hipEventDisableTiming) != hipSuccess) { g4r_destroy(m); return fail("stream create"); }
     DevModel& d = m->dm;
     memset(&d, 0, sizeof(d));
     const int L = cfg->n_layers, B = cfg->batch_size;
@@ -365,6 +369,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         }
         d.ksplit = cdiv(d.ldSc, d.kch);
         DA(d.dhpart, (size_t)d.ksplit * B * d.Dtop);
+        // compact copy of the step's Sy rows for the k_score_bwd2 shapes (k_compact_sy); G4R_SYC=0: gather from the table as before
+        if (score_bwd2(d) && env_int("G4R_SYC", 1) != 0) { DA(d.Syc, (size_t)d.ldSc * d.Dtop); m->syc_forked = env_int("G4R_SYC", 1) == 2; }
         const int TB = wide_scores(d) ? 64 : 32;      // tile edge of k_score_bwd
         m->ndtA = cdiv(d.Dtop + 1, TB);
         m->nblkA = cdiv(d.ldSc, TB) * m->ndtA;
@@ -505,6 +511,8 @@ void g4r_destroy(g4r_model* m) {
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    if (m->ev_fork2) (void)hipEventDestroy(m->ev_fork2);
+    if (m->ev_join2) (void)hipEventDestroy(m->ev_join2);
     if (m->comm_stream) (void)hipStreamDestroy(m->comm_stream);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -775,6 +783,19 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     StepState* stp = (StepState*)d.st;
     bool merged = false;      // the sparse update already ran inside k_update
     if (part != 2) {
+    // the compact copy of the step's Sy rows: first kernel of the step, or (G4R_SYC=2, graph / plain launches only) on a branch of its
+    // own that joins in front of the scoring forward -- it depends on nothing the GRU forward computes
+    const bool syc_fork = d.Syc && m->syc_forked && !recs && !trace;
+    if (d.Syc && !syc_fork) {
+        begin(KN_COMPACT);
+        LK(k_compact_sy, dim3(cdiv((long long)d.ldSc * (d.Dtop / 4), 256)), dim3(256), 0, s, dmp);
+        end();
+    } else if (syc_fork) {
+        HIPCHK(hipEventRecord(m->ev_fork2, s));
+        HIPCHK(hipStreamWaitEvent(m->comm_stream, m->ev_fork2, 0));
+        hipLaunchKernelGGL(k_compact_sy, dim3(cdiv((long long)d.ldSc * (d.Dtop / 4), 256)), dim3(256), 0, m->comm_stream, dmp);
+        HIPCHK(hipEventRecord(m->ev_join2, m->comm_stream));
+    }
     for (int l = 0; l < L; ++l) {
         if (fused_fwd(d, l)) {
             begin(KN_FWD_FUSED);
@@ -790,6 +811,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         LK(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH), SMEM_NN, s, dmp, stp, l, 1, nopa);
         end();
     }
+    if (syc_fork) HIPCHK(hipStreamWaitEvent(s, m->ev_join2, 0));
     begin(KN_SCORE_FWD);
     if (m->sk_W > 0 && m->sk_nst == 3) LK(k_score_fwd_sk<3>, dim3(m->sk_W), dim3(GT_NTH), m->smem_sk, s, dmp, stp, m->sk_ws, m->sk_flags, m->sk_W, m->sk_nrt, m->sk_nct, m->sk_maxct);
     else if (m->sk_W > 0) LK(k_score_fwd_sk<4>, dim3(m->sk_W), dim3(GT_NTH), m->smem_sk, s, dmp, stp, m->sk_ws, m->sk_flags, m->sk_W, m->sk_nrt, m->sk_nct, m->sk_maxct);
@@ -1974,6 +1996,7 @@ int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
     else if (s == "ksplit") { if (count < 1) return fail("count"); host[0] = (float)d.ksplit; return 0; }
     else if (s == "streamk_workers") { if (count < 1) return fail("count"); host[0] = (float)m->sk_W; return 0; }
     else if (s == "dev_syncs") { if (count < 1) return fail("count"); host[0] = (float)m->n_dev_syncs; return 0; }
+    else if (s == "compact_sy") { if (count < 1) return fail("count"); host[0] = d.Syc ? 1.f : 0.f; return 0; }
     else if (s == "dense_count") { if (count < 1) return fail("count"); host[0] = (float)d.dense_count; return 0; }
     else if (s == "occ_score_tile") {      // resident workgroups per CU the runtime reports for the gemm_tile2 scoring kernel
         if (count < 1) return fail("count");

@@ -532,6 +532,24 @@ __global__ __launch_bounds__(512) void k_gru_fwd_fused(const DevModel* __restric
 #define T3_BKS 32    // k per ring stage (measured at B = 512, N = 8704, D = 256 / B = 240, N = 2288, D = 512, us: 3 x 32: 31.3 / 15.0,
                      // 4 x 16: 32.3 / 16.1, 5 x 16: 32.7 / 16.4 -- gemm_tile2: 34.1 / 17.5)
 #endif
+
+// The Wy rows of this step's score columns (targets | samples: cur_col, staged with the step's inputs) copied once into a compact
+// [ldSc][Dtop] buffer at the start of the step (long score rows on a big catalogue: the k_score_bwd2 shapes).  Why: the dh slabs of
+// k_score_bwd2 contract over the COLUMNS -- a 64 x 64 tile walks ~600 gathered rows, 256 bytes of each, and every row is a fresh page
+// of a multi-GB table, re-gathered by the 8 row tiles x 4 d tiles of its slab (32 piece loads per row and step, each a likely
+// translation miss); from the compact copy the same operand is 8.9 MB of consecutive memory that stays in the L2s / Infinity Cache.
+// The rows are those of the END of the previous step (the sparse update is the last kernel of a step), which is what the scoring
+// forward and backward of this step read anyway.  Inactive columns (item < 0) hold zeros.
+__global__ __launch_bounds__(256) void k_compact_sy(const DevModel* __restrict__ mp) {
+    const DevModel& m = *mp;
+    const int D = m.Dtop, q = D >> 2;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)m.ldSc * q) return;
+    const int n = (int)(e / q), c = 4 * (int)(e - (long long)n * q);
+    const int item = m.cur_col[n];
+    const float4 v = ld4_if(m.Wy, (size_t)max(item, 0) * D + c, item >= 0);
+    *reinterpret_cast<GAS float4*>(m.Syc + (size_t)n * D + c) = v;
+}
 // T2 > 3: the gemm_tile2 variant (64 x 64 tiles, mfma 32x32x2) with K chunks of T2 floats; T2 == 3: gemm_tile3 (LDS-DMA ring);
 // TBN / TBK then only name the instance
 template <int TBN, int TBK, int T2 = 0>
@@ -612,9 +630,10 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
         const GAS int* ccol = m.cur_col;
         const int ldc = m.ldSc;
         auto arow = [&](int r) -> const GAS float* { return (m0 + r < M) ? hsrc + (size_t)(m0 + r) * D : nullptr; };
+        const GAS float* syc = m.Syc;      // compact copy of the columns' rows (k_compact_sy) when staged
         auto brow = [&](int r) -> const GAS float* {
             const int item = (n0 + r < ldc) ? ccol[n0 + r] : -1;
-            return item >= 0 ? Wy + (size_t)item * D : nullptr;
+            return item >= 0 ? (syc ? syc + (size_t)(n0 + r) * D : Wy + (size_t)item * D) : nullptr;
         };
         auto pre2 = [&](int row, int n) -> float4 {
             const int item = (n < N) ? ccol[min(n, ldc - 1)] : -1;
@@ -1242,11 +1261,17 @@ __global__ __launch_bounds__(256, G4R_BWD2_WPE) void k_score_bwd2(const DevModel
             const int item = sIt[min(kk + kr, kch - 1)];
             return (item >= 0 && kk + kr < kch) ? Wy + (size_t)item * D + d0 + cc : nullptr;
         };
+        // the same rows out of the compact copy (k_compact_sy): consecutive memory, no item look-up (inactive columns hold zeros there)
+        const GAS float* syc = m.Syc;
+        auto bptr_c = [&](int kk, int kr, int cc) -> const GAS float* {
+            return (kk + kr < kch && kbeg + kk + kr < ld) ? syc + (size_t)(kbeg + kk + kr) * D + d0 + cc : nullptr;
+        };
         auto epi = [&](int b, int d, float v, float4) {
             if (b < M) dhpart[((size_t)kc * B + b) * D + d] = v;
         };
         if (trc && tid == 0) trc[1] = wall_clock64();
-        gemm_tile2k<false, true>(m0, d0, min(kch, ld - kbeg), arow, bptr, m.zrow, NoPre(), epi, smem, trc);
+        if (syc) gemm_tile2k<false, true>(m0, d0, min(kch, ld - kbeg), arow, bptr_c, m.zrow, NoPre(), epi, smem, trc);
+        else gemm_tile2k<false, true>(m0, d0, min(kch, ld - kbeg), arow, bptr, m.zrow, NoPre(), epi, smem, trc);
         return;
     }
     // ---- role C: 64 columns, thread (column tid & 63, row group tid >> 6)

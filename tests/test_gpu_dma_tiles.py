@@ -103,3 +103,30 @@ def test_tile_or_slab_that_starts_on_an_inactive_in_batch_column(B, ns, D):
     into the inactive range."""
     _run('inactive head B=%d D=%d' % (B, D), I=9000, B=B, ns=ns, T=8, store_rows=10, loss='bpr-max', final_act='elu-0.5',
          constrained_embedding=True, layers=(D,), learning_rate=0.1, bpreg=0.5)
+
+
+@pytest.mark.parametrize('B,ns,D,tail', [(256, 3840, 128, True), (240, 2048, 512, False), (512, 8192, 256, True)])
+def test_compact_copy_of_the_score_rows_changes_no_bit(monkeypatch, B, ns, D, tail):
+    """k_compact_sy: at the k_score_bwd2 shapes the scoring forward and the dh slabs read the step's Wy rows from a compact copy made
+    at the start of the step instead of gathering them from the table (G4R_SYC=0: as before).  Same values through the same
+    arithmetic: losses, item tables, accumulators and dense parameters must be IDENTICAL -- with finished sessions (-1 columns),
+    items repeated between inputs / targets / negatives, and a batch that shrinks below B."""
+    outs = []
+    for syc in ('0', '1', '2'):      # 2: the copy runs on a branch of its own next to the GRU forward (inside the step graph)
+        monkeypatch.setenv('G4R_SYC', syc)
+        I, T = 20000, 6
+        _, m = make_pair(I, B, ns, store_rows=8, use_graph=1, loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(D,),
+                         learning_rate=0.1, bpreg=0.5, momentum=0.1)
+        plan = random_plan(I, B, T, seed=5, tail=tail)
+        if tail:
+            plan['M'][T // 2:] = max(1, B - 37)
+        plan['out_idx'][:, 6:12] = plan['in_idx'][:, :6]
+        m.set_plan(plan)
+        m.train_steps(0, T)
+        assert int(m.get_debug('compact_sy', (1,))[0]) == int(syc != '0')
+        outs.append((m.get_losses(0, T), m.get_param('Wy', (I, D)), m.get_param('acc_Wy', (I, D)), m.get_param('By', (I,)),
+                     m.get_param('Wx', (D, 3 * D), 0), m.get_param('Wh', (D, D), 0), m.get_param('acc_Wh', (D, D), 0)))
+        m.close()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            np.testing.assert_array_equal(a, b)
