@@ -20,3 +20,18 @@ rm -rf /tmp/out_s
 timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/out_s -- python $ROOT/bench.py --config cfg4 --steps 600 --warmup 100 --no-cpu-baseline --no-micro --profile-steps 0 --long-steps 0 > $OUT/stats_cfg4.log 2>&1
 cp /tmp/out_s/*/*kernel_stats.csv $OUT/r03_kernel_stats_rocprofv3_cfg4.csv 2>/dev/null; head -12 $OUT/r03_kernel_stats_rocprofv3_cfg4.csv | cut -c1-160
 echo "elapsed $(( $(date +%s) - T0 )) s"
+if [ $(( $(date +%s) - T0 )) -lt 360 ]; then
+  rm -rf /tmp/out_s
+  timeout 100 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/out_s -- python $ROOT/bench.py --config cfg3 --steps 600 --warmup 100 --no-cpu-baseline --no-micro --profile-steps 0 --long-steps 0 > $OUT/stats_cfg3.log 2>&1
+  cp /tmp/out_s/*/*kernel_stats.csv $OUT/r03_kernel_stats_rocprofv3_cfg3.csv 2>/dev/null; head -12 $OUT/r03_kernel_stats_rocprofv3_cfg3.csv | cut -c1-160
+  echo "elapsed $(( $(date +%s) - T0 )) s"
+fi
+if [ $(( $(date +%s) - T0 )) -lt 380 ]; then
+  rm -rf /tmp/out_f /tmp/out_w
+  COMMON="--no-cpu-baseline --no-micro --profile-steps 0 --long-steps 0"
+  timeout 45 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/out_f -- python $ROOT/bench.py --config cfg4 --steps 100 --warmup 20 --no-graph $COMMON > $OUT/pmc_f_cfg4.log 2>&1
+  timeout 45 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/out_w -- python $ROOT/bench.py --config cfg4 --steps 100 --warmup 20 --no-graph $COMMON > $OUT/pmc_w_cfg4.log 2>&1
+  python $ROOT/tools/pmc_summary.py /tmp/out_f/*/*counter_collection.csv /tmp/out_w/*/*counter_collection.csv $OUT/r03_pmc_traffic_cfg4.json > $OUT/pmc_summary_cfg4.txt 2>&1
+  echo "== cfg4 traffic"; cat $OUT/pmc_summary_cfg4.txt | head -20
+  echo "elapsed $(( $(date +%s) - T0 )) s"
+fi
