@@ -369,8 +369,11 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         }
         d.ksplit = cdiv(d.ldSc, d.kch);
         DA(d.dhpart, (size_t)d.ksplit * B * d.Dtop);
-        // compact copy of the step's Sy rows for the k_score_bwd2 shapes (k_compact_sy); G4R_SYC=0: gather from the table as before
-        if (score_bwd2(d) && env_int("G4R_SYC", 1) != 0) { DA(d.Syc, (size_t)d.ldSc * d.Dtop); m->syc_forked = env_int("G4R_SYC", 1) == 2; }
+        // compact copy of the step's Sy rows for the k_score_bwd2 shapes (k_compact_sy), opt-in: G4R_SYC=1 (first kernel of the step)
+        // or 2 (on a branch next to the GRU forward).  Measured at B = 512 / 8192 negatives / 10 M x 256: the scoring forward gains
+        // 1.4 us, the dh slabs nothing (57.1 vs 57.4 -- their rate is not set by the gathers), the copy costs 6.9 us: 5.42 vs 5.58 K
+        // mini-batches/s; forked 5.01 K (profiles/r03_experiments.md #12)
+        if (score_bwd2(d) && env_int("G4R_SYC", 0) != 0) { DA(d.Syc, (size_t)d.ldSc * d.Dtop); m->syc_forked = env_int("G4R_SYC", 0) == 2; }
         const int TB = wide_scores(d) ? 64 : 32;      // tile edge of k_score_bwd
         m->ndtA = cdiv(d.Dtop + 1, TB);
         m->nblkA = cdiv(d.ldSc, TB) * m->ndtA;

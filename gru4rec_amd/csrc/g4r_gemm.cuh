@@ -488,13 +488,23 @@ __device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, 
     // older chunk is written to LDS (loads return in order).  With compiler-issued loads every commit drained to the newest load
     // (round 2, (b) above), i.e. the gathered rows of the dh slabs arrived one 16-deep chunk (~1 us of MFMAs) ahead of use, less than
     // their latency.  The sets are addressed by compile-time constants (the K loop is unrolled by two): no register indexing.
+    // What keeps this safe (guide section 5.7, item 1): hipcc regards an asm load's destination as written when the statement ends,
+    // so a register copy it places between the load and our wait reads the register BEFORE the data lands.  The first version of this
+    // pipeline waited with `"+v"` operands in two branches (vmcnt(2) / vmcnt(0) at the tail); the allocator merged the branches'
+    // outputs with v_mov copies placed in FRONT of the tail's wait: the last chunk of a tile was committed from stale registers
+    // whenever its loads took longer than 1.5 iterations -- never on cache-resident tables, a few times per launch on a 10 GB table
+    // under load (caught by the catalogue-scale parity test; the ISA audit in tests/test_isa_audit.py now checks the pattern).
+    // Now: every wait is a bare `s_waitcnt vmcnt(2)` with no operands and no branch (the tail iterations issue two dummy loads of
+    // the zero row so that the count stays 2), followed by a sched_barrier; nothing ties the data registers to the wait, and the
+    // commit reads the load's own destination registers.
     f32x4 ra0, rb0, ra1, rb1;
     bool oa0 = false, ob0 = false, oa1 = false, ob1 = false;
     auto ldasm = [](const GAS float* p) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory"); return v; };
     auto issue = [&](int kk, f32x4& ra, f32x4& rb, bool& oa, bool& ob) {
-        if constexpr (A_KM) { const GAS float* a_ = aprov(kk, kr, kc); oa = a_ != nullptr; ra = ldasm(a_ ? a_ : safe); }
-        else { oa = oka; ra = ldasm(pa); if (oka) pa += BK; }
-        const GAS float* b_ = bprov(kk, kr, kc);
+        const bool live = kk < K;                       // uniform; past the end: two loads of the zero row, never committed
+        if constexpr (A_KM) { const GAS float* a_ = live ? aprov(kk, kr, kc) : nullptr; oa = a_ != nullptr; ra = ldasm(a_ ? a_ : safe); }
+        else { oa = oka && live; ra = ldasm(oa ? pa : safe); if (oa) pa += BK; }
+        const GAS float* b_ = live ? bprov(kk, kr, kc) : nullptr;
         ob = b_ != nullptr;
         rb = ldasm(b_ ? b_ : safe);
     };
@@ -515,8 +525,9 @@ __device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, 
     const int sw_fr = 2 * ((l32 >> 2) & 7);             // K-contiguous A: swizzle of this lane's fragment row
     const int nchunk = (K + BK - 1) / BK;
     issue(0, ra0, rb0, oa0, ob0);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(rb0) :: "memory");      // chunk 0 (its latency is exposed either way)
-    if (nchunk > 1) issue(BK, ra1, rb1, oa1, ob1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // chunk 0 (its latency is exposed either way)
+    __builtin_amdgcn_sched_barrier(0);
+    issue(BK, ra1, rb1, oa1, ob1);
     const int n = n0 + wn * 32 + l32;
     constexpr int NPF = PRE_COL ? 1 : 16;
     float4 pf[NPF];
@@ -524,7 +535,8 @@ __device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, 
     for (int j = 0; j < NPF; ++j) pf[j] = pre(m0 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3), n);
     commit(0, ra0, rb0, oa0, ob0);
     if (trc && tid == 0) trc[2] = wall_clock64();
-    // one K chunk out of LDS buffer `buf`: fragments, then the loads of the chunk after next, then the MFMAs
+    // one K chunk out of LDS buffer `buf`: fragments, the loads of the chunk after next, the MFMAs, then the wait for the NEXT chunk
+    // (the newest two loads stay in flight; loads return in order, and the epilogue operands requested above are older than both)
     auto chunk = [&](int buf, int i, f32x4& ra, f32x4& rb, bool& oa, bool& ob) {
         __syncthreads();
         const float* fa = A_KM ? smem + buf * BUF + lh * 64 + ((wm * 32 + l32) ^ (32 * lh))
@@ -536,24 +548,25 @@ __device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, 
             av[u] = A_KM ? fa[128 * u] : fa[(2 * u) ^ sw_fr];
             bv[u] = fb[128 * u];
         }
-        if (i + 2 < nchunk) issue((i + 2) * BK, ra, rb, oa, ob);      // into the set chunk i was committed from
+        issue((i + 2) * BK, ra, rb, oa, ob);            // into the set chunk i was committed from
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc = mfma32(av[u], bv[u], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
     for (int i = 0; i < nchunk; i += 2) {
         chunk(0, i, ra0, rb0, oa0, ob0);
         if (i + 1 >= nchunk) break;
-        if (i + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" : "+v"(ra1), "+v"(rb1) :: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra1), "+v"(rb1) :: "memory");
         commit(1, ra1, rb1, oa1, ob1);
         chunk(1, i + 1, ra1, rb1, oa1, ob1);
         if (i + 2 >= nchunk) break;
-        if (i + 3 < nchunk) asm volatile("s_waitcnt vmcnt(2)" : "+v"(ra0), "+v"(rb0) :: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(rb0) :: "memory");
         commit(0, ra0, rb0, oa0, ob0);
     }
+    // the dummy loads of the tail are still in flight and their registers are free as far as the compiler knows: drain before anything reuses them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     if (trc && tid == 0) trc[3] = wall_clock64();
 #pragma unroll
     for (int j = 0; j < 16; ++j) epi(m0 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3), n, acc[j], pf[PRE_COL ? 0 : j]);

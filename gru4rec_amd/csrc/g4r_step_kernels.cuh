@@ -664,11 +664,6 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
 // (MI355X_MICROARCH.md, inter-workgroup visibility: form R1); the owner's poll is bounded and reports through nan_flag instead
 // of hanging should the co-residency assumption ever fail.
 __device__ __forceinline__ void st4_sc1(GAS float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ f32x4 ld4_sc1(const GAS float* p) {
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
 template <int NST>
 __global__ __launch_bounds__(256, NST <= 3 ? 3 : 2) void k_score_fwd_sk(const DevModel* __restrict__ mp, StepState* st, float* ws_, unsigned* flags_, int W,
                                                          int nrt, int nct, int maxct) {
@@ -825,12 +820,14 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : 2) void k_score_fwd_sk(const De
                     }
                 }
                 __syncthreads();
+                // loads and their wait in ONE asm statement, early-clobber outputs (guide section 5.7 item 1, form (i)): the compiler
+                // sees the registers written when the statement ends, which is then true
                 f32x4 o[4];
-#pragma unroll
-                for (int j4 = 0; j4 < 4; ++j4) o[j4] = ld4_sc1(ws + ((size_t)((w + 1) * 4 + j4) * 256 + tid) * 4);
-                // (the loaded registers are operands of the wait: the compiler does not know the asm loads are asynchronous and
-                // must not move their uses above it)
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]) :: "memory");
+                const GAS float* wp = ws + ((size_t)((w + 1) * 4) * 256 + tid) * 4;
+                asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                             "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+                             : "v"(wp), "v"(wp + 1024), "v"(wp + 2048), "v"(wp + 3072) : "memory");
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[j] += o[j >> 2][j & 3];
             }

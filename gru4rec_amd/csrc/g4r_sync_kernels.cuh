@@ -131,11 +131,6 @@ struct P2PArgs {
     long long spin_ticks;
 };
 __device__ __forceinline__ void st4_sys(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ f32x4 ld4_sys_nowait(const float* p) {
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
 __global__ __launch_bounds__(256) void k_p2p_allreduce(P2PArgs a, float* g) {
     __shared__ int bad;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -170,12 +165,19 @@ __global__ __launch_bounds__(256) void k_p2p_allreduce(P2PArgs a, float* g) {
         return;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    // every slot loads (slots past nranks and the own one read the own region): the results go from the load to the wait below
-    // without a branch in between, so the compiler has no reason to copy a register whose data is still in flight
+    // every slot loads (slots past nranks and the own one read the own region); the eight loads and their wait are ONE asm statement
+    // with early-clobber outputs (guide section 5.7 item 1, form (i)): hipcc takes an asm load's destination as written when the
+    // statement ends and may copy it right away -- here that is true
     f32x4 v[G4R_P2P_MAX];
+    const float* pp[G4R_P2P_MAX];
 #pragma unroll
-    for (int q = 0; q < G4R_P2P_MAX; ++q) v[q] = ld4_sys_nowait((q < a.nranks ? a.data[q] : a.own_data) + buf + i);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
+    for (int q = 0; q < G4R_P2P_MAX; ++q) pp[q] = (q < a.nranks ? a.data[q] : a.own_data) + buf + i;
+    asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %10, off sc0 sc1\n\tglobal_load_dwordx4 %3, %11, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %4, %12, off sc0 sc1\n\tglobal_load_dwordx4 %5, %13, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %6, %14, off sc0 sc1\n\tglobal_load_dwordx4 %7, %15, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(pp[0]), "v"(pp[1]), "v"(pp[2]), "v"(pp[3]), "v"(pp[4]), "v"(pp[5]), "v"(pp[6]), "v"(pp[7]) : "memory");
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < G4R_P2P_MAX; ++q)
