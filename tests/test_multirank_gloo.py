@@ -1,12 +1,15 @@
 """The N > 1 path on CPU: two processes (gloo) run the PRODUCT's host code for a data-parallel epoch -- session sharding and plan
 building (gru4rec_amd.plan.build_rank_plan: the C++ scheduler), the common plan length (max over ranks) and the M = 0 padding
 steps (pad_plan) -- with the device calls stood in for by the oracle: dense GRU gradients all-reduced (averaged) every step,
-embedding rows rank-local and reconciled at the end of the epoch as base + sum of every rank's deltas.
+item rows rank-local and reconciled every SYNC_EVERY steps and at the end of the epoch by the product's rule (DESIGN.md section 7,
+g4r_sync_kernels.cuh): for the rows some rank rewrote since the last reconciliation, parameters and velocities end at
+base + MEAN over the touching ranks of (value - base), Adagrad's accumulators at base + SUM.
 
 Checks: (1) the shards partition the sessions and preserve time order, and no event is lost: the events of all rank plans add
-up to the events of the single-rank plan; (2) dense parameters stay bit-identical across ranks; (3) embedding replicas diverge
-during the epoch and agree after the reconciliation, which keeps a row only one rank trained at exactly that rank's value;
-(4) the two-process run equals a single-process emulation of the same algorithm (so the collective placement is right)."""
+up to the events of the single-rank plan; (2) dense parameters stay bit-identical across ranks; (3) item-table replicas diverge
+between reconciliations and agree after each one, and a row only one rank trained keeps exactly that rank's values (under the
+mean as under the sum); (4) the two-process run equals a single-process emulation of the same algorithm (so the collectives sit
+where the product puts them)."""
 import os
 import tempfile
 
@@ -21,6 +24,7 @@ from gru4rec_amd.plan import build_rank_plan, pad_plan, shard_sessions
 from oracle.model import OracleGRU4Rec
 
 I, B, NS, D = 60, 4, 8, 8
+SYNC_EVERY = 4      # GRU4Rec.sync_every (16 in the product; the epoch here is ~20 steps)
 PARAMS = dict(layers=(D,), batch_size=B, loss='bpr-max', final_act='elu-0.5', n_sample=NS, constrained_embedding=True,
               learning_rate=0.1, momentum=0.1)
 
@@ -42,10 +46,45 @@ def make_rank_model(rank):
     return o
 
 
-def run_rank_steps(o, plan, T, reduce_fn):
+def planes(o):
+    """(array, is_mean_plane) of the item-table group Wy / By: parameters and velocities take the mean, accumulators the sum"""
+    return [(o.Wy, True), (o.By, True), (o.vel['Wy'], True), (o.vel['By'], True), (o.acc['Wy'], False), (o.acc['By'], False)]
+
+
+def reconcile(models, bases, allreduce):
+    """The product's reconciliation on a list of local replicas (one per rank in a process group: a list of one + a collective;
+    the emulation: all replicas + a plain sum).  bases: per replica the plane values at the last reconciliation (updated in place)."""
+    touched = [np.zeros(I, dtype=bool) for _ in models]
+    for o, base, t in zip(models, bases, touched):
+        for (cur, _), b0 in zip(planes(o), base):
+            t |= (cur != b0).reshape(I, -1).any(axis=1)
+    count = allreduce([t.astype(np.float64) for t in touched])
+    hit = count > 0
+    n_planes = len(bases[0])
+    for q in range(n_planes):
+        deltas = []
+        for o, base, t in zip(models, bases, touched):
+            cur = planes(o)[q][0]
+            d = cur - base[q]
+            d[~t] = 0
+            deltas.append(d)
+        total = allreduce(deltas)
+        mean = planes(models[0])[q][1]
+        for o, base in zip(models, bases):
+            cur = planes(o)[q][0]
+            div = np.where(count > 1, count, 1.0) if mean else np.ones(I)
+            new = base[q] + total / (div if total.ndim == 1 else div[:, None])
+            cur[hit] = new[hit]
+            base[q][...] = cur
+    return touched
+
+
+def run_rank_steps(o, plan, T, reduce_fn, sync_fn):
     o.dense_grad_hook = reduce_fn
     for t in range(T):
         o.train_step(plan['in_idx'][t], plan['out_idx'][t], int(plan['M'][t]), plan['reset'][t])
+        if (t + 1) % SYNC_EVERY == 0 or t + 1 == T:
+            sync_fn(t)
 
 
 def flat_dense(o):
@@ -71,14 +110,22 @@ def worker(rank, world, store_path, out_path):
                 red.append(t.numpy() / world)            # k_dense_apply scales by 1/nranks
             out.append((i, *red))
         return out
+
+    def allreduce_one(arrays):                           # this process holds one replica: the sum over ranks is a collective
+        t = torch.from_numpy(np.ascontiguousarray(arrays[0]))
+        dist.all_reduce(t)
+        return t.numpy()
     o = make_rank_model(rank)
-    base = o.Wy.copy()                                   # identical on every rank (same initialisation)
-    run_rank_steps(o, plan, T, allreduce_avg)
-    wy_local = o.Wy.copy()
-    t = torch.from_numpy(o.Wy - base)
-    dist.all_reduce(t)                                   # g4r_comm_sync_sparse: base + sum of every rank's deltas
-    np.savez(out_path % rank, dense=flat_dense(o), wy_local=wy_local, wy_sync=base + t.numpy(), T=T, base=base,
-             events=int(plan['M'].sum()))
+    base = [cur.copy() for cur, _ in planes(o)]          # identical on every rank (same initialisation)
+    log = dict(local=[], synced=[], touched=[])
+
+    def sync(t):
+        log['local'].append(o.Wy.copy())
+        log['touched'].append(reconcile([o], [base], allreduce_one)[0])
+        log['synced'].append(np.concatenate([cur.reshape(I, -1) for cur, _ in planes(o)], axis=1))
+    run_rank_steps(o, plan, T, allreduce_avg, sync)
+    np.savez(out_path % rank, dense=flat_dense(o), local=np.array(log['local']), synced=np.array(log['synced']), touched=np.array(log['touched']),
+             T=T, events=int(plan['M'].sum()))
     dist.destroy_process_group()
 
 
@@ -91,11 +138,15 @@ def test_two_ranks_gloo_match_single_process_emulation():
         mp.start_processes(worker, args=(world, store, out), nprocs=world, join=True, start_method='fork')
         r = [np.load(out % k) for k in range(world)]
     np.testing.assert_array_equal(r[0]['dense'], r[1]['dense'])          # (2) dense replicas identical
-    assert np.abs(r[0]['wy_local'] - r[1]['wy_local']).max() > 1e-6      # (3) embeddings are rank-local ...
-    np.testing.assert_array_equal(r[0]['wy_sync'], r[1]['wy_sync'])      # ... and agree after the reconciliation
-    only0 = (np.abs(r[0]['wy_local'] - r[0]['base']).max(axis=1) > 0) & (np.abs(r[1]['wy_local'] - r[1]['base']).max(axis=1) == 0)
-    assert only0.any()                                                   # rows only rank 0 trained keep rank 0's full update
-    np.testing.assert_allclose(r[0]['wy_sync'][only0], r[0]['wy_local'][only0], rtol=0, atol=1e-15)
+    n_sync = len(r[0]['synced'])
+    assert n_sync >= 3
+    np.testing.assert_array_equal(r[0]['synced'], r[1]['synced'])        # (3) replicas agree after EVERY reconciliation ...
+    assert np.abs(r[0]['local'] - r[1]['local']).max() > 1e-6            # ... and had diverged before it
+    only0 = r[0]['touched'] & ~r[1]['touched']
+    both = r[0]['touched'] & r[1]['touched']
+    assert only0.any() and both.any()
+    for k in range(n_sync):                                              # a row only rank 0 trained keeps rank 0's own value
+        np.testing.assert_allclose(r[0]['synced'][k][only0[k], :D], r[0]['local'][k][only0[k]], rtol=1e-14, atol=0)      # (base + delta: one rounding)
     # (1) no event is lost: all rank plans together hold the events of the single-rank plan
     off, order, items = make_sessions()
     single = _native.build_plan(off, order, items, B, NS)
@@ -106,6 +157,8 @@ def test_two_ranks_gloo_match_single_process_emulation():
     assert T == int(r[0]['T']) and min(p['T'] for p in plans) < T        # the padding is exercised
     plans = [pad_plan(p, T) for p in plans]
     models = [make_rank_model(k) for k in range(world)]
+    bases = [[cur.copy() for cur, _ in planes(m)] for m in models]
+    emu_local = []
     for t in range(T):
         grads = []
         for k in range(world):
@@ -130,8 +183,14 @@ def test_two_ranks_gloo_match_single_process_emulation():
         for k in range(world):
             models[k].dense_grad_hook = lambda g, avg=avg: avg
             models[k].train_step(plans[k]['in_idx'][t], plans[k]['out_idx'][t], int(plans[k]['M'][t]), plans[k]['reset'][t])
+        if (t + 1) % SYNC_EVERY == 0 or t + 1 == T:
+            emu_local.append(models[1].Wy.copy())
+            reconcile(models, bases, lambda arrays: np.sum(arrays, axis=0))
     np.testing.assert_allclose(flat_dense(models[0]), r[0]['dense'], rtol=0, atol=1e-12)
-    np.testing.assert_allclose(models[1].Wy, r[1]['wy_local'], rtol=0, atol=1e-12)
+    for k in range(world):
+        got = np.concatenate([cur.reshape(I, -1) for cur, _ in planes(models[k])], axis=1)
+        np.testing.assert_allclose(got, r[k]['synced'][-1], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(np.array(emu_local), r[1]['local'], rtol=0, atol=1e-12)
 
 
 def test_shards_partition_sessions_in_time_order():
