@@ -663,7 +663,7 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
 // write-through 16-byte stores and L1-bypassing loads (`sc1` on both sides) behind a drained, step-stamped flag
 // (MI355X_MICROARCH.md, inter-workgroup visibility: form R1); the owner's poll is bounded and reports through nan_flag instead
 // of hanging should the co-residency assumption ever fail.
-__device__ __forceinline__ void st4_sc1(GAS float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st4_sc1(GAS float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }      // s_nop: the data registers may be rewritten right behind an asm store
 template <int NST>
 __global__ __launch_bounds__(256, NST <= 3 ? 3 : 2) void k_score_fwd_sk(const DevModel* __restrict__ mp, StepState* st, float* ws_, unsigned* flags_, int W,
                                                          int nrt, int nct, int maxct) {
