@@ -295,7 +295,7 @@ def main():
         # replicas drift apart); that cost is measured here, separately, over the rows the next `sync_every` steps touch, and
         # reported next to `value` -- never inside it, never hidden.
         from gru4rec_amd.gru4rec import GRU4Rec
-        K = GRU4Rec().sync_every
+        K = GRU4Rec().sync_steps(max(world, 1)) or 16
         try:
             t_sync = []
             base_t = args.warmup + args.steps + n_long + n_profile

@@ -122,8 +122,11 @@ class GRU4Rec:
         self.steps_per_call = 16384  # plan steps per C-ABI call (NaN check granularity)
         # multi-GPU runs: the GPU-local item tables are reconciled every `sync_every` steps and at the end of every epoch.  Measured
         # with virtual ranks (profiles/r03_virtual_ranks.json): reconciling only per epoch lets the replicas'
-        # embedding spaces drift apart under the shared (all-reduced) GRU weights -- Recall@20 0.41 -> 0.15 at two ranks
-        self.sync_every = 16
+        # embedding spaces drift apart under the shared (all-reduced) GRU weights -- Recall@20 0.41 -> 0.15 at two ranks.  'auto':
+        # 4 steps at two ranks (every 16: 0.20, every 4: 0.40 against 0.41 on one rank), 16 from three ranks on (four / eight ranks lose
+        # 0.01 - 0.015 against every 4 and the exchange moves about the whole table each time); an integer is taken as given, 0 / None
+        # reconciles at the end of the epoch only
+        self.sync_every = 'auto'
         self._model = None
         self._dist = None
         self._cpu_store = False
@@ -574,6 +577,21 @@ class GRU4Rec:
         self._plan_key = key
         return plan
 
+    def sync_steps(self, nranks=None):
+        """Steps between two reconciliations of the GPU-local item tables for `nranks` ranks (default: this object's layout): the
+        `sync_every` attribute, 'auto' resolved as documented there; 0 = only at the end of an epoch."""
+        if nranks is None:
+            nranks = self._dist['nranks'] if self._dist else 1
+        k = self.sync_every
+        if k == 'auto':
+            return 4 if nranks == 2 else 16
+        if not k:
+            return 0
+        k = int(k)
+        if k < 0:
+            raise ValueError('sync_every must be a number of steps, 0 / None or "auto"')
+        return k
+
     def run_epoch(self, epoch, max_steps=None):
         """One pass of the reference's epoch body (gru4rec.py:587-661).  Returns (costs, M per step) or None on NaN."""
         m = self._model
@@ -586,11 +604,12 @@ class GRU4Rec:
         since_sync = 0
         # small item tables are reconciled inside the library (every sync_every steps, between two steps, on the stream); otherwise
         # the calls are cut at those points and g4r_comm_sync_sparse runs in between
-        host_sync = bool(self._dist and self.sync_every) and not m.set_sync_every(int(self.sync_every))
+        sync_k = self.sync_steps()
+        host_sync = bool(self._dist and sync_k) and not m.set_sync_every(sync_k)
         while done < T:
             n = min(self.steps_per_call, T - done)
             if host_sync:
-                n = min(n, int(self.sync_every) - since_sync)      # every rank cuts at the same steps: plans have one common length
+                n = min(n, sync_k - since_sync)      # every rank cuts at the same steps: plans have one common length
             if self._cpu_store:
                 # host sample store: the row pointer is the global step modulo the store length; a new store is drawn when it
                 # wraps (gru4rec.py:609-613), so no device call runs across that point
@@ -610,7 +629,7 @@ class GRU4Rec:
                 return None
             done += n
             since_sync += n
-            if host_sync and since_sync >= int(self.sync_every) and done < T:
+            if host_sync and since_sync >= sync_k and done < T:
                 m.comm_sync_sparse()
                 since_sync = 0
         cc = plan['M'][:T]
@@ -685,7 +704,7 @@ class GRU4Rec:
                                   'exposes the same computation through gru4rec_amd.evaluation.evaluate_gpu')
 
     # ------------------------------------------------------------------ (de)serialisation (gru4rec.py:742-781)
-    _EXTRAS = dict(seed=12345, device=0, use_graph=True, steps_per_call=16384, sync_every=16)     # attributes the reference does not have
+    _EXTRAS = dict(seed=12345, device=0, use_graph=True, steps_per_call=16384, sync_every='auto')     # attributes the reference does not have
 
     def __getstate__(self):
         st = dict(self.__dict__)

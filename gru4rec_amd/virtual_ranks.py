@@ -52,7 +52,7 @@ def fit_virtual_ranks(params, data, nranks, sample_store=10000000, sync_every='d
                 g._model.sync_set_rule(*rule)
         grus.append(g)
     if sync_every == 'default':
-        sync_every = grus[0].sync_every
+        sync_every = grus[0].sync_steps(nranks)
     if nranks <= 1:
         sync_every = None      # nothing to reconcile
     models = [g._model for g in grus]

@@ -79,7 +79,9 @@ def test_epoch_loop_terminates_and_cuts_at_the_reconciliation_points(monkeypatch
         assert sum(n for _, n in calls) == 2 * T                      # every step of both epochs, once
         per_epoch = [c for c in calls[:len(calls) // 2]]
         assert [t for t, _ in per_epoch] == list(np.cumsum([0] + [n for _, n in per_epoch[:-1]]))      # contiguous
-    k = grus[0].sync_every if sync_every == 'default' else sync_every
+    k = grus[0].sync_steps(nranks) if sync_every == 'default' else sync_every
+    if sync_every == 'default':
+        assert k == (4 if nranks == 2 else 16)      # 'auto': two ranks need the tighter coupling
     if nranks > 1:
         expect = (((T - 1) // k) if k else 0) + 1                        # every k steps inside the epoch, and at its end
         assert st['syncs'] == 2 * expect
@@ -90,7 +92,7 @@ def test_epoch_loop_terminates_and_cuts_at_the_reconciliation_points(monkeypatch
 
 
 @pytest.mark.parametrize('dev', [False, True])
-@pytest.mark.parametrize('sync_every,steps_per_call,T', [(16, 16384, 50), (4, 7, 23), (0, 10, 23), (16, 5, 16)])
+@pytest.mark.parametrize('sync_every,steps_per_call,T', [(16, 16384, 50), (4, 7, 23), (0, 10, 23), (16, 5, 16), ('auto', 16384, 23)])
 def test_run_epoch_reconciles_every_sync_every_steps_on_every_rank(sync_every, steps_per_call, T, dev):
     """GRU4Rec.run_epoch with a (fake) communicator: C-ABI calls are cut at the reconciliation points, g4r_comm_sync_sparse runs every
     `sync_every` steps (never behind the last step: fit() reconciles at the epoch end itself), the NaN exits stay collective."""
@@ -124,8 +126,9 @@ def test_run_epoch_reconciles_every_sync_every_steps_on_every_rank(sync_every, s
     m = g._model
     assert sum(n for _, n in m.calls) == T and all(n <= steps_per_call for _, n in m.calls)
     # (dev: the library reconciles small tables itself inside g4r_train_steps -- the host then neither cuts its calls nor syncs)
-    want = [k for k in range(sync_every, T, sync_every)] if (sync_every and not dev) else []
+    every = 4 if sync_every == 'auto' else sync_every      # two ranks: 'auto' is 4 steps
+    want = [k for k in range(every, T, every)] if (every and not dev) else []
     assert m.syncs == want
-    if sync_every:
-        assert m.dev_k == sync_every
+    if every:
+        assert m.dev_k == every
     assert m.maxes == len(m.calls) + 1            # one collective NaN check per call + one for the epoch loss
