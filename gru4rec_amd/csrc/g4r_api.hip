@@ -829,7 +829,11 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     end();
     begin(KN_SCORE_BWD);
     if (score_bwd2(d)) {
-        const int ndt = d.Dtop / 64, nrt = cdiv(B, 64), nA = cdiv(d.ldSc, 64) * ndt, nB = d.ksplit * nrt * ndt, nC = cdiv(d.ldSc, 64);
+        const int ndt = d.Dtop / 64, nrt = cdiv(B, 64);
+        int nA = cdiv(d.ldSc, 64) * ndt, nB = d.ksplit * nrt * ndt, nC = cdiv(d.ldSc, 64);
+        // measurement only (results are WRONG): one role of the launch alone -- 1: the dS tiles, 2: the dh slabs (tools/bwd2_roles.sh)
+        static const int only = env_int("G4R_DEBUG_BWD2_ROLE", 0);
+        if (only == 1) { nB = 0; nC = 0; } else if (only == 2) { nA = 0; nC = 0; }
         LK(k_score_bwd2, dim3(nA + nB + nC), dim3(GT_NTH), (size_t)(4 * 64 * 16) * sizeof(float) + (size_t)std::max(d.kch, 64) * sizeof(int), s, dmp, stp, nA, nB, ndt, nrt);
     } else if (wide_scores(d)) LK(k_score_bwd_w, dim3(m->nblkA + m->nblkB), dim3(GT_NTH), SMEM_SBW + (size_t)d.kch * sizeof(int), s, dmp, stp, m->nblkA, m->ndtA, m->ndtB, m->nrtB);
     else LK(k_score_bwd_n, dim3(m->nblkA + m->nblkB), dim3(GT_NTH), std::max(SMEM_TN, SMEM_NN) + (size_t)d.kch * sizeof(int), s, dmp, stp, m->nblkA, m->ndtA, m->ndtB, m->nrtB);
