@@ -21,7 +21,9 @@ def build(force=False, verbose=False, out=None, defs=()):
     return _compile(OUT, [], verbose)
 
 
-MUTANTS = {1: 'sparse accumulator increments x 1.01', 2: 'sparse Adagrad steps x 1.01', 3: 'dense accumulator increments x 1.01'}
+MUTANTS = {1: 'sparse accumulator increments x 1.01', 2: 'sparse Adagrad steps x 1.01', 3: 'dense accumulator increments x 1.01',
+           4: "round 3's stale-register pipeline of gemm_tile2k (tied wait operands in two branches): fails the ISA audit, so it is the "
+              "one library built with audit=False"}
 
 
 def mutant_path(k):
@@ -38,8 +40,8 @@ def build_mutants(force=False, verbose=False):
     if not todo:
         return [mutant_path(k) for k in MUTANTS]
     _host_object(verbose)
-    with ThreadPoolExecutor(len(todo)) as ex:
-        list(ex.map(lambda k: _device(mutant_path(k), ['G4R_MUTATE=%d' % k], verbose), todo))
+    with ThreadPoolExecutor(min(len(todo), 2)) as ex:      # two hipcc at a time (each peaks at ~2 GB)
+        list(ex.map(lambda k: _device(mutant_path(k), ['G4R_MUTATE=%d' % k], verbose, audit=(k != 4)), todo))
     return [mutant_path(k) for k in MUTANTS]
 
 
@@ -52,16 +54,70 @@ def _host_object(verbose):
     return obj
 
 
-def _device(OUT, defs, verbose):
+class AuditError(RuntimeError):
+    """The generated code uses the destination of a hand-counted asm load before the wait that retires it (isa_audit.py)."""
+
+
+def hipcc_version():
+    rocm = os.environ.get('ROCM_PATH', '/opt/rocm')
+    try:
+        out = subprocess.run([os.path.join(rocm, 'bin', 'hipcc'), '--version'], capture_output=True, text=True).stdout
+    except OSError:
+        return 'unknown'
+    hip = [ln for ln in out.splitlines() if ln.startswith('HIP version')]
+    return hip[0].split(':', 1)[1].strip() if hip else 'unknown'
+
+
+def build_dir(OUT):
+    """Where the device listing (`*.s`) and the per-kernel resource table of library OUT are kept (git-ignored)."""
+    return os.path.join(HERE, '_build', os.path.splitext(os.path.basename(OUT))[0])
+
+
+def _device(OUT, defs, verbose, audit=True):
+    """hipcc -> OUT.  The device listing hipcc assembles into the library (-save-temps) is kept under _build/ and AUDITED
+    (isa_audit.audit): a library whose code names the destination register of a hand-counted asm load before the wait that
+    retires it is deleted and AuditError raised -- another compiler version cannot silently produce a wrong library (round 3's
+    stale-register bug passed 250 parity tests).  `audit=False` exists for the test build of exactly that bug (mutant 4)."""
+    import glob
+    import json
+    import shutil
+    from . import isa_audit
     rocm = os.environ.get('ROCM_PATH', '/opt/rocm')
     obj = os.path.join(HERE, 'csrc', 'g4r_io.o')
     trace = ['-DG4R_CLK_TRACE'] if os.environ.get('G4R_BUILD_CLK') else []      # in-kernel phase traces for tools/clk*.py
-    cmd = [os.path.join(rocm, 'bin', 'hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC'] + trace + ['-D' + d for d in defs] + [
-           '-I' + os.path.join(rocm, 'include'), '-o', OUT, SRC, '-Wl,' + obj, '-pthread', '-L' + os.path.join(rocm, 'lib'), '-lrccl',
-           '-Wl,-rpath,' + os.path.join(rocm, 'lib')]
+    tmp = build_dir(OUT)
+    shutil.rmtree(tmp, ignore_errors=True)
+    os.makedirs(tmp)
+    ver = hipcc_version()
+    cmd = [os.path.join(rocm, 'bin', 'hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-save-temps=obj',
+           '-DG4R_HIPCC_VERSION="%s"' % ver] + trace + ['-D' + d for d in defs] + [
+           '-I' + os.path.join(rocm, 'include'), '-o', os.path.join(tmp, os.path.basename(OUT)), SRC, '-Wl,' + obj, '-pthread',
+           '-L' + os.path.join(rocm, 'lib'), '-lrccl', '-Wl,-rpath,' + os.path.join(rocm, 'lib')]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
+    listing = glob.glob(os.path.join(tmp, '*amdgcn*gfx950.s'))
+    if len(listing) != 1:
+        raise AuditError('no device listing next to the library (%s): cannot audit the asm loads' % tmp)
+    asm = open(listing[0]).read()
+    findings, counted = isa_audit.audit(asm)
+    with open(os.path.join(tmp, 'resources.json'), 'w') as f:
+        json.dump({'hipcc': ver, 'validated_hipcc': isa_audit.VALIDATED_HIPCC, 'asm_register_loads': counted,
+                   'audit_findings': [list(x) for x in findings], 'kernels': isa_audit.resources(asm)}, f, indent=1, sort_keys=True)
+    for junk in glob.glob(os.path.join(tmp, '*')):      # keep the listing and the table, drop the other intermediates
+        if not (junk.endswith('gfx950.s') or junk.endswith('resources.json') or junk.endswith('.so')):
+            os.remove(junk)
+    built = os.path.join(tmp, os.path.basename(OUT))
+    if findings and audit:
+        os.remove(built)
+        if os.path.exists(OUT):
+            os.remove(OUT)
+        raise AuditError('%d premature use(s) of an asm load destination in the code %s generated, first: %s line %d `%s` names '
+                         'in-flight v%s -- library NOT installed (gru4rec_amd/isa_audit.py)' % ((len(findings), ver) + tuple(findings[0])))
+    if not any('k_score_bwd2' in k for k in counted) and audit:
+        os.remove(built)
+        raise AuditError('the audit no longer sees the asm loads of k_score_bwd2 it was written for: %s' % sorted(counted))
+    os.replace(built, OUT)
     return OUT
 
 

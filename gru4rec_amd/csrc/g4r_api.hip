@@ -236,7 +236,12 @@ int g4r_device_count(void) {
     return n;
 }
 const char* g4r_last_error(void) { return g_err.c_str(); }
-const char* g4r_version(void) { return "gru4rec_hip 0.1 (gfx950)"; }
+#ifndef G4R_HIPCC_VERSION
+#define G4R_HIPCC_VERSION "unknown"
+#endif
+// library version, target, and the hipcc the device code was generated with (gru4rec_amd/build.py passes it; the same build
+// audits the generated code for premature uses of hand-counted asm loads and refuses to install a library that has one)
+const char* g4r_version(void) { return "gru4rec_hip 0.4 (gfx950; hipcc " G4R_HIPCC_VERSION "; isa-audited)"; }
 int g4r_sizeof_config(void) { return (int)sizeof(g4r_config); }
 
 int g4r_create(const g4r_config* cfg, g4r_model** out) {
@@ -1655,6 +1660,13 @@ int g4r_sync_enable(g4r_model* m) {
         if (m->planes[g].size() <= 12 && bytes <= (size_t)env_int("G4R_SYNC_DENSE_MB", 64) * 1024 * 1024 && env_int("G4R_SYNC_DENSE", 1))
             if (dalloc(m, &m->d_dense[g], I * w, false)) return -1;
     }
+    // Rule of the optimizer-statistic planes: SUM is right for Adagrad only -- its accumulator is a plain sum of squared
+    // gradients, so the ranks' increments add up exactly as they would on one GPU.  rmsprop / adadelta / adam keep MOVING
+    // AVERAGES (a <- v a + (1 - v) g^2, gru4rec.py:300-381): each rank's delta contains -(1 - v^k) a0, and the sum over N ranks
+    // leaves a0 (1 - N (1 - v^k)) + ... -- negative for rows several ranks touched (v = 0.95, 8 ranks, 16 steps: -3.5 a0), i.e. a
+    // NaN in the next sqrt; Adam's first moment would be inflated up to N-fold.  Those statistics take the MEAN over the touching
+    // ranks (an average of averages stays inside the range of its inputs), like parameters and velocities.
+    m->sync_rule[1] = (m->cfg.adapt == G4R_ADAPT_ADAGRAD) ? G4R_SYNC_SUM : G4R_SYNC_MEAN;
     if (const char* e = getenv("G4R_SYNC_RULE")) {      // "<param><stat>", s = sum, m = mean: experiments (tools/virtual_ranks_study.py)
         if (e[0]) m->sync_rule[0] = e[0] == 's' ? G4R_SYNC_SUM : G4R_SYNC_MEAN;
         if (e[0] && e[1]) m->sync_rule[1] = e[1] == 's' ? G4R_SYNC_SUM : G4R_SYNC_MEAN;

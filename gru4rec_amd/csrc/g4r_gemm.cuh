@@ -525,9 +525,18 @@ __device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, 
     const int sw_fr = 2 * ((l32 >> 2) & 7);             // K-contiguous A: swizzle of this lane's fragment row
     const int nchunk = (K + BK - 1) / BK;
     issue(0, ra0, rb0, oa0, ob0);
+#if defined(G4R_MUTATE) && G4R_MUTATE == 4
+    // Mutation build 4 (tests only, gru4rec_amd/build.py builds it with the audit switched off): round 3's first version of this
+    // pipeline -- waits with tied "+v" operands in two branches, no dummy loads at the tail.  hipcc merges the branches' outputs
+    // with copies in FRONT of the tail's wait: the last chunk is committed from registers whose loads may not have landed.
+    // The ISA audit must flag it (tests/test_isa_audit.py) and the GPU stress test must turn red on it (tests/test_gpu_stress.py).
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(rb0) :: "memory");
+    if (nchunk > 1) issue(BK, ra1, rb1, oa1, ob1);
+#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // chunk 0 (its latency is exposed either way)
     __builtin_amdgcn_sched_barrier(0);
     issue(BK, ra1, rb1, oa1, ob1);
+#endif
     const int n = n0 + wn * 32 + l32;
     constexpr int NPF = PRE_COL ? 1 : 16;
     float4 pf[NPF];
@@ -548,6 +557,13 @@ __device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, 
             av[u] = A_KM ? fa[128 * u] : fa[(2 * u) ^ sw_fr];
             bv[u] = fb[128 * u];
         }
+#if defined(G4R_MUTATE) && G4R_MUTATE == 4
+        if (i + 2 < nchunk) issue((i + 2) * BK, ra, rb, oa, ob);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = mfma32(av[u], bv[u], acc);
+        __builtin_amdgcn_sched_barrier(0);
+#else
         issue((i + 2) * BK, ra, rb, oa, ob);            // into the set chunk i was committed from
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -555,13 +571,22 @@ __device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, 
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+#endif
     };
     for (int i = 0; i < nchunk; i += 2) {
         chunk(0, i, ra0, rb0, oa0, ob0);
         if (i + 1 >= nchunk) break;
+#if defined(G4R_MUTATE) && G4R_MUTATE == 4
+        if (i + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" : "+v"(ra1), "+v"(rb1) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra1), "+v"(rb1) :: "memory");
+#endif
         commit(1, ra1, rb1, oa1, ob1);
         chunk(1, i + 1, ra1, rb1, oa1, ob1);
         if (i + 2 >= nchunk) break;
+#if defined(G4R_MUTATE) && G4R_MUTATE == 4
+        if (i + 3 < nchunk) asm volatile("s_waitcnt vmcnt(2)" : "+v"(ra0), "+v"(rb0) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(rb0) :: "memory");
+#endif
         commit(0, ra0, rb0, oa0, ob0);
     }
     // the dummy loads of the tail are still in flight and their registers are free as far as the compiler knows: drain before anything reuses them

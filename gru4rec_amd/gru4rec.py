@@ -325,6 +325,12 @@ class GRU4Rec:
             rank=rank, nranks=nranks, use_graph=1 if self.use_graph else 0)
         if self._dist and self._dist['unique_id'] is not None:
             m.comm_init(self._dist['unique_id'], nranks, rank)
+            if nranks > 1:
+                # every rank holds the communicator once this max-reduce returns: the rendezvous file has done its job and goes
+                # now, not after fit() (a crash during training must not leave an id behind for the next run to read)
+                from . import launch
+                launch.barrier(m)
+                launch.cleanup(rank)
             if os.environ.get('G4R_P2P') == '1' and nranks <= 8:
                 # the switch next to the RCCL all-reduce: every rank reads its peers' gradients over xGMI itself (g4r_p2p_enable)
                 m.p2p_enable()

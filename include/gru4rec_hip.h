@@ -188,7 +188,9 @@ int g4r_comm_sync_sparse(g4r_model* m);
 /* combine rule of the reconciliation, per kind of plane: parameters (Wy / By / E and their velocities) and optimizer statistics
  * (Adagrad / RMSprop accumulators, Adam moments and counters).  G4R_SYNC_SUM: base + sum of the deltas of the ranks that touched
  * the row; G4R_SYNC_MEAN: base + their mean.  Default: parameters MEAN (N full-size steps from one starting point must not add up:
- * measured), statistics SUM (squared gradients of all ranks' events add up as they would on one GPU). */
+ * measured); statistics SUM with adapt = adagrad (squared gradients of all ranks' events add up as they would
+ * on one GPU) and MEAN with rmsprop / adadelta / adam, whose statistics are moving averages: summed deltas of a decayed
+ * average go negative once several ranks touch a row (NaN in the next sqrt) -- tests/test_gpu_virtual_ranks.py. */
 #define G4R_SYNC_SUM 0
 #define G4R_SYNC_MEAN 1
 int g4r_sync_set_rule(g4r_model* m, int32_t param_rule, int32_t stat_rule);

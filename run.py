@@ -38,7 +38,7 @@ OPTIONS = [
     ('-pm', '--primary_metric', dict(metavar='METRIC', choices=['recall', 'mrr'], default='recall', help='metric reported on the PRIMARY METRIC line (default recall)')),
     ('-lpm', '--log_primary_metric', dict(action='store_true', help='print the PRIMARY METRIC line after every evaluation')),
     (None, '--gpus', dict(metavar='N', type=int, default=1, help='train on N GPUs of this node (not in the reference): one process per GPU, sessions sharded over '
-                          'the ranks, dense GRU gradients all-reduced by RCCL every step, item rows GPU-local and reconciled per epoch; rank 0 saves / evaluates')),
+                          'the ranks, dense GRU gradients all-reduced by RCCL every step, item rows GPU-local and reconciled every sync_every steps (4 at two ranks, 16 from three on) and at every epoch end; rank 0 saves / evaluates')),
 ]
 
 

@@ -93,3 +93,35 @@ def test_identical_ranks_reproduce_the_single_rank_run():
     assert abs(r1[0] - r2[0]) <= 0.01
     for g in one + two:
         g.close()
+
+
+@pytest.mark.parametrize('adapt', ['rmsprop', 'adam', 'adadelta'])
+def test_moving_average_statistics_stay_valid_across_ranks(adapt):
+    """The reconciliation rule of the optimizer statistics follows the optimizer: Adagrad's sum of squares adds up over ranks,
+    the moving averages of rmsprop / adadelta / adam (gru4rec.py:300-381) take the MEAN of the touching ranks' deltas -- summed,
+    a popular item's accumulator becomes a0 (1 - N (1 - v^k)) + ... < 0 and the next step's sqrt returns NaN (8 ranks, v = 0.95,
+    16 steps: -3.5 a0).  Eight virtual ranks on a small catalogue (every rank touches the popular rows every step): accumulators
+    must stay >= 0 and the loss finite; with the SUM rule forced the same run must break (that is what the default replaces)."""
+    data = synth.make_sessions(6000, n_items=300, seed=11)
+    train, _ = synth.train_test_split(data, test_frac=0.1)
+    ap = {'rmsprop': [0.95], 'adadelta': [0.95], 'adam': [0.9, 0.999]}[adapt]
+    p = dict(PARAMS, batch_size=32, n_sample=256, adapt=adapt, adapt_params=ap,
+             learning_rate={'adam': 0.002, 'adadelta': 1.0}.get(adapt, 0.05))
+    grus, stats = fit_virtual_ranks(p, train, 8, sample_store=256 * 200, sync_every=16)
+    acc = grus[0]._model.get_param('acc_Wy', (grus[0].n_items, 100))
+    report('virtual ranks x8 %-8s loss %.5f  min(acc) %.3e  reconciliations %d' % (adapt, stats['loss'][0], acc.min(), stats['syncs']))
+    assert np.isfinite(stats['loss'][0]) and np.isfinite(acc).all() and acc.min() >= 0.0
+    assert np.isfinite(grus[0].Wy).all()
+    for g in grus:
+        g.close()
+    if adapt == 'rmsprop':
+        bad = None
+        try:
+            grus, stats = fit_virtual_ranks(p, train, 8, sample_store=256 * 200, sync_every=16, rule=('mean', 'sum'))
+            acc = grus[0]._model.get_param('acc_Wy', (grus[0].n_items, 100))
+            bad = (not np.isfinite(stats['loss'][0])) or acc.min() < 0.0 or not np.isfinite(acc).all()
+            for g in grus:
+                g.close()
+        except FloatingPointError:
+            bad = True
+        assert bad, 'summed deltas of a moving average were expected to break the run'

@@ -66,3 +66,34 @@ def test_library_code_has_no_premature_use_of_an_asm_load():
     f, c = isa_audit.audit(isa_audit.device_asm())
     assert any('k_score_bwd2' in k for k in c), 'the audit no longer sees the pipeline it was written for: %s' % sorted(c)
     assert not f, '\n'.join('%s line %d: %s names in-flight v%s' % x for x in f[:20])
+
+
+@pytest.mark.skipif(shutil.which('hipcc') is None and not os.path.exists('/opt/rocm/bin/hipcc'), reason='needs hipcc')
+def test_the_build_refuses_the_stale_register_pipeline(tmp_path):
+    """Mutant 4 = round 3's faulty gemm_tile2k (tied wait operands in two branches).  build._device audits the listing hipcc
+    assembles into the library: it must raise and leave NO library behind; with audit=False (how the GPU stress test gets its red
+    build) the same source links."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from gru4rec_amd import build
+    out = str(tmp_path / 'libg4r_mut4_audit.so')
+    build._host_object(False)
+    with pytest.raises(build.AuditError) as e:
+        build._device(out, ['G4R_MUTATE=4'], False, audit=True)
+    assert 'k_score_bwd2' in str(e.value) and not os.path.exists(out)
+    import json
+    info = json.load(open(os.path.join(build.build_dir(out), 'resources.json')))
+    assert len(info['audit_findings']) >= 4 and info['hipcc'] != 'unknown'
+
+
+def test_the_shipped_library_names_its_compiler_and_has_a_clean_audit_record():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from gru4rec_amd import _native, build
+    if not os.path.exists(_native.LIB_PATH):
+        pytest.skip('library not built')
+    v = _native.lib().g4r_version().decode()
+    assert 'hipcc' in v and 'isa-audited' in v and 'unknown' not in v
+    rec = os.path.join(build.build_dir(build.OUT), 'resources.json')
+    if os.path.exists(rec):      # written by the build that produced the library (not shipped to the GPU box)
+        import json
+        info = json.load(open(rec))
+        assert info['audit_findings'] == [] and any('k_score_bwd2' in k for k in info['asm_register_loads'])

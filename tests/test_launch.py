@@ -59,3 +59,36 @@ def test_layout_defaults_to_one_process(monkeypatch):
         monkeypatch.delenv(k, raising=False)
     assert launch.layout() == (0, 1, 0)
     assert launch.unique_id(0, 1, make=lambda: b'x' * 128) is None
+
+
+def test_a_stale_or_foreign_rendezvous_file_is_not_accepted(tmp_path, monkeypatch):
+    """Advisor finding of round 3: a file a crashed run left behind (or one planted by somebody else) must not be read as this run's
+    id -- ncclCommInitRank would wait for a dead root.  The record carries a magic word and rank 0's clock; rank 0 removes an old
+    file before it creates the id; the directory is private (0700)."""
+    import struct
+    d = tmp_path / 'rdzv'
+    d.mkdir(mode=0o700)
+    monkeypatch.setenv('G4R_RDZV_DIR', str(d))
+    monkeypatch.setenv('G4R_RDZV', 'tok')
+    path = launch._rendezvous_file()
+    assert os.path.dirname(path) == str(d)
+    # (a) a bare 128-byte file (the round-3 format), (b) a well-formed record stamped long before this process started
+    for rec in (b'\x01' * 128, launch._MAGIC + struct.pack('<d', time.time() - 7200.0) + b'\x02' * 128):
+        with open(path, 'wb') as f:
+            f.write(rec)
+        t0 = time.time()
+        try:
+            launch.unique_id(1, 2, timeout=0.3, make=lambda: b'')
+            raise AssertionError('accepted a stale rendezvous file')
+        except RuntimeError as e:
+            assert 'no RCCL unique id' in str(e) and time.time() - t0 < 5
+    # rank 0 replaces whatever is there; a reader then gets exactly its bytes
+    uid = launch.unique_id(0, 2, make=lambda: bytes(range(128)))
+    assert launch.unique_id(1, 2, timeout=5.0, make=lambda: b'') == uid == bytes(range(128))
+    assert os.stat(path).st_mode & 0o077 == 0
+    launch.cleanup(0)
+    assert not os.path.exists(path)
+    # without a launcher-made directory the fallback is a private per-user directory
+    monkeypatch.delenv('G4R_RDZV_DIR')
+    fb = launch._rendezvous_dir()
+    assert os.stat(fb).st_mode & 0o077 == 0 and os.stat(fb).st_uid == os.getuid()
