@@ -10,7 +10,8 @@ already resident in HBM; it includes sample-store refills (as the reference's ep
 excludes plan building / upload.  metric = mini-batches/s exactly as gru4rec.py:661 prints it (steps / seconds);
 events/s is reported next to it.  For N > 1 (one process per GPU: `bench.py --gpus N` spawns its ranks itself, or
 `python -m torch.distributed.run` provides RANK / LOCAL_RANK / WORLD_SIZE) sessions are sharded over ranks, dense GRU gradients
-are all-reduced by RCCL every step, value = sum over ranks.  No torch anywhere: the ranks meet through gru4rec_amd/launch.py
+are all-reduced by RCCL every step, value = sum over ranks INCLUDING the reconciliation of the GPU-local item tables every
+sync_every steps (the bare step is reported next to it as value_step_only).  No torch anywhere: the ranks meet through gru4rec_amd/launch.py
 (file rendezvous of the RCCL unique id) and synchronise through the communicator (g4r_comm_max_i64).
 """
 import argparse
@@ -86,20 +87,55 @@ def algorithmic_cost(cfg):
 PEAK = {'hbm': (8000.0, 'GB/s'), 'mfma': (157.3, 'TFLOP/s')}   # MI355X_MICROARCH.md: HBM3E 8 TB/s, fp32 MFMA 157.3 TF
 
 
-def make_plan(cfg, n_steps, rank, nranks, seed=42):
-    """RSC15-shaped sessions -> (plan, number of sessions).  Enough sessions for n_steps full-batch steps."""
+def mom_planes(cfg):
+    return 2 if cfg['momentum'] > 0 else 0
+
+
+def newest_profile(suffix):
+    """profiles/rNN_<suffix> of the newest round that has one (the files are written by tools/final_profile.sh on the GPU box)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_' + suffix)))
+    return hits[-1] if hits else os.path.join(ROOT, 'profiles', 'none_' + suffix)
+
+
+def rocprof_means(config):
+    """{bench kernel name: mean us} from the tracked rocprofv3 --kernel-trace --stats CSV of this config (+ '__file__')."""
+    import csv
+    path = newest_profile('kernel_stats_rocprofv3_%s.csv' % config)
+    if not os.path.exists(path):
+        return {}
+    out = {'__file__': os.path.relpath(path, ROOT)}
+    alias = {'k_gru_fwd_fused': 'k_gru_fwd', 'k_gru_bwd_fused': 'k_gru_bwd', 'k_score_bwd2': 'k_score_bwd'}
+    acc = {}
+    for r in csv.DictReader(open(path)):
+        name = r['Name'].split('(')[0].replace('void ', '').split('<')[0].strip()
+        name = alias.get(name, name)
+        t = acc.setdefault(name, [0.0, 0])
+        t[0] += float(r['TotalDurationNs']); t[1] += int(r['Calls'])
+    for name, (ns, n) in acc.items():
+        if n:
+            out[name] = ns / n / 1000.0
+    return out
+
+
+def make_plan(cfg, n_steps, rank, nranks, seed=42, session_items=0):
+    """RSC15-shaped sessions -> (plan, number of sessions).  Enough sessions for n_steps full-batch steps.
+    session_items: distinct items the SESSIONS are drawn from (0 = the whole catalogue); a smaller set is spread over the catalogue
+    by a fixed random injection (round 1-3 used 200,000 for the 3 M / 10 M-item configs: input / target rows were more
+    cache-resident than a real stream's; the negatives always covered the full catalogue)."""
     from gru4rec_amd import _native, synth
     B = cfg['batch_size']
     n_sessions = int(n_steps * B / 2.6) + 8 * B           # ~2.9 scoring events per session
-    n_items = min(cfg['n_items'], 200000)
+    n_items = min(cfg['n_items'], session_items) if session_items > 0 else cfg['n_items']
     data = synth.make_sessions(n_sessions * nranks, n_items=n_items, seed=seed)
     sizes = data.groupby('SessionId').size().values
     offs = np.zeros(len(sizes) + 1, dtype=np.int64)
     offs[1:] = np.cumsum(sizes)
     ids, inv = np.unique(data.ItemId.values, return_inverse=True)
     items_all = inv.astype(np.int32)
-    if cfg['n_items'] > n_items:
-        # spread the item ids over the full catalogue (large-table configs): a fixed random injection
+    if cfg['n_items'] > len(ids):
+        # the sessions name len(ids) distinct items (np.unique made them consecutive): spread them over the full catalogue with a
+        # fixed random injection, so that their rows lie all over the table and not in its first pages
         rng = np.random.RandomState(seed + 1)
         spread = np.sort(rng.choice(cfg['n_items'], size=len(ids), replace=False)).astype(np.int32)
         items_all = spread[items_all]
@@ -197,6 +233,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-micro', action='store_true', help='skip the row gather / scatter micro-benchmark object')
+    ap.add_argument('--session-items', type=int, default=0, help='distinct items the synthetic sessions are drawn from (0 = the whole catalogue of the '
+                    'config; rounds 1-3 used 200000 for cfg3 / cfg4)')
     ap.add_argument('--long-steps', type=int, default=2000, help='a run of --steps below this also times that many steps behind the timed region and '
                     'reports them as "long_run" (a 20-step window is ~1 ms; 0 = off)')
     args = ap.parse_args()
@@ -217,8 +255,8 @@ def main():
     # per-kernel durations behind the timed region: every rank runs those steps (the all-reduce is collective), rank 0 reports
     n_profile = args.profile_steps
     n_long = args.long_steps if (0 < args.steps < args.long_steps) else 0
-    total_steps = args.warmup + args.steps + n_long + n_profile + 8 + 64 + (min(args.steps, 2000) if (world > 1 or os.environ.get('G4R_FORCE_STAGED')) else 0)
-    plan, support = make_plan(cfg, total_steps, rank, world)
+    total_steps = args.warmup + args.steps + n_long + n_profile + max(8, n_profile // 4) + 8 + 64 + (min(args.steps, 2000) if (world > 1 or os.environ.get('G4R_FORCE_STAGED')) else 0)
+    plan, support = make_plan(cfg, total_steps, rank, world, session_items=args.session_items)
     assert plan['T'] >= total_steps, 'synthetic plan too short: %d < %d' % (plan['T'], total_steps)
     assert (plan['M'][:total_steps] == cfg['batch_size']).all()
     m = create_model(cfg, support, rank, world, local_rank if world > 1 else 0, unique_id, use_graph=not args.no_graph)
@@ -274,7 +312,9 @@ def main():
                                    cfg['n_items'], cfg['layers'], cfg['batch_size'], cfg['n_sample'], cfg['loss'])
                    if args.config == 'cfg2' else args.config,
                    'global_batch': cfg['batch_size'] * world, 'parallelism': 'session-sharded dp%d' % world,
-                   'hip_graph': not args.no_graph},
+                   'hip_graph': not args.no_graph,
+                   'session_items': int(min(cfg['n_items'], args.session_items) if args.session_items > 0 else cfg['n_items']),
+                   'distinct_items_in_plan': int(len(np.unique(np.concatenate([plan['in_idx'].ravel(), plan['out_idx'].ravel()]))))},
         'events_per_s': events / dt, 'loss_first': float(losses[0]), 'loss_last': float(losses[-1]),
         'loss_finite': bool(np.isfinite(losses).all()),
     }
@@ -288,6 +328,15 @@ def main():
         m.profile(False)
         kt = m.kernel_times()
     staged = world > 1 or bool(os.environ.get('G4R_FORCE_STAGED'))
+    kt_split = {}
+    if n_profile > 0 and world == 1 and not staged:
+        # the same again with the update launch split into its two roles (g4r_profile(m, 2)): the embedding gather / scatter -- the
+        # kernel north_star prices against the HBM roofline -- timed ALONE, next to the merged launch the step actually runs
+        n_split = max(8, n_profile // 4)
+        m.profile(2)
+        m.train_steps(args.warmup + args.steps + n_long + n_profile, n_split)
+        m.profile(False)
+        kt_split = m.kernel_times()
     reconcile = None
     if staged:
         # The timed region is the training step north_star defines for N > 1 (dense-gradient all-reduce every step, item rows
@@ -298,7 +347,7 @@ def main():
         K = GRU4Rec().sync_steps(max(world, 1)) or 16
         try:
             t_sync = []
-            base_t = args.warmup + args.steps + n_long + n_profile
+            base_t = args.warmup + args.steps + n_long + n_profile + max(8, n_profile // 4)
             spare = total_steps - base_t - 1
             reps = max(0, min(3, spare // max(K, 1)))
             m.comm_sync_sparse()                      # rows of the whole run so far: not timed
@@ -333,6 +382,26 @@ def main():
                                      'steps: step %.4f ms + %.4f ms amortised' % (K, len(t_sync), K, step_ms, ms / K)}
         except Exception as e:      # the reconciliation must not take the step measurement down with it
             reconcile = {'error': str(e)}
+    if world > 1 and reconcile and 'error' not in reconcile:
+        # N > 1: the headline is the throughput fit() achieves -- WITH the reconciliation of the item tables the model cannot train
+        # without.  Measured directly when the library reconciles inside g4r_train_steps (small tables), else the
+        # timed step plus the measured cost of a reconciliation amortised over sync_every steps.  The bare step (what north_star
+        # literally describes: all-reduce every step, item rows GPU-local) stays next to it as value_step_only.
+        meas = reconcile.get('measured_with_reconciliation_inside_train_steps')
+        out['value_step_only'] = out['value']
+        out['ms_per_step_step_only'] = out['ms_per_step']
+        if meas:
+            out['value'], out['ms_per_step'] = meas['value'], meas['ms_per_step']
+            out['value_source'] = ('%d steps with a reconciliation every %d steps inside g4r_train_steps (barrier / synchronize on both sides, max '
+                                   'over ranks); the --steps window without reconciliation is value_step_only' % (meas['steps'], reconcile['sync_every']))
+        else:
+            out['value'] = reconcile['value_with_reconciliation']
+            out['ms_per_step'] = 1000.0 * world / out['value']
+            out['value_source'] = ('timed --steps window + measured ms_per_reconciliation / sync_every (host-driven packed-parts exchange: the '
+                                   'item tables are too large for the on-stream dense form)')
+        out['events_per_s'] = out['events_per_s'] * out['value'] / out['value_step_only']
+        if args.config == 'cfg2':
+            out['vs_baseline'] = out['value'] / A30_PUBLISHED_MBS
     if world > 1:
         def us(name):
             return 1000.0 * kt[name][0] / max(kt[name][1], 1) if name in kt else None
@@ -364,13 +433,23 @@ def main():
                              bytes_GBps=a['bytes'] / per / (us * 1e-6) / 1e9)
                 e['frac'] = e['achieved'] / PEAK[e['bound']][0]
             kern[name] = e
+        # the second clock: mean duration per kernel in the tracked rocprofv3 --kernel-trace --stats summary of this command
+        # (STATIC file under profiles/, written by tools/final_profile.sh on an earlier call; the profiler's own clock reads up to 10 %
+        # more than the HIP events on the big launches, and its fraction is the one DESIGN.md quotes)
+        rp = rocprof_means(args.config)
+        for name, e in kern.items():
+            r_us = rp.get(name)
+            if r_us:
+                e['rocprofv3_avg_us'] = r_us
+                if 'frac' in e:
+                    e['frac_rocprofv3'] = e['frac'] * e['avg_us'] / r_us
         out['kernels'] = kern
+        out['kernel_clock_note'] = ('avg_us / frac: HIP events attached to the dispatches in THIS run; rocprofv3_avg_us / frac_rocprofv3: %s '
+                                    '(static file of an earlier rocprofv3 --kernel-trace --stats pass of the same command)' % rp.get('__file__', 'no tracked rocprofv3 summary found'))
         out['kernel_time_sum_us_per_step'] = sum(1000.0 * ms / n_profile for ms, n in kt.values())
         dom = max(kern.items(), key=lambda kv: kv[1]['avg_us'] * kv[1]['launches_per_step'])
         out['dominant_kernel'] = dom[0]
-        pmc_path = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic_%s.json' % args.config)
-        if not os.path.exists(pmc_path):
-            pmc_path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_%s.json' % args.config)
+        pmc_path = newest_profile('pmc_traffic_%s.json' % args.config)
         pmc = json.load(open(pmc_path))['kernels'] if os.path.exists(pmc_path) else {}
 
         def traffic_of(name):      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_summary.py), bytes per launch
@@ -388,8 +467,9 @@ def main():
                                'traffic_source': ('%s (STATIC file: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this '
                                                   'command, tools/pmc_traffic.sh; not measured by the run that prints this line)' %
                                                   os.path.relpath(pmc_path, ROOT)) if pmc else None,
-                               'avg_us_source': 'HIP events attached to the dispatches (hipExtLaunchKernelGGL) in this run; rocprofv3 '
-                                                '--kernel-trace of the same command reads 0.3-0.9 us more per kernel (profiles/r0x_kernel_stats_*)',
+                               'rocprofv3_avg_us': dv.get('rocprofv3_avg_us'), 'frac_rocprofv3': dv.get('frac_rocprofv3'),
+                               'avg_us_source': 'HIP events attached to the dispatches (hipExtLaunchKernelGGL) in this run; rocprofv3_avg_us / '
+                                                'frac_rocprofv3: the tracked rocprofv3 --kernel-trace summary of the same command (kernel_clock_note)',
                                'note': 'dominant kernel of the step by time; achieved = algorithmic %s per launch / mean launch duration '
                                        '(HIP events attached to the dispatches, %d steps); traffic = 2 x FETCH_SIZE + WRITE_SIZE from separate '
                                        'rocprofv3 --pmc passes (profiles/%s) when that file is present' % (
@@ -402,9 +482,27 @@ def main():
             k = kern[rk]
             sparse_bytes = alg['k_sparse_update']['bytes']
             gbps = sparse_bytes / (k['avg_us'] * 1e-6) / 1e9
+            alone = None
+            if 'k_sparse_update' in kt_split:
+                ms_a, n_a = kt_split['k_sparse_update']
+                us_a = 1000.0 * ms_a / max(n_a, 1)
+                ms_d, n_d = kt_split.get('k_dense_grad', (0.0, 0))
+                # bytes this kernel REALLY moves since round 4: single-occurrence rows (accumulator written in place by the producer
+                # of the step row) cost a step-row read and a parameter read + write = 3 row transfers, not 8d's 5
+                moved = (3 + mom_planes(cfg)) * (2 * cfg['batch_size'] + cfg['n_sample']) * cfg['layers'][-1] * 4
+                alone = {'kernel': 'k_sparse_update', 'avg_us': us_a, 'launches': n_a,
+                         'achieved': sparse_bytes / (us_a * 1e-6) / 1e9, 'frac': sparse_bytes / (us_a * 1e-6) / 1e9 / 8000.0, 'unit': 'GB/s',
+                         'traffic': traffic_of('k_sparse_update'),
+                         'rows_moved_bytes': moved, 'achieved_on_rows_moved': moved / (us_a * 1e-6) / 1e9,
+                         'k_dense_grad_alone_us': (1000.0 * ms_d / n_d) if n_d else None,
+                         'note': 'g4r_profile(m, 2): the sparse row update as a launch of its own (k_sparse_update; the dense-gradient tiles '
+                                 'run as k_dense_grad next to it), HIP events on the dispatches; achieved / frac price it with SURVEY 8d\'s '
+                                 'sparse bytes like the merged launch; rows_moved_bytes is what it reads and writes if every row is a '
+                                 'single occurrence (3 row transfers: the accumulator is updated in place by the gradient producer)'}
             out['roofline_gather_scatter'] = {
                 'kernel': rk, 'bound': 'hbm', 'achieved': gbps, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbps / 8000.0,
                 'traffic': traffic_of(rk), 'sparse_bytes': sparse_bytes, 'avg_us': k['avg_us'],
+                'rocprofv3_avg_us': k.get('rocprofv3_avg_us'), 'sparse_role_alone': alone,
                 'dense_param_bytes_same_launch': (alg['k_update']['bytes'] - sparse_bytes) if rk == 'k_update' else 0,
                 'note': 'sparse bytes per launch = (5 R D + 5 N + R) * 4, R = 2B + n_sample gathered rows, N = B + n_sample score columns '
                         '(SURVEY 8d); on one GPU the same launch also holds the dense-gradient tiles (their parameter / accumulator bytes '

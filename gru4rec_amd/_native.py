@@ -327,7 +327,8 @@ class Model:
         _chk(lib().g4r_set_step_counters(self.h, int(global_step), int(refills)))
 
     def profile(self, enable):
-        _chk(lib().g4r_profile(self.h, 1 if enable else 0))
+        """False / True, or 2: profile with the update launch split into its two roles (k_dense_grad, k_sparse_update)."""
+        _chk(lib().g4r_profile(self.h, 2 if enable == 2 else (1 if enable else 0)))
 
     def kernel_times(self):
         out = {}

@@ -97,6 +97,7 @@ struct g4r_model {
     bool dist_graph_failed = false;              // capturing the step with its RCCL all-reduce did not work: head graph + eager tail
     // profiling
     bool profiling = false;
+    bool profile_split = false;
     double kn_ms[KN_COUNT] = {0};
     int64_t kn_n[KN_COUNT] = {0};
     std::vector<hipEvent_t> evs;
@@ -478,17 +479,24 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_a, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_b, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_dense_grad<0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_update<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_update<1, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_update<1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_dense_grad<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update_generic<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update_generic<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update_generic<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_update<1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_update<1, 32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_update<1, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_store, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -861,7 +869,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         else LK(k_gru_bwd_b, dim3(cdiv(d.IN[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_BB, s, dmp, stp, l);
         end();
     }
-    merged = merged_update(m);
+    merged = merged_update(m) && !(recs && m->profile_split);      // g4r_profile(m, 2): the two roles of k_update as launches of their own
     if (merged) {
         // dense-gradient tiles (+ fused dense Adagrad on a single GPU; gradients to the RCCL buffer otherwise) and the sparse row
         // update in ONE launch (k_update): the two are independent, the all-reduce / dense apply of N > 1 follow behind
@@ -869,13 +877,18 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         const dim3 grid(m->ntiles + m->nblk_occ + 1), blk(SP_WAVES * 64);
         const bool one = row_chunks(d) == 1;
         begin(KN_UPDATE);
+        const bool mo = d.mom > 0.f;
+#define G4R_LK_UPDATE(CH, DT_)                                                                                                          \
+        do {                                                                                                                            \
+            if (mo) LK((k_update<CH, DT_, true>), grid, blk, smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);  \
+            else LK((k_update<CH, DT_, false>), grid, blk, smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);    \
+        } while (0)
         if (m->dt == 0) {
-            if (one) LK((k_update<1, 0>), grid, blk, smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);
-            else LK((k_update<2, 0>), grid, blk, smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);
+            if (one) G4R_LK_UPDATE(1, 0); else G4R_LK_UPDATE(2, 0);
         } else {
-            if (one) LK((k_update<1, 32>), grid, blk, smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);
-            else LK((k_update<2, 32>), grid, blk, smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);
+            if (one) G4R_LK_UPDATE(1, 32); else G4R_LK_UPDATE(2, 32);
         }
+#undef G4R_LK_UPDATE
         end();
         if (d.apply_dense_inplace || part == 1) { HIPCHK(hipGetLastError()); return 0; }
     } else {
@@ -886,7 +899,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     }
     }
     if (part == 1) { HIPCHK(hipGetLastError()); return 0; }
-    if (part == 2) merged = merged_update(m);
+    if (part == 2) merged = merged_update(m) && !(recs && m->profile_split);
     // multi-rank: dense-gradient all-reduce, dense Adagrad, then the sparse embedding update, in stream order.
     // Optionally the first two run on their own stream next to the sparse update (which touches item rows only)
     // and join before the next step reads the GRU weights
@@ -928,9 +941,17 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     }
     if (merged) { HIPCHK(hipGetLastError()); return 0; }
     begin(KN_SPARSE);
-    if (row_chunks(d) == 1) LK(k_sparse_update<1>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
-    else if (row_chunks(d) == 2) LK(k_sparse_update<2>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
-    else LK(k_sparse_update<4>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
+    {
+        const bool mo = d.mom > 0.f;
+        const dim3 grid(m->nblk_occ + 1), blk(SP_WAVES * 64);
+#define G4R_LK_SPARSE(CH)                                                                                            \
+        do {                                                                                                         \
+            if (mo) LK((k_sparse_update<CH, true>), grid, blk, m->smem_sparse, s, dmp, stp, m->nblk_occ);            \
+            else LK((k_sparse_update<CH, false>), grid, blk, m->smem_sparse, s, dmp, stp, m->nblk_occ);              \
+        } while (0)
+        if (row_chunks(d) == 1) G4R_LK_SPARSE(1); else if (row_chunks(d) == 2) G4R_LK_SPARSE(2); else G4R_LK_SPARSE(4);
+#undef G4R_LK_SPARSE
+    }
     end();
     if (overlap) HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0));
 #undef begin
@@ -1190,6 +1211,7 @@ int g4r_set_step_counters(g4r_model* m, int64_t global_step, int64_t refills) {
 int g4r_profile(g4r_model* m, int32_t enable) {
     if (!m) return fail("null model");
     m->profiling = enable != 0;
+    m->profile_split = enable == 2;      // the sparse row update timed ALONE (k_sparse_update next to k_dense_grad instead of the merged k_update)
     if (enable) for (int i = 0; i < KN_COUNT; ++i) { m->kn_ms[i] = 0; m->kn_n[i] = 0; }
     return 0;
 }

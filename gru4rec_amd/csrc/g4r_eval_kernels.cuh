@@ -237,18 +237,25 @@ __global__ void k_selftest_mfma32(const float* A, const float* Bm, float* C, int
 }
 
 // explicit instantiations: the launching host code is not visible to the device pass
-template __global__ void k_sparse_update<1>(const DevModel*, StepState*, int);
-template __global__ void k_sparse_update<2>(const DevModel*, StepState*, int);
+template __global__ void k_sparse_update<1, false>(const DevModel*, StepState*, int);
+template __global__ void k_sparse_update<1, true>(const DevModel*, StepState*, int);
+template __global__ void k_sparse_update<2, false>(const DevModel*, StepState*, int);
+template __global__ void k_sparse_update<2, true>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update_generic<1>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update_generic<2>(const DevModel*, StepState*, int);
 template __global__ void k_loss_rows<false>(const DevModel*, StepState*);
 template __global__ void k_loss_rows<true>(const DevModel*, StepState*);
-template __global__ void k_sparse_update<4>(const DevModel*, StepState*, int);
+template __global__ void k_sparse_update<4, false>(const DevModel*, StepState*, int);
+template __global__ void k_sparse_update<4, true>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update_generic<4>(const DevModel*, StepState*, int);
-template __global__ void k_update<1, 32>(const DevModel*, StepState*, const DenseTile*, int, int);
-template __global__ void k_update<2, 32>(const DevModel*, StepState*, const DenseTile*, int, int);
-template __global__ void k_update<1, 0>(const DevModel*, StepState*, const DenseTile*, int, int);
-template __global__ void k_update<2, 0>(const DevModel*, StepState*, const DenseTile*, int, int);
+template __global__ void k_update<1, 32, false>(const DevModel*, StepState*, const DenseTile*, int, int);
+template __global__ void k_update<1, 32, true>(const DevModel*, StepState*, const DenseTile*, int, int);
+template __global__ void k_update<2, 32, false>(const DevModel*, StepState*, const DenseTile*, int, int);
+template __global__ void k_update<2, 32, true>(const DevModel*, StepState*, const DenseTile*, int, int);
+template __global__ void k_update<1, 0, false>(const DevModel*, StepState*, const DenseTile*, int, int);
+template __global__ void k_update<1, 0, true>(const DevModel*, StepState*, const DenseTile*, int, int);
+template __global__ void k_update<2, 0, false>(const DevModel*, StepState*, const DenseTile*, int, int);
+template __global__ void k_update<2, 0, true>(const DevModel*, StepState*, const DenseTile*, int, int);
 template __global__ void k_dense_grad<0>(const DevModel*, StepState*, const DenseTile*);
 template __global__ void k_dense_grad<32>(const DevModel*, StepState*, const DenseTile*);
 template __global__ void k_score_fwd<GT_BN, GT_BK>(const DevModel*, StepState*);

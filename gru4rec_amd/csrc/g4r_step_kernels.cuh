@@ -1145,7 +1145,14 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
         // the per-occurrence Adagrad scaling (gru4rec.py:335-340) happens here, in parallel over all occurrences:
         // every occurrence uses the PRE-step accumulator of its item, so the steps are independent; the sparse
         // kernel only has to add them up in occurrence order.
-        const GAS float *accWy = m.accWy, *accBy = m.accBy;
+        // An item that occurs ONCE among the step's gathered rows (count field of its occ_fl entry, complete since the forward
+        // kernels; ~80 % of the occurrences) gets its new accumulator written IN PLACE right here -- this epilogue holds acc[item]
+        // already -- so that the update kernel moves three rows for it (step read, parameter read + write) instead of five, and the
+        // dA plane is only written for items with several occurrences (all of which must see the PRE-step accumulator: they go
+        // through dA and the owner wave of the update kernel as before).  The parameter itself cannot be written here: role B of
+        // this launch gathers the same Wy rows.
+        GAS float *accWy = m.accWy, *accBy = m.accBy;
+        const GAS int* occ_fl = m.occ_fl;
         GAS float *dSy = m.dSy, *dAy = m.dAy, *dSBy = m.dSBy, *dABy = m.dABy;
         const float lr = m.lr;
         const bool generic = m.generic != 0;
@@ -1153,15 +1160,23 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
             const int item = (n - n0 < TB) ? sIt[n - n0] : -1;
             const bool ok = item >= 0 && d <= D;
             const float a = (d < D) ? ldf_at(accWy, (size_t)max(item, 0) * D + d, ok) : ldf_at(accBy, max(item, 0), ok);
-            return make_float4(a, ok ? 1.f : 0.f, 0.f, 0.f);
+            const int cnt = occ_fl[4 * (size_t)max(item, 0) + 2];
+            return make_float4(a, ok ? 1.f : 0.f, __int_as_float(cnt), 0.f);
         };
         auto epi = [&](int n, int d, float g, float4 p) {
             if (n >= N || d > D) return;
             const float an = p.x + G4R_MUT_ACC(g * g);
             float step = (p.y != 0.f) ? G4R_MUT_STEP(lr * g * frsq(an + G4R_EPS_ADAGRAD)) : 0.f;
             if (generic) step = (p.y != 0.f) ? g : 0.f;      // raw per-occurrence gradient: the update kernel applies the rule
-            if (d < D) { dSy[(size_t)n * D + d] = step; dAy[(size_t)n * D + d] = an; }
-            else { dSBy[n] = step; dABy[n] = an; }
+            const bool single = !generic && p.y != 0.f && __float_as_int(p.z) == 1;
+            const int item = single ? sIt[n - n0] : 0;
+            if (d < D) {
+                dSy[(size_t)n * D + d] = step;
+                if (single) accWy[(size_t)item * D + d] = an; else dAy[(size_t)n * D + d] = an;
+            } else {
+                dSBy[n] = step;
+                if (single) accBy[item] = an; else dABy[n] = an;
+            }
         };
         gemm_tile<TB, TB, TBK, true, false, GT_NTH>(n0, d0, M, aload, bload, pre, epi, smem);
         return;
@@ -1226,19 +1241,23 @@ __global__ __launch_bounds__(256, G4R_BWD2_WPE) void k_score_bwd2(const DevModel
         auto bptr = [&](int kk, int kr, int cc) -> const GAS float* {       // h[b = kk + kr][d0 + cc ..]
             return (kk + kr < M) ? h + (size_t)(kk + kr) * D + d0 + cc : nullptr;
         };
-        const GAS float* accWy = m.accWy;
+        GAS float* accWy = m.accWy;
+        const GAS int* occ_fl = m.occ_fl;
         GAS float *dSy = m.dSy, *dAy = m.dAy;
-        auto pre = [&](int n, int d) -> float4 {
+        auto pre = [&](int n, int d) -> float4 {      // (accumulator in place for single-occurrence items: see k_score_bwd)
             const int item = sIt[n - n0];
             const bool ok = item >= 0;
-            return make_float4(ldf_at(accWy, (size_t)max(item, 0) * D + d, ok), ok ? 1.f : 0.f, 0.f, 0.f);
+            const int cnt = occ_fl[4 * (size_t)max(item, 0) + 2];
+            return make_float4(ldf_at(accWy, (size_t)max(item, 0) * D + d, ok), ok ? 1.f : 0.f, __int_as_float(cnt), 0.f);
         };
         auto epi = [&](int n, int d, float g, float4 p) {
             if (n >= N) return;
             const float an = p.x + G4R_MUT_ACC(g * g);
             float step = (p.y != 0.f) ? G4R_MUT_STEP(lr * g * frsq(an + G4R_EPS_ADAGRAD)) : 0.f;
             if (generic) step = (p.y != 0.f) ? g : 0.f;
-            dSy[(size_t)n * D + d] = step; dAy[(size_t)n * D + d] = an;
+            dSy[(size_t)n * D + d] = step;
+            if (!generic && p.y != 0.f && __float_as_int(p.z) == 1) accWy[(size_t)sIt[n - n0] * D + d] = an;
+            else dAy[(size_t)n * D + d] = an;
         };
         if (trc && tid == 0) trc[1] = wall_clock64();
         gemm_tile2k<true, false>(n0, d0, M, aptr, bptr, m.zrow, pre, epi, smem, trc);
@@ -1289,10 +1308,12 @@ __global__ __launch_bounds__(256, G4R_BWD2_WPE) void k_score_bwd2(const DevModel
             const float g = (smem[cl] + smem[64 + cl]) + (smem[128 + cl] + smem[192 + cl]);
             const int item = m.col_item[n];
             const bool ok = item >= 0;
+            const int cnt = m.occ_fl[4 * (size_t)max(item, 0) + 2];
             const float an = ldf_at(m.accBy, max(item, 0), ok) + G4R_MUT_ACC(g * g);
             float step = ok ? G4R_MUT_STEP(lr * g * frsq(an + G4R_EPS_ADAGRAD)) : 0.f;
             if (generic) step = ok ? g : 0.f;
-            m.dSBy[n] = step; m.dABy[n] = an;
+            m.dSBy[n] = step;
+            if (!generic && ok && cnt == 1) m.accBy[item] = an; else m.dABy[n] = an;
         }
     }
 }
@@ -1386,14 +1407,16 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_bwd_b(const DevModel* __rest
         const int n = n0 + r, k = kk + cc;
         return ld4_if(Wx, (size_t)n * D3 + k, n < IN && k < D3);
     };
-    const GAS float* accT = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.accWy : m.accE;
+    GAS float* accT = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.accWy : m.accE;
+    const GAS int* occ_fl = m.occ_fl + 4 * ((m.embed_mode == G4R_EMBED_CONSTRAINED) ? (size_t)0 : (size_t)m.n_items);
     const float lr = m.lr, drop_e = m.drop_e;
     const bool generic = m.generic != 0;
     const unsigned long long seed = m.seed;
     GAS float *dSx = m.dSx, *dAx = m.dAx, *dylo = (l > 0) ? m.dyl[l - 1] : nullptr;
-    auto pre = [&](int row, int n) -> float4 {      // pre-step accumulator of the input item's row (layer 0)
+    auto pre = [&](int row, int n) -> float4 {      // pre-step accumulator of the input item's row (layer 0) and its occurrence count
         const int item = (row - m0 < GT_BM) ? sRow[row - m0] : -1;
-        return make_float4(ldf_at(accT, (size_t)max(item, 0) * IN + n, item >= 0 && n < IN), 0.f, 0.f, 0.f);
+        const int cnt = occ_fl[4 * (size_t)max(item, 0) + 2];
+        return make_float4(ldf_at(accT, (size_t)max(item, 0) * IN + n, item >= 0 && n < IN), __int_as_float(cnt), 0.f, 0.f);
     };
     auto epi = [&](int row, int n, float v, float4 p) {
         if (row >= M || n >= IN) return;
@@ -1401,7 +1424,9 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_bwd_b(const DevModel* __rest
             if (drop_e > 0.f) v *= drop_mult(seed, (unsigned)c.g, G4R_STREAM_DROP_EMBED, row, n, 1.0f - drop_e);
             const float an = p.x + G4R_MUT_ACC(v * v);
             dSx[(size_t)row * IN + n] = generic ? v : G4R_MUT_STEP(lr * v * frsq(an + G4R_EPS_ADAGRAD));
-            dAx[(size_t)row * IN + n] = an;
+            // single-occurrence item: new accumulator in place (see k_score_bwd), else through dA and the update kernel's owner wave
+            if (!generic && __float_as_int(p.y) == 1) accT[(size_t)sRow[row - m0] * IN + n] = an;
+            else dAx[(size_t)row * IN + n] = an;
         } else {
             dylo[(size_t)row * IN + n] = v;
         }
@@ -1570,13 +1595,16 @@ __global__ __launch_bounds__(512) void k_gru_bwd_fused(const DevModel* __restric
     __syncthreads();
     if (clk && tid == 0) clk[4] = wall_clock64();
     // stage-2 epilogue operands (waves 0, 1): pre-step accumulator of the input item's row, layer 0 (as k_gru_bwd_b)
-    const GAS float* accT = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.accWy : m.accE;
+    GAS float* accT = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.accWy : m.accE;
+    const GAS int* occ_flT = m.occ_fl + 4 * ((m.embed_mode == G4R_EMBED_CONSTRAINED) ? (size_t)0 : (size_t)m.n_items);
     const int ns2 = wid & 1, kq = wid >> 1;
     float a2[4];
+    int cnt2[4];      // occurrences of the row's item among the step's gathered rows (1: accumulator written in place below)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
         const int item = sRow[4 * lg + rg], n = n0 + ns2 * 16 + li;
         a2[rg] = ldf_at(accT, (size_t)max(item, 0) * IN + n, item >= 0 && n < IN);
+        cnt2[rg] = occ_flT[4 * (size_t)max(item, 0) + 2];
     }
     // k-steps in fully unrolled groups of 8 (all fragment reads ahead of the MFMAs); steps past kend read on inside the
     // workgroup's LDS and are replaced by zeros
@@ -1640,7 +1668,8 @@ __global__ __launch_bounds__(512) void k_gru_bwd_fused(const DevModel* __restric
             if (drop_e > 0.f) v *= drop_mult(seed, (unsigned)c.g, G4R_STREAM_DROP_EMBED, row, n, 1.0f - drop_e);
             const float an = a2[rg] + G4R_MUT_ACC(v * v);
             dSx[(size_t)row * IN + n] = generic ? v : G4R_MUT_STEP(lr * v * frsq(an + G4R_EPS_ADAGRAD));
-            dAx[(size_t)row * IN + n] = an;
+            if (!generic && cnt2[rg] == 1) accT[(size_t)sRow[4 * lg + rg] * IN + n] = an;      // single occurrence: in place (see k_score_bwd)
+            else dAx[(size_t)row * IN + n] = an;
         } else {
             dylo[(size_t)row * IN + n] = v;
         }
@@ -1670,8 +1699,10 @@ __global__ __launch_bounds__(256) void k_onehot_step(const DevModel* __restrict_
     const float lr = m.lr;
     const float4 g = ld4(m.dV[0] + (size_t)row * W + 4 * c4);
     const float4 a = ld4(m.accE + (size_t)item * W + 4 * c4);
+    const int cnt = m.occ_fl[4 * ((size_t)m.n_items + item) + 2];
     const float4 an = make_float4(a.x + g.x * g.x, a.y + g.y * g.y, a.z + g.z * g.z, a.w + g.w * g.w);
-    st4(m.dAx + (size_t)row * W + 4 * c4, an);
+    if (!m.generic && cnt == 1) st4(m.accE + (size_t)item * W + 4 * c4, an);      // single occurrence: in place (see k_score_bwd)
+    else st4(m.dAx + (size_t)row * W + 4 * c4, an);
     if (m.generic) { st4(m.dSx + (size_t)row * W + 4 * c4, g); return; }
     st4(m.dSx + (size_t)row * W + 4 * c4, make_float4(lr * g.x * frsq(an.x + G4R_EPS_ADAGRAD), lr * g.y * frsq(an.y + G4R_EPS_ADAGRAD),
                                                          lr * g.z * frsq(an.z + G4R_EPS_ADAGRAD), lr * g.w * frsq(an.w + G4R_EPS_ADAGRAD)));
@@ -1967,8 +1998,12 @@ __global__ __launch_bounds__(256) void k_dense_apply(const DevModel* __restrict_
 //   no momentum:  P = P0 - (S + n*reg)                      reg = lr*lmbd*P0
 //   momentum:     P = P0 + n*mom*V0 - (S + n*reg) ,  V = mom*V0 - (s_k + reg)
 //   A = dA[k]
+// Items with ONE occurrence (count field of occ_fl == 1; ~80 % of a step's rows) have had their accumulator written in place by
+// the gradient producer (k_score_bwd* / k_gru_bwd_* epilogues): for them this kernel moves THREE rows -- step row read, parameter
+// row read + write -- and is done before the workgroup's first barrier.  Only items with several occurrences go through dA (read
+// by the owner once the count is known) and the occurrence list.
 // One wave per occurrence k of (X | Y | samples); the wave of an item's LAST occurrence owns the row, so the
-// row state, s_k and dA[k] can be requested before anything is known about duplicates.  The occurrence list is
+// row state and s_k can be requested before anything is known about duplicates.  The occurrence list is
 // staged in LDS once per workgroup and scanned with ballots.  Up to SP_UB earlier occurrences are summed by the
 // owner in one batch of loads (one round trip); hotter items (popularity-sampled negatives repeat the head of
 // the catalogue dozens of times per step) are summed by all SP_WAVES waves of the workgroup together, wave w taking
@@ -1976,29 +2011,37 @@ __global__ __launch_bounds__(256) void k_dense_apply(const DevModel* __restrict_
 // The extra last block folds the per-row losses into loss_steps[t] and advances the step state.
 #define SP_WAVES 8   // occurrences (waves) per workgroup
 #ifndef SP_UB
-#define SP_UB 8
+#define SP_UB 4
 #endif
-// SP_UB: float4 step-row chunks one lane fetches together; items with more earlier occurrences are "hot"
+#ifndef SP_HOT
+#define SP_HOT 8
+#endif
+// SP_UB: float4 step-row chunks one lane fetches together (one round trip); SP_HOT: items with more earlier occurrences (in
+// float4 chunks per lane) are "hot".  (Round 3 fetched SP_HOT chunks per round trip: 32 more registers at the peak of a path a
+// fifth of the waves take, which cost the kernel its spills; 5-8 earlier occurrences now take two round trips.)
 
-// MAXCH = float4 chunks per lane (1: row width <= 256, 2: <= 512, 4: <= 1024).
-template <int MAXCH>
+// MAXCH = float4 chunks per lane (1: row width <= 256, 2: <= 512, 4: <= 1024).  MOM: the model trains with momentum (velocity
+// rows read and written; a compile-time switch: as a run-time one its condition mask was the last scalar register hipcc spilled).
+template <int MAXCH, bool MOM>
 __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__ mp, StepState* st, int nblk_occ, int blk, float* smem) {
     const DevModel& m = *mp;
-    constexpr int UB = SP_UB / MAXCH;
+    constexpr int UB = SP_UB / MAXCH, HOT = SP_HOT / MAXCH;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const StepCtx c = load_ctx(st);
     const int B = m.B, R = m.R;
     // descriptor fields used inside loops are snapshotted into registers: re-reading them through `mp` costs a
     // scalar-memory round trip per iteration (the compiler does not hoist them across the global stores)
     const float lr = m.lr, momc = m.mom, lmbd = m.lmbd;
     const bool constrained = (m.embed_mode == G4R_EMBED_CONSTRAINED);
-    GAS float *tE = m.E, *tWy = m.Wy, *tvE = m.velE, *tvWy = m.velWy, *tBy = m.By, *taBy = m.accBy, *tvBy = m.velBy,
-              *taE = m.accE, *taWy = m.accWy;
+    // (the output-bias tables are NOT snapshotted: they are used twice, far apart, and holding six more scalar registers across
+    // the whole kernel made hipcc spill eight of them to vector lanes)
+    GAS float *tE = m.E, *tWy = m.Wy, *tvE = m.velE, *tvWy = m.velWy, *taE = m.accE, *taWy = m.accWy;
     const int wE = m.Ein, wY = m.Dtop;
     const GAS int* g_occ = m.occ_idx;
-    const GAS float *g_dSx = m.dSx, *g_dSy = m.dSy, *g_dAx = m.dAx, *g_dAy = m.dAy, *g_dSBy = m.dSBy, *g_dABy = m.dABy;
+    const GAS float *g_dSx = m.dSx, *g_dSy = m.dSy, *g_dSBy = m.dSBy;      // (the dA planes are only read by owners of repeated items: not snapshotted)
     if (blk == nblk_occ) {
         // ---- bookkeeping block: cost = sum_i L_i / batch_size (gru4rec.py:577), NaN flag (:626), advance state
+        // (the only block of this role that needs the step context: the row update works from occ_idx / occ_fl alone)
+        const StepCtx c = load_ctx(st);
         const int Mn = m.Mplan[c.t + 1];     // the plan carries one trailing entry (and one trailing row)
         if (wid == 0) {
             float s = 0.f;
@@ -2036,7 +2079,7 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     // short occurrence lists (Rpad <= 4096) are requested right away, next to the first loads of the wave, and only written to
     // LDS if some wave turns out to own an item with earlier occurrences; longer lists are fetched when that is known (for
     // those the loads below all go to element 0: one cache line per wave, no branch between the loads)
-    constexpr int EARLY = 2;
+    constexpr int EARLY = (MAXCH >= 2 && MOM) ? 1 : 2;      // (momentum at two chunks per lane: the second early quad is what would spill)
     const int n4 = Rpad >> 2;
     const GAS int4* g_occ4 = (const GAS int4*)g_occ;
     const bool early = n4 <= EARLY * SP_WAVES * 64;
@@ -2053,7 +2096,7 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     GAS float* V = tableE ? tvE : tvWy;
     const int W = tableE ? wE : wY;
     const int nc4 = W >> 2;
-    const bool mom = momc > 0.f;
+    constexpr bool mom = MOM;
     const bool bias = (k >= B);
     // ---- the item's (last, first, count) entry (published with atomics by k_gru_p1 / k_score_fwd), the row state and
     // the last occurrence's step / accumulator rows: one round trip (unconditional loads with clamped indices:
@@ -2062,20 +2105,18 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     GAS int* flp = g_fl + 4 * ((tableE ? (size_t)nI : 0) + item_c);
     const int4 fl = ldi4(flp);
     const GAS float* srow_k = (k_c < B) ? g_dSx + (size_t)k_c * W : g_dSy + (size_t)(k_c - B) * W;
-    const GAS float* arow_k = (k_c < B) ? g_dAx + (size_t)k_c * W : g_dAy + (size_t)(k_c - B) * W;
-    float4 pz[MAXCH], vz[MAXCH], sk[MAXCH], ak[MAXCH];
+    float4 pz[MAXCH], vz[MAXCH], sk[MAXCH];
 #pragma unroll
     for (int q = 0; q < MAXCH; ++q) {
         const int cc = 4 * min(lane + 64 * q, nc4 - 1);
         pz[q] = ld4(P + (size_t)item_c * W + cc);
         sk[q] = ld4(srow_k + cc);
-        ak[q] = ld4(arow_k + cc);
         vz[q] = mom ? ld4(V + (size_t)item_c * W + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float bpz = 0.f, bvz = 0.f, bsk = 0.f, bak = 0.f;
+    float bpz = 0.f, bvz = 0.f, bsk = 0.f;
     if (bias) {
-        bpz = tBy[item_c]; bsk = g_dSBy[k_c - B]; bak = g_dABy[k_c - B];
-        if (mom) bvz = tvBy[item_c];
+        bpz = m.By[item_c]; bsk = g_dSBy[k_c - B];
+        if (mom) bvz = m.velBy[item_c];
     }
     // the wave of the item's last occurrence owns the row (and clears the item's entry for the next step)
     const bool owner = item >= 0 && fl.x == k + 1;
@@ -2087,10 +2128,63 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     // the order the list walk would have used: no occurrence list, no second round trip for the step rows.
     const bool allsmp = owner && fl.z > 1 && first_j >= 2 * B;
     const bool dup = owner && fl.z > 1 && !allsmp;
-    const bool hot = owner && fl.z - 1 > UB && !allsmp;
+    const bool hot = owner && fl.z - 1 > HOT && !allsmp;
     if (owner && lane == 0) {
         *(GAS int4*)flp = make_int4(0, 0, 0, 0);
         if (m.touched) m.touched[(tableE ? (size_t)nI : 0) + item] = 1;
+    }
+    // final row values from the sum `ss` of the item's step rows, the last occurrence's step row `sl` and the pre-step row state;
+    // n occurrences in all, nb of them among Y | samples (the output bias is only touched by those, gru4rec.py:486-489)
+    auto finish = [&](const float4 (&S)[MAXCH], float Sb, int n, int nb) {
+        const float fn = (float)n;
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) {
+            const int c4 = lane + 64 * q;
+            const float p0[4] = {pz[q].x, pz[q].y, pz[q].z, pz[q].w}, v0[4] = {vz[q].x, vz[q].y, vz[q].z, vz[q].w};
+            const float sl[4] = {sk[q].x, sk[q].y, sk[q].z, sk[q].w};
+            const float ss[4] = {S[q].x + sk[q].x, S[q].y + sk[q].y, S[q].z + sk[q].z, S[q].w + sk[q].w};
+            float pn[4], vn[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float reg = (lmbd > 0.f) ? lr * lmbd * p0[e] : 0.f;
+                const float tot = (lmbd > 0.f) ? ss[e] + fn * reg : ss[e];
+                if (mom) { vn[e] = momc * v0[e] - (sl[e] + reg); pn[e] = p0[e] + (fn * (momc * v0[e]) - tot); }
+                else { vn[e] = 0.f; pn[e] = p0[e] - tot; }
+            }
+            if (c4 < nc4) {
+                const size_t o = (size_t)item * W + 4 * c4;
+                st4(P + o, make_float4(pn[0], pn[1], pn[2], pn[3]));
+                if (mom) st4(V + o, make_float4(vn[0], vn[1], vn[2], vn[3]));
+            }
+        }
+        if (bias && lane == 0) {
+            const float fb = (float)nb;
+            const float reg = (lmbd > 0.f) ? lr * lmbd * bpz : 0.f;
+            const float sb = Sb + bsk;
+            const float tot = (lmbd > 0.f) ? sb + fb * reg : sb;
+            if (mom) { m.By[item] = bpz + (fb * (momc * bvz) - tot); m.velBy[item] = momc * bvz - (bsk + reg); }
+            else m.By[item] = bpz - tot;
+        }
+    };
+    float4 S[MAXCH];
+    float Sb = 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) S[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ---- the common case: the item's only occurrence.  Its accumulator is already in place (written by the producer of the step
+    // row); parameter (and velocity) rows are final right here, ahead of the workgroup's barrier
+    const bool single = owner && fl.z == 1;
+    if (single) finish(S, 0.f, 1, bias ? 1 : 0);
+    // owners of items with several occurrences: the last occurrence's accumulator row (dA plane), requested now that the count
+    // is known -- it lands during the barrier / the list walk below
+    float4 ak[MAXCH];
+    float bak = 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) ak[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (owner && !single) {      // wave-uniform
+        const GAS float* arow_k = (k_c < B) ? m.dAx + (size_t)k_c * W : m.dAy + (size_t)(k_c - B) * W;
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) ak[q] = ld4(arow_k + 4 * min(lane + 64 * q, nc4 - 1));
+        if (bias) bak = m.dABy[k_c - B];
     }
     const long long t_own = G4R_DBGCLK(m) ? wall_clock64() : 0;
 
@@ -2099,14 +2193,15 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     auto scan = [&](int it, int a, int b, int pass, int& nb) {
         int idx = 0;
         nb = 0;
-        for (int base0 = a & ~255; base0 < b; base0 += 1024) {
+        constexpr int NV = (MAXCH >= 2 && MOM) ? 2 : 4;      // (momentum at two chunks per lane: the register budget is at its limit)
+        for (int base0 = a & ~255; base0 < b; base0 += 256 * NV) {
             // 1024 entries per step: four 16-byte LDS reads per lane (four consecutive entries each) are requested together;
             // reads past Rpad stay inside the workgroup's LDS allocation and can never match (j < b fails)
-            int4 vv[4];
+            int4 vv[NV];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) vv[u] = *reinterpret_cast<const int4*>(sOcc + base0 + 256 * u + 4 * lane);
+            for (int u = 0; u < NV; ++u) vv[u] = *reinterpret_cast<const int4*>(sOcc + base0 + 256 * u + 4 * lane);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NV; ++u) {
             const int4 v = vv[u];
             const int j = base0 + 256 * u + 4 * lane;
             const bool h0 = v.x == it && j >= a && j < b, h1 = v.y == it && j + 1 >= a && j + 1 < b;
@@ -2138,11 +2233,7 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     };
 
     // S = sum of the step rows of the item's occurrences before k, Sb = the same for the output bias
-    float4 S[MAXCH];
-    float Sb = 0.f;
     int n_e = 0, nb_e = 0;
-#pragma unroll
-    for (int q = 0; q < MAXCH; ++q) S[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lane == 0) { sHot[wid] = hot ? item : -1; sHot[SP_WAVES + wid] = first_j; }
     const bool any_dup = __syncthreads_or(dup ? 1 : 0) != 0;
     long long t_col = t_own, t_app = t_own, t_h[5] = {0, 0, 0, 0, 0};      // t_h: phases of the last hot round (debug)
@@ -2271,73 +2362,55 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
         }
         n_e = fl.z - 1; nb_e = fl.z - 1;
     }
-    // ---- final row values from S + s_k (sum over all occurrences) and the last occurrence's rows, and the stores
-    if (owner) {
-        const int n = n_e + 1, nb = nb_e + (bias ? 1 : 0);
-        const float fn = (float)n;
+    // ---- items with several occurrences: final rows from S + s_k, accumulator = the last occurrence's dA row
+    if (owner && !single) {
+        if constexpr (MAXCH == 2 && MOM) {
+            // two chunks per lane with momentum: the pre-step velocity row is fetched AGAIN here rather than carried through the list
+            // walk (nobody but this wave writes it) -- carried, it was the quad hipcc spilled right behind its load, with a vmcnt(0)
+            // in front of the spill that every wave of the kernel paid for
+#pragma unroll
+            for (int q = 0; q < MAXCH; ++q) vz[q] = ld4(V + (size_t)item * W + 4 * min(lane + 64 * q, nc4 - 1));
+        }
+        finish(S, Sb, n_e + 1, nb_e + (bias ? 1 : 0));
 #pragma unroll
         for (int q = 0; q < MAXCH; ++q) {
             const int c4 = lane + 64 * q;
-            const float p0[4] = {pz[q].x, pz[q].y, pz[q].z, pz[q].w}, v0[4] = {vz[q].x, vz[q].y, vz[q].z, vz[q].w};
-            const float sl[4] = {sk[q].x, sk[q].y, sk[q].z, sk[q].w};
-            const float ss[4] = {S[q].x + sk[q].x, S[q].y + sk[q].y, S[q].z + sk[q].z, S[q].w + sk[q].w};
-            float pn[4], vn[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float reg = (lmbd > 0.f) ? lr * lmbd * p0[e] : 0.f;
-                const float tot = (lmbd > 0.f) ? ss[e] + fn * reg : ss[e];
-                if (mom) { vn[e] = momc * v0[e] - (sl[e] + reg); pn[e] = p0[e] + (fn * (momc * v0[e]) - tot); }
-                else { vn[e] = 0.f; pn[e] = p0[e] - tot; }
-            }
-            if (c4 < nc4) {
-                const size_t o = (size_t)item * W + 4 * c4;
-                st4(P + o, make_float4(pn[0], pn[1], pn[2], pn[3]));
-                st4(A + o, ak[q]);
-                if (mom) st4(V + o, make_float4(vn[0], vn[1], vn[2], vn[3]));
-            }
+            if (c4 < nc4) st4(A + (size_t)item * W + 4 * c4, ak[q]);
         }
-        if (bias && lane == 0) {     // output bias By: occurrences among Y|samples only (gru4rec.py:486-489)
-            const float fb = (float)nb;
-            const float reg = (lmbd > 0.f) ? lr * lmbd * bpz : 0.f;
-            const float sb = Sb + bsk;
-            const float tot = (lmbd > 0.f) ? sb + fb * reg : sb;
-            if (mom) { tBy[item] = bpz + (fb * (momc * bvz) - tot); tvBy[item] = momc * bvz - (bsk + reg); }
-            else tBy[item] = bpz - tot;
-            taBy[item] = bak;
-        }
+        if (bias && lane == 0) m.accBy[item] = bak;
     }
     if (G4R_DBGCLK(m) && lane == 0 && k < R) {
         const long long t_end = wall_clock64();
         GAS long long* tr = G4R_DBGCLK(m) + 64 + 8 * k;
-        tr[0] = t_start; tr[1] = t_own; tr[2] = t_col; tr[3] = t_app; tr[4] = t_end; tr[5] = (owner ? fl.z : 0) | ((t_h[0] ? t_h[0] - t_app : 0) << 20); tr[6] = c.t;
+        tr[0] = t_start; tr[1] = t_own; tr[2] = t_col; tr[3] = t_app; tr[4] = t_end; tr[5] = (owner ? fl.z : 0) | ((t_h[0] ? t_h[0] - t_app : 0) << 20); tr[6] = 0;
         tr[7] = (t_h[1] - t_h[0]) | ((t_h[2] - t_h[1]) << 16) | ((t_h[3] - t_h[2]) << 32) | ((t_h[4] - t_h[3]) << 48);
     }
 }
 
-template <int MAXCH>
+template <int MAXCH, bool MOM>
 __global__ __launch_bounds__(SP_WAVES * 64, MAXCH > 2 ? 2 : 4) void k_sparse_update(const DevModel* __restrict__ mp, StepState* st, int nblk_occ) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // workgroup 0 does the step bookkeeping (it depends on nothing the other workgroups produce; dispatched first, it is off the tail)
-    sparse_update_block<MAXCH>(mp, st, nblk_occ, blockIdx.x == 0 ? nblk_occ : (int)blockIdx.x - 1, smem);
+    sparse_update_block<MAXCH, MOM>(mp, st, nblk_occ, blockIdx.x == 0 ? nblk_occ : (int)blockIdx.x - 1, smem);
 }
 
 // Single GPU: the dense-gradient tiles (+ fused dense Adagrad) and the sparse row update are independent of each other
 // (the tiles read layer-0 input rows from yin0, not from the table), so they share ONE launch: blocks [0, ntiles) are
 // dense tiles, the rest sparse-update blocks.  One dispatch (~4.5 us) less per step.
 static_assert(GT_NTH_FEW == SP_WAVES * 64, "both roles use the same workgroup size");
-template <int MAXCH, int DT>
+template <int MAXCH, int DT, bool MOM>
 __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_update(const DevModel* __restrict__ mp, StepState* st, const DenseTile* __restrict__ tiles_,
                                                              int ntiles, int nblk_occ) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // workgroup 0: step bookkeeping (dispatched first: off the tail), then the dense tiles, then the sparse-update workgroups
     // (interleaving the two kinds in dispatch order was measured: no change -- both draw on L2 / fabric bandwidth)
     const int b = (int)blockIdx.x - 1;
-    if (b < 0) sparse_update_block<MAXCH>(mp, st, nblk_occ, nblk_occ, smem);
+    if (b < 0) sparse_update_block<MAXCH, MOM>(mp, st, nblk_occ, nblk_occ, smem);
     else if (b < ntiles) {
         const int t = G4R_XCD_TILE(b, ntiles);      // neighbouring tiles of the table share their X rows: keep them on one XCD
         if constexpr (DT == 0) dense_grad_direct<SP_WAVES>(*mp, st, tiles_, t, smem);
         else dense_grad_tile<DT>(*mp, st, tiles_, t, smem);
-    } else sparse_update_block<MAXCH>(mp, st, nblk_occ, b - ntiles, smem);
+    } else sparse_update_block<MAXCH, MOM>(mp, st, nblk_occ, b - ntiles, smem);
 }
 
 // ---------------------------------------------------------------------------------------------

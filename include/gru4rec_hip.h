@@ -123,7 +123,10 @@ int64_t g4r_global_step(g4r_model* m);
  * puts a fresh handle where a saved run stopped (global step: dropout counters, store row pointer; refills: store contents) */
 int64_t g4r_refills(g4r_model* m);
 int g4r_set_step_counters(g4r_model* m, int64_t global_step, int64_t refills);
-/* average HIP-event time (ms) per launch of each step kernel since the last reset; names via index */
+/* average HIP-event time (ms) per launch of each step kernel since the last reset; names via index.
+ * g4r_profile: 0 = off, 1 = on (steps are launched eagerly with start / stop events attached to every dispatch), 2 = on, with the
+ * two roles of the single-GPU update launch as launches of their own (k_dense_grad, k_sparse_update): the embedding
+ * gather / scatter north_star prices against the HBM roofline, timed ALONE (results are identical either way). */
 int g4r_kernel_time(g4r_model* m, int32_t which, const char** name, double* total_ms, int64_t* launches);
 int g4r_profile(g4r_model* m, int32_t enable);
 
