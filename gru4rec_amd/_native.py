@@ -43,7 +43,7 @@ SYMBOLS = [
     'g4r_sample_store_rows', 'g4r_build_plan', 'g4r_set_plan', 'g4r_train_steps', 'g4r_get_losses',
     'g4r_synchronize', 'g4r_global_step', 'g4r_refills', 'g4r_set_step_counters', 'g4r_kernel_time', 'g4r_profile', 'g4r_reset_hidden',
     'g4r_predict_begin', 'g4r_predict_hidden', 'g4r_predict_step', 'g4r_rank_targets', 'g4r_evaluate', 'g4r_comm_unique_id',
-    'g4r_comm_init', 'g4r_virtual_train_steps', 'g4r_virtual_sync_dense', 'g4r_comm_sync_sparse', 'g4r_sync_set_rule', 'g4r_set_sync_every', 'g4r_comm_min_i64', 'g4r_comm_max_i64', 'g4r_comm_nranks', 'g4r_p2p_enable', 'g4r_p2p_export', 'g4r_p2p_attach', 'g4r_p2p_active', 'g4r_sync_enable', 'g4r_sync_row_floats', 'g4r_sync_export', 'g4r_sync_import', 'g4r_get_debug', 'g4r_selftest_mfma', 'g4r_bench_rows',
+    'g4r_comm_init', 'g4r_virtual_train_steps', 'g4r_virtual_sync_dense', 'g4r_comm_sync_sparse', 'g4r_sync_set_rule', 'g4r_set_sync_every', 'g4r_comm_min_i64', 'g4r_comm_max_i64', 'g4r_comm_nranks', 'g4r_p2p_enable', 'g4r_p2p_export', 'g4r_p2p_attach', 'g4r_p2p_active', 'g4r_sync_enable', 'g4r_sync_row_floats', 'g4r_sync_export', 'g4r_sync_import', 'g4r_get_debug', 'g4r_stress_start', 'g4r_stress_stop', 'g4r_selftest_mfma', 'g4r_bench_rows',
     'g4r_events_load', 'g4r_events_rows', 'g4r_events_items', 'g4r_events_item_bytes', 'g4r_events_time_kind',
     'g4r_events_copy', 'g4r_events_free',
 ]
@@ -118,6 +118,8 @@ def lib():
     L.g4r_sync_import.argtypes = [vp, i32, i32, i64p, C.POINTER(i32p), C.POINTER(f32p)]
     L.g4r_get_debug.argtypes = [vp, C.c_char_p, f32p, i64]
     L.g4r_selftest_mfma.argtypes = [f32p]
+    L.g4r_stress_start.argtypes = [i32, i64, i32, C.POINTER(vp)]
+    L.g4r_stress_stop.argtypes = [vp]
     L.g4r_bench_rows.argtypes = [i32, i64, i32, i64, i32, i32, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.g4r_events_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, i32, C.POINTER(vp)]
     for fn in (L.g4r_events_rows, L.g4r_events_items, L.g4r_events_item_bytes):
@@ -499,3 +501,23 @@ def selftest_mfma():
     e = C.c_float()
     _chk(lib().g4r_selftest_mfma(C.byref(e)))
     return e.value
+
+
+class MemoryStress:
+    """HBM / Infinity-Cache load on a stream of its own while the `with` body runs (g4r_stress_start / g4r_stress_stop)."""
+
+    def __init__(self, mbytes=4096, launches=400, device=0):
+        self.args = (int(device), int(mbytes), int(launches))
+        self.h = None
+
+    def __enter__(self):
+        h = C.c_void_p()
+        _chk(lib().g4r_stress_start(self.args[0], self.args[1], self.args[2], C.byref(h)))
+        self.h = h
+        return self
+
+    def __exit__(self, *exc):
+        if self.h is not None:
+            _chk(lib().g4r_stress_stop(self.h))
+            self.h = None
+        return False

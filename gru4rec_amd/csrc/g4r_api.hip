@@ -2120,6 +2120,36 @@ int g4r_bench_rows(int32_t device, int64_t n_items, int32_t W, int64_t rows_per_
     return 0;
 }
 
+// ---- memory-system load for the stress test (tests/test_gpu_stress.py): `launches` passes of k_stress_stream over `mbytes` MiB on a
+// stream of their own, queued asynchronously; g4r_stress_stop waits for them and frees the buffer
+struct g4r_stress { int device; float* buf; hipStream_t s; };
+int g4r_stress_start(int32_t device, int64_t mbytes, int32_t launches, void** handle) {
+    if (!handle || mbytes < 1 || launches < 1 || launches > 4096) return fail("bad argument");
+    if (device < 0 || device >= g4r_device_count()) return fail("device ordinal out of range");
+    HIPCHK(hipSetDevice(device));
+    g4r_stress* h = new g4r_stress{device, nullptr, nullptr};
+    const size_t bytes = (size_t)mbytes << 20;
+    if (hipMalloc((void**)&h->buf, bytes) != hipSuccess) { delete h; (void)hipGetLastError(); return fail("stress buffer allocation failed"); }
+    if (hipStreamCreateWithFlags(&h->s, hipStreamNonBlocking) != hipSuccess) { (void)hipFree(h->buf); delete h; return fail("stress stream"); }
+    (void)hipMemsetAsync(h->buf, 0, bytes, h->s);
+    const long long n4 = (long long)(bytes / 16);
+    const unsigned grid = (unsigned)((n4 + 16383) / 16384);
+    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(k_stress_stream, dim3(grid), dim3(256), 0, h->s, h->buf, n4);
+    *handle = h;
+    return 0;
+}
+int g4r_stress_stop(void* handle) {
+    if (!handle) return fail("null handle");
+    g4r_stress* h = (g4r_stress*)handle;
+    (void)hipSetDevice(h->device);
+    hipError_t e = hipStreamSynchronize(h->s);
+    (void)hipStreamDestroy(h->s);
+    (void)hipFree(h->buf);
+    delete h;
+    if (e != hipSuccess) return fail(std::string("stress stream: ") + hipGetErrorString(e));
+    return 0;
+}
+
 int g4r_selftest_mfma(float* max_abs_err) {
     if (g4r_device_count() <= 0) return fail("no HIP device");
     const int K = 20;

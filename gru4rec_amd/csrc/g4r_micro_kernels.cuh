@@ -65,3 +65,22 @@ __global__ __launch_bounds__(256) void k_micro_rows(const float* __restrict__ ta
 }
 template __global__ void k_micro_rows<1>(const float*, float*, const int*, float*, long long, int, int);
 template __global__ void k_micro_rows<2>(const float*, float*, const int*, float*, long long, int, int);
+
+// Memory-system load for tests/test_gpu_stress.py: every workgroup streams its 256 KiB slice of a buffer far larger than the
+// Infinity Cache (16-byte loads, 16-byte stores of the complemented bits), so that the step kernels running next to it on the
+// library's stream see HBM latencies several times the idle ones -- the condition under which round 3's stale-register pipeline
+// (mutant 4) committed registers whose loads had not landed, and which no parity test on an idle GPU reproduces.
+__global__ __launch_bounds__(256) void k_stress_stream(float* __restrict__ buf_, long long n4) {
+    GAS float4* buf = (GAS float4*)buf_;
+    constexpr int PER_BLOCK = 16384;      // float4 per workgroup = 256 KiB
+    const long long base = (long long)blockIdx.x * PER_BLOCK;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < PER_BLOCK; i += 256) {
+        const long long j = base + i;
+        if (j < n4) {
+            float4 v = buf[j];
+            v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w;
+            buf[j] = v;
+        }
+    }
+}

@@ -252,6 +252,12 @@ int g4r_selftest_mfma(float* max_abs_err);
  * time of a launch (HIP events attached to the dispatch); wall_us: back-to-back launches on one stream, per launch. */
 int g4r_bench_rows(int32_t device, int64_t n_items, int32_t W, int64_t rows_per_launch, int32_t launches, int32_t mode, uint64_t seed,
                    double* kernel_us, double* wall_us);                    /* 16x16x4 f32 MFMA layout check */
+/* Test support (tests/test_gpu_stress.py): `launches` passes of a streaming read-modify-write over `mbytes` MiB of device memory
+ * on a stream of their own, queued asynchronously -- HBM / Infinity-Cache load next to the caller's training steps, the condition
+ * under which round 3's stale-register pipeline (mutation build 4) went wrong and an idle GPU never shows.  g4r_stress_stop waits
+ * for the passes and frees the buffer.  Nothing of the reference corresponds to it. */
+int g4r_stress_start(int32_t device, int64_t mbytes, int32_t launches, void** handle);
+int g4r_stress_stop(void* handle);
 
 #ifdef __cplusplus
 }

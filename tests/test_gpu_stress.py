@@ -1,0 +1,80 @@
+"""Results must not depend on how busy the memory system is.
+
+Round 3's first two-chunks-ahead pipeline of gemm_tile2k (scoring backward of the B >= 256 / >= 4096-column shapes) waited for its
+hand-counted asm loads with tied operands in two branches; hipcc placed register copies in front of the tail's wait, so the last K
+chunk of a tile was written to LDS from registers whose loads might not have landed.  On an idle GPU they always had: 250 parity
+tests were green, and only the 10 GB-table test with three other processes on the GPU saw it.  That build is kept as mutation
+build 4 (gru4rec_amd/build.py; the only library built with the ISA audit switched off -- the audit flags it, tests/test_isa_audit.py).
+
+Here the same training steps (the cfg #4 tile shapes: gemm_tile2k in k_score_bwd2, gemm_tile3 in k_score_fwd, a 2 GB item table)
+run twice, once on an idle GPU and once next to `MemoryStress` -- passes of a streaming read-modify-write over 6 GB on a second
+stream, which multiplies the load latencies the kernels see.  The product library must produce the same bits both times; the
+mutant must not (run in a child process with G4R_LIB pointing at it), which is what proves the load is heavy enough to expose
+this class of bug without a 10 GB table and three neighbours."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from gru4rec_amd import _native, build as g4r_build
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+I, D, B, NS, T = 2_000_000, 256, 512, 8192, 12
+
+
+def _model_and_plan():
+    rng = np.random.RandomState(5)
+    m = _native.Model(n_items=I, layers=[D], batch_size=B, n_sample=NS, loss=_native.LOSS_IDS['bpr-max'], final_act=_native.ACT_IDS['elu'],
+                      final_act_p0=0.5, hidden_act=_native.ACT_IDS['tanh'], embed_mode=0, embedding=0, learning_rate=0.1, momentum=0.0,
+                      bpreg=1.0, sample_alpha=0.75, sample_store=NS * 16, seed=3, device=0, rank=0, nranks=1, use_graph=1)
+    block = (rng.randn(4096, D) * 0.05).astype(np.float32)
+    m.set_param('Wy', np.tile(block, (I // 4096 + 1, 1))[:I])
+    s = lambda *sh: (rng.randn(*sh) * 0.08).astype(np.float32)
+    m.set_param('Wx', s(D, 3 * D)); m.set_param('Wh', s(D, D)); m.set_param('Wrz', s(D, 2 * D))
+    m.set_popularity(np.linspace(0, 1, I, dtype=np.float32), None, None)
+    m.set_sample_store(rng.randint(0, I, size=(16, NS)).astype(np.int32))
+    plan = dict(in_idx=rng.randint(0, I, size=(T, B)).astype(np.int32), out_idx=rng.randint(0, I, size=(T, B)).astype(np.int32),
+                reset=(rng.rand(T, B) < 0.2).astype(np.uint8), M=np.full(T, B, dtype=np.int32), T=T, n_compact=0,
+                compact_steps=np.zeros(0, dtype=np.int64), compact_maps=np.zeros((0, B), dtype=np.int32))
+    m.set_plan(plan)
+    m.reset_hidden()
+    return m, plan
+
+
+def _run(stress):
+    m, plan = _model_and_plan()
+    if stress:
+        with _native.MemoryStress(mbytes=6144, launches=300):
+            m.train_steps(0, T)
+    else:
+        m.train_steps(0, T)
+    rows = np.unique(np.concatenate([plan['in_idx'].ravel(), plan['out_idx'].ravel()]))[:4096]
+    out = dict(loss=m.get_losses(0, T), Wx=m.get_param('Wx', (D, 3 * D)), Wh=m.get_param('Wh', (D, D)),
+               dS=m.get_debug('dSy', ((B + NS + 15) // 16 * 16, D)))
+    m.close()
+    return out
+
+
+def test_results_do_not_depend_on_memory_load():
+    idle = _run(False)
+    assert np.isfinite(idle['loss']).all()
+    for attempt in range(3):
+        busy = _run(True)
+        for k in idle:
+            assert np.array_equal(idle[k], busy[k]), '%s differs between an idle and a loaded GPU (attempt %d): max |diff| %.3e' % (
+                k, attempt, np.abs(idle[k].astype(np.float64) - busy[k].astype(np.float64)).max())
+
+
+def test_the_stale_register_build_is_caught_under_load():
+    paths = dict(zip(sorted(g4r_build.MUTANTS), g4r_build.build_mutants()))
+    if 'G4R_LIB' in os.environ:
+        pytest.skip('already inside a child run')
+    env = dict(os.environ, G4R_LIB=paths[4])
+    r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_stress.py::test_results_do_not_depend_on_memory_load', '-x', '-q',
+                        '-p', 'no:cacheprovider'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 1 and 'differs between an idle and a loaded GPU' in (r.stdout + r.stderr), \
+        'mutation build 4 (stale-register pipeline) passed the stress test:\n' + (r.stdout + r.stderr)[-3000:]
