@@ -12,13 +12,22 @@ DEPS = [os.path.join(HERE, 'csrc', f) for f in ('g4r_api.hip', 'g4r_device.cuh',
        [os.path.join(os.path.dirname(HERE), 'include', 'gru4rec_hip.h')]
 
 
-def build(force=False, verbose=False, out=None, defs=()):
-    """`out` / `defs`: a second library with extra -D flags next to the product one (kernel experiments, selected with G4R_LIB)."""
+def build(force=False, verbose=False, out=None, defs=(), flags=()):
+    """`out` / `defs` / `flags`: a second library with extra -D definitions / raw hipcc flags next to the product one (kernel
+    experiments, selected with G4R_LIB)."""
     if out is not None:
-        return _compile(out, list(defs), verbose)
+        return _compile(out, list(defs), verbose, list(flags))
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     return _compile(OUT, [], verbose)
+
+
+# raw hipcc flags of every build.  Kernarg preload (gfx940+): the first 16 dwords of a kernel's arguments -- the descriptor and
+# step-state pointers every step kernel takes -- arrive in scalar registers with the wave instead of behind an s_load from the
+# kernarg segment: one scalar memory round trip (~0.4 us) less at the head of EVERY launch.  Measured (profiles/r04_experiments.md):
+# cfg #2 kernel sum 43.8 -> 41.8 us, 21.5 -> 21.9 K mb/s; cfg #4 5.62 -> 5.75 K.  Code objects keep the compatibility prologue hipcc
+# emits for firmware without the feature.
+COMMON_FLAGS = ['-mllvm', '-amdgpu-kernarg-preload-count=16']
 
 
 MUTANTS = {1: 'sparse accumulator increments x 1.01', 2: 'sparse Adagrad steps x 1.01', 3: 'dense accumulator increments x 1.01',
@@ -73,7 +82,7 @@ def build_dir(OUT):
     return os.path.join(HERE, '_build', os.path.splitext(os.path.basename(OUT))[0])
 
 
-def _device(OUT, defs, verbose, audit=True):
+def _device(OUT, defs, verbose, audit=True, flags=()):
     """hipcc -> OUT.  The device listing hipcc assembles into the library (-save-temps) is kept under _build/ and AUDITED
     (isa_audit.audit): a library whose code names the destination register of a hand-counted asm load before the wait that
     retires it is deleted and AuditError raised -- another compiler version cannot silently produce a wrong library (round 3's
@@ -90,7 +99,7 @@ def _device(OUT, defs, verbose, audit=True):
     os.makedirs(tmp)
     ver = hipcc_version()
     cmd = [os.path.join(rocm, 'bin', 'hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-save-temps=obj',
-           '-DG4R_HIPCC_VERSION="%s"' % ver] + trace + ['-D' + d for d in defs] + [
+           '-DG4R_HIPCC_VERSION="%s"' % ver] + COMMON_FLAGS + list(flags) + trace + ['-D' + d for d in defs] + [
            '-I' + os.path.join(rocm, 'include'), '-o', os.path.join(tmp, os.path.basename(OUT)), SRC, '-Wl,' + obj, '-pthread',
            '-L' + os.path.join(rocm, 'lib'), '-lrccl', '-Wl,-rpath,' + os.path.join(rocm, 'lib')]
     if verbose:
@@ -121,15 +130,17 @@ def _device(OUT, defs, verbose, audit=True):
     return OUT
 
 
-def _compile(OUT, defs, verbose):
+def _compile(OUT, defs, verbose, flags=()):
     _host_object(verbose)
-    return _device(OUT, defs, verbose)
+    return _device(OUT, defs, verbose, flags=flags)
 
 
 if __name__ == '__main__':
-    # python -m gru4rec_amd.build [--force] | --variant <path.so> NAME=VALUE ...
+    # python -m gru4rec_amd.build [--force] | --variant <path.so> NAME=VALUE ... [-flag ...]
     if '--variant' in sys.argv:
         k = sys.argv.index('--variant')
-        print(build(out=os.path.abspath(sys.argv[k + 1]), defs=sys.argv[k + 2:], verbose=True))
+        rest = sys.argv[k + 2:]
+        print(build(out=os.path.abspath(sys.argv[k + 1]), defs=[a for a in rest if not a.startswith('-')],
+                    flags=[a for a in rest if a.startswith('-')], verbose=True))
     else:
         print(build(force='--force' in sys.argv, verbose=True))

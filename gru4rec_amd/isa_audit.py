@@ -32,7 +32,7 @@ def device_asm(path=None, defs=()):
         return open(path).read()
     out = os.path.join(tempfile.mkdtemp(prefix='g4r_isa_'), 'g4r.s')
     hipcc = os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'bin', 'hipcc')
-    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S'] + ['-D' + d for d in defs] + [
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S', '-mllvm', '-amdgpu-kernarg-preload-count=16'] + ['-D' + d for d in defs] + [
                            os.path.join(ROOT, 'gru4rec_amd', 'csrc', 'g4r_api.hip'), '-o', out], stderr=subprocess.DEVNULL)
     return open(out).read()
 
