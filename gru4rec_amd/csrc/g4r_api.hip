@@ -80,7 +80,7 @@ struct g4r_model {
     // launch geometry
     DenseTile* d_tiles = nullptr;
     int dt = 32;                                 // edge of the dense-gradient tiles (64 for wide layers)
-    int ntiles = 0, nblkA = 0, nblkB = 0, ndtA = 0, ndtB = 0, nrtB = 0, nblk_occ = 0;
+    int ntiles = 0, nblkA = 0, nblkB = 0, ndtA = 0, ndtB = 0, nrtB = 0, nblk_occ = 0, nblk_occ_g = 0;
     size_t smem_score = 0, smem_loss = 0, smem_sparse = 0;
     // persistent stream-K scoring forward (k_score_fwd_sk): workers, tile grid, column tiles a worker may touch, scratch
     int sk_W = 0, sk_nrt = 0, sk_nct = 0, sk_maxct = 0, sk_nst = 3;
@@ -98,6 +98,8 @@ struct g4r_model {
     // profiling
     bool profiling = false;
     bool profile_split = false;
+    bool exact = false;                          // g4r_config::sparse_exact with nranks > 1
+    size_t smem_exact = 0;
     double kn_ms[KN_COUNT] = {0};
     int64_t kn_n[KN_COUNT] = {0};
     std::vector<hipEvent_t> evs;
@@ -297,7 +299,11 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     d.inv_B = 1.0f / (float)B;
     d.smoothing = cfg->smoothing;
     d.adapt = cfg->adapt; d.ap0 = cfg->adapt_p0; d.ap1 = cfg->adapt_p1; d.grad_cap = cfg->grad_cap;
-    d.generic = (cfg->adapt != G4R_ADAPT_ADAGRAD || cfg->grad_cap > 0.f) ? 1 : 0;
+    // exact-replica mode of N > 1: raw per-occurrence gradients (the generic path's producers), exchanged every step
+    const bool exact = cfg->sparse_exact != 0 && cfg->nranks > 1;
+    if (cfg->sparse_exact != 0 && cfg->grad_cap > 0.f) { g4r_destroy(m); return fail("sparse_exact does not support grad_cap (the norm would be per rank)"); }
+    m->exact = exact;
+    d.generic = (cfg->adapt != G4R_ADAPT_ADAGRAD || cfg->grad_cap > 0.f || exact) ? 1 : 0;
     d.drop_h = cfg->dropout_p_hidden; d.drop_e = cfg->dropout_p_embed;
     d.seed = cfg->seed;
     d.Dtop = cfg->layers[L - 1];
@@ -346,10 +352,25 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     DA(m->d_tmpH, (size_t)B * maxD);
     DA(d.yin0, (size_t)B * std::max(d.IN[0], 4));
     DA(d.Sc, (size_t)B * d.ldSc);
-    DA(d.dSx, (size_t)B * d.Ein); DA(d.dSy, (size_t)d.ldSc * d.Dtop); DA(d.dSBy, d.ldSc);
+    {
+        // occ_idx | dSx | dSy | dSBy of this rank in ONE block (DevModel::xbase): what the exact-replica mode all-gathers every step.
+        // Offsets are multiples of 64 floats (16-byte rows stay aligned); occ_idx is staged with 16-byte loads up to Rpad.
+        auto up64 = [](size_t n) { return (n + 63) & ~(size_t)63; };
+        const size_t nOcc = up64((size_t)((d.R + 255) & ~255) + 256 + 64);
+        d.xoffSx = (int)nOcc;
+        d.xoffSy = (int)(nOcc + up64((size_t)B * d.Ein));
+        d.xoffSBy = (int)(d.xoffSy + up64((size_t)d.ldSc * d.Dtop));
+        d.xstride = (long long)(d.xoffSBy + up64((size_t)d.ldSc));
+        d.xn = exact ? cfg->nranks : 1;
+        d.xmode = exact ? std::min(std::max(cfg->sparse_exact, 1), 3) : 0;
+        float* xb = nullptr;
+        DA(xb, (size_t)d.xn * (size_t)d.xstride);
+        d.xbase = xb;
+        float* own = xb + (size_t)(exact ? cfg->rank : 0) * (size_t)d.xstride;
+        d.occ_idx = (int*)own; d.dSx = own + d.xoffSx; d.dSy = own + d.xoffSy; d.dSBy = own + d.xoffSBy;
+    }
     DA(d.dAx, (size_t)B * d.Ein); DA(d.dAy, (size_t)d.ldSc * d.Dtop); DA(d.dABy, d.ldSc);
     DA(d.lossrow, B);
-    DA(d.occ_idx, ((d.R + 255) & ~255) + 256 + 64);      // k_sparse_update stages it with 16-byte loads up to Rpad
     DA(d.col_item, d.ldSc); DA(d.cur_in, B); DA(d.cur_col, d.ldSc);
     DA(d.occ_fl, (size_t)(cfg->embed_mode != G4R_EMBED_CONSTRAINED ? 2 : 1) * I * 4);
     DA(d.st, 1);
@@ -387,6 +408,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         m->nrtB = cdiv(B, TB);
         m->nblkB = d.ksplit * m->nrtB * m->ndtB;
         m->nblk_occ = cdiv(d.R, SP_WAVES);
+        m->nblk_occ_g = m->nblk_occ;      // generic optimizer path (one occurrence per wave; exact-replica mode: sized at launch)
         m->smem_sparse = (size_t)(((d.R + 255) & ~255) + 256) * sizeof(int) + (2 + 64) * SP_WAVES * sizeof(int) +
                          (size_t)SP_WAVES * (std::max(d.Dtop, d.Ein) + 4) * sizeof(float);
     }
@@ -503,6 +525,13 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel (one copy of a score row must fit the 160 KB of LDS)"); }
     if (m->smem_sparse > (size_t)big) { g4r_destroy(m); return fail("2 * batch_size + n_sample too large for the sparse update (the step's list of gathered rows must fit the 160 KB of LDS)"); }
+    if (m->exact) {
+        m->smem_exact = (size_t)((((size_t)d.R * d.xn + 255) & ~(size_t)255) + 256) * sizeof(int) + 64 * SP_WAVES * sizeof(int);
+        if (m->smem_exact > (size_t)big) {
+            g4r_destroy(m);
+            return fail("sparse_exact: nranks * (2 * batch_size + n_sample) occurrences do not fit the 160 KB of LDS the update stages the concatenated list in -- use the GPU-local mode (sync_every) at this shape");
+        }
+    }
     { float* z = nullptr; if (dalloc(m, &z, ZROW_FLOATS)) { g4r_destroy(m); return -1; } d.zrow = z; }
     if (getenv("G4R_CLK")) {
         if (dalloc(m, &d.dbgclk, 64 + 8 * (size_t)d.R) || dalloc(m, &d.dbgtile, 8 * (size_t)(4096 + 4096))) { g4r_destroy(m); return -1; }
@@ -931,10 +960,25 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     }
     if (d.generic) {
         // generic optimizer path: the sparse rule on raw per-occurrence gradients
+        int nblk_g = m->nblk_occ_g;
+        size_t smem_g = m->smem_sparse;
+        if (m->exact) {
+            // exact-replica mode: every rank's block of (occurrence list, gradient rows) to every rank, then the (last, first, count)
+            // table of the concatenated list; the update below then runs over nranks * R occurrences, identically on every rank
+            if (!m->virtual_ranks) {      // (virtual ranks: g4r_virtual_train_steps has copied the blocks)
+                if (!m->comm_ready) return fail("sparse_exact needs the RCCL communicator (g4r_comm_init)");
+                NCCLCHK(ncclAllGather((const float*)d.xbase + (size_t)m->cfg.rank * (size_t)d.xstride, (float*)d.xbase, (size_t)d.xstride, ncclFloat, m->comm, s));
+            }
+            hipLaunchKernelGGL(k_exact_clear, dim3(cdiv(d.R, 256)), dim3(256), 0, s, dmp);
+            const long long rlist = d.xmode == 3 ? (long long)d.xn * 2 * B + d.ns : (long long)d.R * d.xn;      // xlist_len
+            hipLaunchKernelGGL(k_exact_occ, dim3(cdiv(rlist, 256)), dim3(256), 0, s, dmp);
+            nblk_g = cdiv(rlist, SP_WAVES);
+            smem_g = m->smem_exact;
+        }
         begin(KN_SPARSE);
-        if (row_chunks(d) == 1) LK(k_sparse_update_generic<1>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
-        else if (row_chunks(d) == 2) LK(k_sparse_update_generic<2>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
-        else LK(k_sparse_update_generic<4>, dim3(m->nblk_occ + 1), dim3(SP_WAVES * 64), m->smem_sparse, s, dmp, stp, m->nblk_occ);
+        if (row_chunks(d) == 1) LK(k_sparse_update_generic<1>, dim3(nblk_g + 1), dim3(SP_WAVES * 64), smem_g, s, dmp, stp, nblk_g);
+        else if (row_chunks(d) == 2) LK(k_sparse_update_generic<2>, dim3(nblk_g + 1), dim3(SP_WAVES * 64), smem_g, s, dmp, stp, nblk_g);
+        else LK(k_sparse_update_generic<4>, dim3(nblk_g + 1), dim3(SP_WAVES * 64), smem_g, s, dmp, stp, nblk_g);
         end();
         HIPCHK(hipGetLastError());
         return 0;
@@ -1132,7 +1176,8 @@ int g4r_virtual_train_steps(g4r_model* const* ms, int32_t n, int64_t t0, int64_t
         g4r_model* m = ms[q];
         if (!m || !m->d_in) return fail("virtual ranks: null model / no plan uploaded");
         if (m->cfg.nranks != n || m->cfg.rank != q) return fail("virtual ranks: handle q must be created with rank = q, nranks = n");
-        if (m->cfg.device != ms[0]->cfg.device || m->dm.dense_count != ms[0]->dm.dense_count) return fail("virtual ranks: handles differ");
+        if (m->cfg.device != ms[0]->cfg.device || m->dm.dense_count != ms[0]->dm.dense_count || m->exact != ms[0]->exact || m->dm.xstride != ms[0]->dm.xstride)
+            return fail("virtual ranks: handles differ");
         if (m->comm_ready || m->p2p_ready) return fail("virtual ranks: the handle already has a communicator / peer mappings");
         if (t0 < 0 || n_steps < 0 || t0 + n_steps > m->T) return fail("step range outside the plan");
         if (m->dm.ns > 0 && !m->have_pop && !m->store_frozen) return fail("negative sampling needs g4r_set_popularity first");
@@ -1162,6 +1207,16 @@ int g4r_virtual_train_steps(g4r_model* const* ms, int32_t n, int64_t t0, int64_t
             if (launch_step(m, nullptr, 1)) return -1;
         }
         for (int q = 0; q < n; ++q) HIPCHK(hipStreamSynchronize(ms[q]->stream));
+        if (m0->exact) {
+            // what the all-gather of the exact-replica mode delivers: every handle's own block into every other handle's buffer
+            for (int q = 0; q < n; ++q)
+                for (int p = 0; p < n; ++p)
+                    if (p != q) HIPCHK(hipMemcpyAsync((float*)ms[q]->dm.xbase + (size_t)p * (size_t)m0->dm.xstride,
+                                                      (const float*)ms[p]->dm.xbase + (size_t)p * (size_t)m0->dm.xstride,
+                                                      (size_t)m0->dm.xstride * sizeof(float), hipMemcpyDeviceToDevice, ms[q]->stream));
+            // (the next step's kernels of handle p rewrite p's block: every copy out of it must have run before p's tail is queued)
+            for (int q = 0; q < n; ++q) HIPCHK(hipStreamSynchronize(ms[q]->stream));
+        }
         hipLaunchKernelGGL(k_virtual_sum, dim3(cdiv(cnt, 256)), dim3(256), 0, m0->stream, va, n, cnt, m0->d_vsum);
         hipLaunchKernelGGL(k_virtual_bcast, dim3(cdiv(cnt, 256)), dim3(256), 0, m0->stream, va, n, cnt, (const float*)m0->d_vsum);
         HIPCHK(hipStreamSynchronize(m0->stream));
@@ -1657,6 +1712,7 @@ static inline int nblk256(long long n) { return (int)((n + 255) / 256); }
 int g4r_sync_enable(g4r_model* m) {
     if (!m) return fail("null model");
     if (m->sync_on) return 0;
+    if (m->exact) return 0;      // exact-replica mode: the item tables never diverge -- no touched-row bitmap, no base copies
     HIPCHK(hipSetDevice(m->cfg.device));
     DevModel& d = m->dm;
     const size_t I = d.n_items;
@@ -1898,6 +1954,7 @@ int g4r_set_sync_every(g4r_model* m, int32_t k) {
 // delta rows, one all-gather (padded to the largest part of the range) brings all parts, sync_apply adds them in rank order.
 // The traffic follows the number of touched rows, not the table size.
 int g4r_comm_sync_sparse(g4r_model* m) {
+    if (m && m->exact) return 0;      // exact-replica mode: nothing to reconcile
     if (!m) return fail("null model");
     if (m->cfg.nranks <= 1 && !m->comm_ready) return 0;
     if (!m->comm_ready) return fail("g4r_comm_init first");

@@ -151,6 +151,14 @@ struct DevModel {
     GP(const float) zrow;   // 8192 zero floats: what the LDS-DMA tiles read for rows outside the matrix / inactive gathered rows
     GP(float) Syc;          // [ldSc][Dtop] the Wy rows of this step's score columns, compact (k_compact_sy); nullptr = not staged
     GP(long long) dbgtile;  // optional [dense tile][8] phase timestamps of the dense-gradient tiles (G4R_CLK)
+    // Per-occurrence exchange blocks.  occ_idx | dSx | dSy | dSBy of this rank are carved out of ONE block of xstride floats; in the
+    // exact-replica mode of N > 1 (g4r_config::sparse_exact) xbase holds xn = nranks such blocks, this rank's own at index `rank`
+    // (where the pointers above point) and the peers' filled in by an all-gather every step, and the generic sparse update walks the
+    // concatenated occurrence list K = q * R + k (block q, occurrence k) in rank order.  xn = 1: the own block alone.
+    GP(float) xbase;
+    long long xstride;
+    int xn, xoffSx, xoffSy, xoffSBy;      // float offsets of dSx / dSy / dSBy inside a block (occ_idx sits at offset 0, as ints)
+    int xmode, xpad;                      // g4r_config::sparse_exact when xn > 1 (1 SUM, 2 MEAN, 3 REDUCE form of the exact-replica mode), else 0
 };
 
 // In-kernel phase traces (tools/clk*.py) exist only in builds made with G4R_BUILD_CLK=1 (-DG4R_CLK_TRACE): a test of a

@@ -2414,19 +2414,69 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_update(const DevModel* __r
 }
 
 // ---------------------------------------------------------------------------------------------
+// Exact-replica mode (g4r_config::sparse_exact): the (last, first, count) table of the CONCATENATED occurrence list.  The forward
+// kernels published this rank's own occurrences with their local positions: k_exact_clear takes those entries back to zero,
+// k_exact_occ (behind it in stream order, after the all-gather) publishes all xn * R occurrences with their global positions.
+__global__ __launch_bounds__(256) void k_exact_clear(const DevModel* __restrict__ mp) {
+    const DevModel& m = *mp;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= m.R) return;
+    const int item = m.occ_idx[k];
+    if (item < 0) return;
+    const bool tableE = (k < m.B && m.embed_mode != G4R_EMBED_CONSTRAINED);
+    *(GAS int4*)(m.occ_fl + 4 * ((tableE ? (size_t)m.n_items : 0) + item)) = make_int4(0, 0, 0, 0);
+}
+// Position K of the exchanged occurrence list -> (rank block q, occurrence k of that rank's X | Y | samples list).
+//   xmode 1 / 2 (SUM / MEAN forms): the ranks' lists one behind the other, K = q * R + k, xn * R entries;
+//   xmode 3 (REDUCE form; all ranks draw the SAME negatives): X | Y of rank 0, X | Y of rank 1, ..., then the sample part ONCE
+//     (xn * 2B + ns entries): a sample entry stands for that column of every rank, its gradient row is the sum over the ranks
+//     (block -1 below) -- the all-reduce of the negatives' gradient rows a data-parallel step owes the reference's shared row of
+//     negatives (gru4rec.py:436-437); the list then is exactly the occurrence list of ONE batch of xn * B rows.
+struct XPos { int q, k; };
+__device__ __forceinline__ int xlist_len(const DevModel& m) { return m.xmode == 3 ? m.xn * 2 * m.B + m.ns : m.xn * m.R; }
+__device__ __forceinline__ XPos xlist_pos(const DevModel& m, int K) {
+    XPos p;
+    if (m.xmode == 3) {
+        const int nxy = m.xn * 2 * m.B;
+        if (K >= nxy) { p.q = -1; p.k = 2 * m.B + (K - nxy); }
+        else { p.q = K / (2 * m.B); p.k = K - p.q * 2 * m.B; }
+    } else { p.q = K / m.R; p.k = K - p.q * m.R; }
+    return p;
+}
+__global__ __launch_bounds__(256) void k_exact_occ(const DevModel* __restrict__ mp) {
+    const DevModel& m = *mp;
+    const int K = blockIdx.x * 256 + threadIdx.x, R = xlist_len(m);
+    if (K >= R) return;
+    const XPos ps = xlist_pos(m, K);
+    const int k = ps.k;
+    const int item = ((const GAS int*)(m.xbase + (long long)max(ps.q, 0) * m.xstride))[k];
+    if (item < 0) return;
+    const bool tableE = (k < m.B && m.embed_mode != G4R_EMBED_CONSTRAINED);
+    int* fl = (int*)m.occ_fl + 4 * ((tableE ? (size_t)m.n_items : 0) + item);
+    atomicMax(fl, K + 1);
+    atomicMax(fl + 1, R - K);
+    atomicAdd(fl + 2, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Sparse update of the generic optimizer path (rmsprop / adadelta / adam / plain SGD, and adagrad under grad_cap).
 // Same ownership scheme as k_sparse_update (the wave of an item's last occurrence owns its rows; first / last / count table),
 // but the gradient rows are RAW: the owner sums S = sum g, Q = sum g^2 (and adagrad's per-occurrence scaled sum) over all
 // occurrences of the item, applies opt_rule once per element and writes parameter, statistics and velocity.  With the
 // reference's "accurate" duplicate handling (gru4rec.py:321-326,349-358,373-378) every occurrence of an item sees the same
 // final statistic, so sums are all that is needed.  Simple rather than fast: the owner walks its occurrences alone.
+// Exact-replica mode of N > 1 (g4r_config::sparse_exact): the occurrence list is the concatenation of the xn ranks' lists, K = q * R + k
+// (block q of the exchange buffer, occurrence k of that rank: X | Y | samples), and the gradient rows are read from the owning
+// rank's block; the duplicate semantics -- per-occurrence Adagrad scaling with the pre-step accumulator, increments accumulate,
+// statistics / velocity take the LAST occurrence -- hold over the concatenated list, i.e. ranks count as later occurrences in rank
+// order.  xn == 1 is the single-rank generic path.
 template <int MAXCH>
 __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const DevModel* __restrict__ mp, StepState* st, int nblk_occ) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const StepCtx c = load_ctx(st);
-    const int B = m.B, R = m.R;
+    const int B = m.B, Rl = m.R, xn = m.xn, R = xlist_len(m);      // Rl: occurrences per rank, R: of the whole (exchanged) list
     if ((int)blockIdx.x == nblk_occ) {       // bookkeeping block, as in k_sparse_update
         const int Mn = m.Mplan[c.t + 1];
         if (wid == 0) {
@@ -2446,17 +2496,25 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
         stage_step_inputs(m, c.t + 1, c.g + 1, Mn, tid, SP_WAVES * 64);
         return;
     }
+    const GAS float* xb = m.xbase;
+    const long long xs = m.xstride;
     const int Rpad = ((R + 255) & ~255) + 256;
     int* sOcc = reinterpret_cast<int*>(smem);
     int* myList = sOcc + Rpad + 64 * wid;
-    for (int j = tid; j < Rpad; j += SP_WAVES * 64) sOcc[j] = j < R ? m.occ_idx[j] : -2;
+    for (int j = tid; j < Rpad; j += SP_WAVES * 64) {
+        const XPos pj = xlist_pos(m, min(j, R - 1));
+        sOcc[j] = j < R ? ((const GAS int*)(xb + (long long)max(pj.q, 0) * xs))[pj.k] : -2;
+    }
     __syncthreads();
     const int k = blockIdx.x * SP_WAVES + wid;
     if (k >= R) return;
     const int item = sOcc[k];
     if (item < 0) return;
+    const int kl = xlist_pos(m, k).k;             // local occurrence of k (position in its rank's X | Y | samples list)
+    auto is_x = [&](int j) { return xlist_pos(m, j).k < B; };      // an input occurrence (table E when the tables are separate; no output bias)
+    const float xscale = (m.xmode == 3) ? 1.0f / (float)xn : 1.0f;      // REDUCE form: gradients of the GLOBAL batch (cost / (xn * B))
     const bool constrained = (m.embed_mode == G4R_EMBED_CONSTRAINED);
-    const bool tableE = (k < B && !constrained);
+    const bool tableE = (kl < B && !constrained);
     GAS int* flp = m.occ_fl + 4 * ((tableE ? (size_t)m.n_items : 0) + item);
     const int4 fl = ldi4(flp);
     if (fl.x != k + 1) return;               // not the last occurrence of the item
@@ -2464,16 +2522,23 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
         *(GAS int4*)flp = make_int4(0, 0, 0, 0);
         if (m.touched) m.touched[(tableE ? (size_t)m.n_items : 0) + item] = 1;
     }
-    const int lo = (constrained || k < B) ? 0 : B;
+    // occurrence range sharing a table with k: constrained -> everything; separate tables -> the X parts (table E) or the
+    // Y | samples parts (table Wy) of all blocks: `same_table(j)` filters the scan below
+    const int lo = (constrained || kl < B || xn > 1) ? 0 : B;
     const int first_j = max(lo, R - fl.y);
+    auto same_table = [&](int j) { return constrained || is_x(j) == tableE; };
     GAS float *P = tableE ? m.E : m.Wy, *A = tableE ? m.accE : m.accWy, *A2 = tableE ? m.acc2E : m.acc2Wy,
               *Cn = tableE ? m.cntE : m.cntWy, *V = tableE ? m.velE : m.velWy;
     const int W = tableE ? m.Ein : m.Dtop, nc4 = W >> 2;
-    const bool bias = (k >= B), mom = m.mom > 0.f;
+    // output bias (gru4rec.py:486-489: By is indexed by Y | samples only).  In one rank's list the X occurrences come first, so an
+    // item whose LAST occurrence is an input has no bias occurrence at all; in a concatenated list (xn > 1) a later rank's input may
+    // follow an earlier rank's target / negative: the owner then still updates the bias, from the bias occurrences the scan finds,
+    // and "the last occurrence" of the bias statistics is the last of THOSE
+    const bool bias_own = (kl >= B), bias_maybe = bias_own || (xn > 1 && fl.z > 1 && constrained), mom = m.mom > 0.f;
     const int adapt = m.adapt;
     const float v1 = m.ap0, v3 = m.ap1, lr = m.lr, lmbd = m.lmbd, momc = m.mom, clip = m.gclip[0];
     const bool adagrad = (adapt == G4R_ADAPT_ADAGRAD);
-    const GAS float *g_dSx = m.dSx, *g_dSy = m.dSy, *g_dSBy = m.dSBy;
+    const int oSx = m.xoffSx, oSy = m.xoffSy, oSB = m.xoffSBy;
     // row state
     float4 p0[MAXCH], a0[MAXCH], u0[MAXCH], c0[MAXCH], w0[MAXCH], S[MAXCH], Q[MAXCH], T1[MAXCH], gk[MAXCH];
     auto sq = [](float4 x) { return make_float4(x.x * x.x, x.y * x.y, x.z * x.z, x.w * x.w); };
@@ -2482,10 +2547,23 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
         return make_float4(g.x / sqrtf(a.x + g.x * g.x + G4R_EPS_ADAGRAD), g.y / sqrtf(a.y + g.y * g.y + G4R_EPS_ADAGRAD),
                            g.z / sqrtf(a.z + g.z * g.z + G4R_EPS_ADAGRAD), g.w / sqrtf(a.w + g.w * g.w + G4R_EPS_ADAGRAD));
     };
-    auto grow = [&](int j, int q) {          // clipped gradient row chunk of occurrence j
-        const GAS float* srow = (j < B) ? g_dSx + (size_t)j * W : g_dSy + (size_t)(j - B) * W;
-        const float4 g = ld4(srow + 4 * min(lane + 64 * q, nc4 - 1));
-        return make_float4(clip * g.x, clip * g.y, clip * g.z, clip * g.w);
+    const float gsc = clip * xscale;
+    auto grow = [&](int j, int q) {          // clipped gradient row chunk of occurrence j (of the exchanged list)
+        const XPos pj = xlist_pos(m, j);
+        const int jl = pj.k, c = 4 * min(lane + 64 * q, nc4 - 1);
+        const size_t ro = (jl < B) ? (size_t)oSx + (size_t)jl * W : (size_t)oSy + (size_t)(jl - B) * W;
+        float4 g = ld4(xb + (long long)max(pj.q, 0) * xs + ro + c);
+        if (pj.q < 0)                          // REDUCE form, a shared negative: the sum over the ranks' rows of this column, in rank order
+            for (int r2 = 1; r2 < xn; ++r2) { const float4 h = ld4(xb + (long long)r2 * xs + ro + c); g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w; }
+        return make_float4(gsc * g.x, gsc * g.y, gsc * g.z, gsc * g.w);
+    };
+    auto bgrad = [&](int j) {                // clipped output-bias gradient of occurrence j (only for j among Y | samples of its block)
+        const XPos pj = xlist_pos(m, j);
+        const int o = oSB + max(pj.k - B, 0);
+        float g = (xb + (long long)max(pj.q, 0) * xs)[o];
+        if (pj.q < 0)
+            for (int r2 = 1; r2 < xn; ++r2) g += (xb + (long long)r2 * xs)[o];
+        return gsc * g;
     };
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -2497,20 +2575,33 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
         S[q] = z4; Q[q] = z4; T1[q] = z4;
     }
     float bp0 = 0.f, ba0 = 0.f, bu0 = 0.f, bc0 = 0.f, bw0 = 0.f, bgk = 0.f, bS = 0.f, bQ = 0.f, bT1 = 0.f;
-    if (bias) {
-        bp0 = m.By[item]; ba0 = m.accBy[item]; bgk = clip * g_dSBy[k - B];
+    int lastb = bias_own ? k : -1;      // last bias occurrence of the item found so far
+    if (bias_maybe) {
+        bp0 = m.By[item]; ba0 = m.accBy[item]; bgk = bias_own ? bgrad(k) : 0.f;
         if (m.acc2By) bu0 = m.acc2By[item];
         if (m.cntBy) bc0 = m.cntBy[item];
         if (mom) bw0 = m.velBy[item];
     }
     // earlier occurrences in [first, k), 64 per pass, 4 rows per round trip
-    int n = 1, nb = bias ? 1 : 0;
+    int n = 1, nb = bias_own ? 1 : 0;
+    // MEAN form of the exact-replica mode (sparse_exact = 2; what the GPU-local mode's reconciliation does, taken every step): the
+    // item's parameter increment is the MEAN over the ranks that touch it of each rank's own increment (N full-size Adagrad steps
+    // from one starting point must not add up: measured), and the Adagrad accumulator takes the SUM over those
+    // ranks of each rank's last-occurrence increment.  nq / nqb: touching ranks of the row / of the bias; Aadd / bAadd: the
+    // accumulator increments of the ranks' last occurrences.  (An item with more than 64 earlier occurrences: rank boundaries that
+    // fall on a pass boundary are not seen -- a deterministic approximation, identical on every rank.)
+    const bool xmean = m.xmode == 2;
+    int nq = 1, nqb = bias_own ? 1 : 0;
+    float4 Aadd[MAXCH];
+    float bAadd = 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) Aadd[q] = z4;
     if (fl.z > 1) {
         for (int pass = 0;; ++pass) {
             int idx = 0;
             for (int base = first_j & ~63; base < k; base += 64) {
                 const int j = base + lane;
-                const bool hit = j >= first_j && j < k && sOcc[j] == item;
+                const bool hit = j >= first_j && j < k && sOcc[j] == item && same_table(j);
                 const unsigned long long mask = __ballot(hit);
                 const int ord = idx - 64 * pass + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                 if (hit && ord >= 0 && ord < 64) myList[ord] = j;
@@ -2518,11 +2609,33 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
             }
             const int cnt = min(idx - 64 * pass, 64);
             const int myj = lane < cnt ? myList[lane] : -1;
-            if (bias) {
-                const float g = (myj >= B) ? clip * g_dSBy[myj - B] : 0.f;
+            const bool final_pass = idx <= 64 * (pass + 1);
+            // the last occurrence of each rank among the hits: its successor (the next hit, or k behind the final pass) is another rank's
+            int lastrow = 0;
+            if (xmean) {
+                const int nxt_l = myList[min(lane + 1, 63)];
+                const int nxt = (lane + 1 < cnt) ? nxt_l : (final_pass ? k : myj);
+                lastrow = (lane < cnt && (myj / Rl) != (nxt / Rl)) ? 1 : 0;
+                nq += __popcll(__ballot(lastrow != 0));
+            }
+            if (bias_maybe) {
+                const bool isb = myj >= 0 && !is_x(myj);
+                const float g = isb ? bgrad(myj) : 0.f;
                 bS += wave_sum(g); bQ += wave_sum(g * g);
-                bT1 += wave_sum((myj >= B) ? g / sqrtf(ba0 + g * g + G4R_EPS_ADAGRAD) : 0.f);
-                nb += __popcll(__ballot(myj >= B));
+                bT1 += wave_sum(isb ? g / sqrtf(ba0 + g * g + G4R_EPS_ADAGRAD) : 0.f);
+                nb += __popcll(__ballot(isb));
+                if (!bias_own) lastb = max(lastb, (int)wave_max(isb ? (float)myj : -1.f));      // (list positions < 2^24: exact as floats)
+                if (xmean) {
+                    // the next BIAS hit behind this lane (or k, if the owner is a bias occurrence itself)
+                    const unsigned long long mb = __ballot(isb);
+                    const unsigned long long hi = (lane < 63) ? (mb >> (lane + 1)) : 0ull;
+                    const int nl = hi ? lane + 1 + (int)__builtin_ctzll(hi) : -1;
+                    const int nbj_l = myList[max(nl, 0) & 63];
+                    const int nbj = nl >= 0 ? nbj_l : ((final_pass && bias_own) ? k : -1);
+                    const bool lastbias = isb && (nbj < 0 || (myj / Rl) != (nbj / Rl));
+                    nqb += __popcll(__ballot(lastbias));
+                    bAadd += wave_sum(lastbias ? g * g : 0.f);
+                }
             }
             for (int i0 = 0; i0 < cnt; i0 += 4) {
                 float4 g[4][MAXCH];
@@ -2535,10 +2648,12 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (i0 + u < cnt) {
+                        const bool lr_u = __builtin_amdgcn_readlane(lastrow, min(i0 + u, cnt - 1) & 63) != 0;
 #pragma unroll
                         for (int q = 0; q < MAXCH; ++q) {
                             add4(S[q], g[u][q]); add4(Q[q], sq(g[u][q]));
                             if (adagrad) add4(T1[q], ada(g[u][q], a0[q]));
+                            if (lr_u) add4(Aadd[q], sq(g[u][q]));
                         }
                     }
                 }
@@ -2563,9 +2678,11 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
             const OptOut o = opt_rule(adapt, v1, v3, false, aa[e], uu[e], cc[e], ss[e], qq[e], tt[e], gg[e], fn);
             const float reg = (lmbd > 0.f) ? lmbd * pp[e] : 0.f;
             const float dsum = lr * (o.G + fn * reg);                  // sum of the per-occurrence deltas (gru4rec.py:419-423)
-            an[e] = o.A; un[e] = o.U; cn[e] = o.C;
-            if (mom) { vn[e] = momc * ww[e] - lr * (o.gl + reg); pn[e] = pp[e] + (fn * (momc * ww[e]) - dsum); }
-            else { vn[e] = 0.f; pn[e] = pp[e] - dsum; }
+            const float ad[4] = {Aadd[q].x, Aadd[q].y, Aadd[q].z, Aadd[q].w};
+            an[e] = (xmean && adagrad) ? o.A + ad[e] : o.A; un[e] = o.U; cn[e] = o.C;
+            const float inc = mom ? (fn * (momc * ww[e]) - dsum) : -dsum;      // the parameter increment of all occurrences together
+            vn[e] = mom ? momc * ww[e] - lr * (o.gl + reg) : 0.f;
+            pn[e] = pp[e] + (xmean ? inc / (float)nq : inc);
         }
         const int c4 = lane + 64 * q;
         if (c4 < nc4) {
@@ -2577,17 +2694,19 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
             if (mom) st4(V + o, make_float4(vn[0], vn[1], vn[2], vn[3]));
         }
     }
-    if (bias && lane == 0) {
-        bS += bgk; bQ += bgk * bgk; bT1 += bgk / sqrtf(ba0 + bgk * bgk + G4R_EPS_ADAGRAD);
+    if (bias_maybe && nb > 0 && lane == 0) {
+        if (bias_own) { bS += bgk; bQ += bgk * bgk; bT1 += bgk / sqrtf(ba0 + bgk * bgk + G4R_EPS_ADAGRAD); }
+        else bgk = bgrad(lastb);      // the sums already hold every bias occurrence; statistics / velocity follow the last of them
         const float fb = (float)nb;
         const OptOut o = opt_rule(adapt, v1, v3, false, ba0, bu0, bc0, bS, bQ, bT1, bgk, fb);
         const float reg = (lmbd > 0.f) ? lmbd * bp0 : 0.f;
         const float dsum = lr * (o.G + fb * reg);
-        m.accBy[item] = o.A;
+        m.accBy[item] = (xmean && adagrad) ? o.A + bAadd : o.A;
         if (m.acc2By) m.acc2By[item] = o.U;
         if (m.cntBy) m.cntBy[item] = o.C;
-        if (mom) { m.velBy[item] = momc * bw0 - lr * (o.gl + reg); m.By[item] = bp0 + (fb * (momc * bw0) - dsum); }
-        else m.By[item] = bp0 - dsum;
+        const float inc = mom ? (fb * (momc * bw0) - dsum) : -dsum;
+        if (mom) m.velBy[item] = momc * bw0 - lr * (o.gl + reg);
+        m.By[item] = bp0 + (xmean ? inc / (float)max(nqb, 1) : inc);
     }
 }
 

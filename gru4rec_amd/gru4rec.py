@@ -127,6 +127,18 @@ class GRU4Rec:
         # 0.01 - 0.015 against every 4 and the exchange moves about the whole table each time); an integer is taken as given, 0 / None
         # reconciles at the end of the epoch only
         self.sync_every = 'auto'
+        # multi-GPU runs, the other way to keep the replicas together: sparse_exact = True all-gathers every rank's per-occurrence
+        # gradient rows of the gathered item rows EVERY step and every rank applies all of them in rank order with the reference's
+        # duplicate semantics (gru4rec.py:335-340,407-431 over the concatenated occurrence list): the item tables never diverge, there
+        # is nothing to reconcile and no sync_every to choose (SURVEY 8e option 3).  Costs an all-gather of R x D floats per rank and
+        # step and needs nranks x (2 batch_size + n_sample) list entries in LDS: for small-catalogue shapes.
+        # All ranks then draw the SAME negatives (one sample stream: the global batch shares its row of negatives, as the reference's
+        # batch does, gru4rec.py:436-437).  True / 'reduce': the gradient rows of the shared negatives are SUMMED over the ranks (what
+        # an all-reduce would give), the ranks' input / target occurrences are listed one rank behind the other, everything scaled to
+        # the global batch -- the occurrence list of ONE batch of nranks x batch_size rows, updated exactly as the reference updates
+        # its batch.  Kept for the A/B of DESIGN.md section 7: 'mean' (every rank's occurrences listed, an item's increment = the mean
+        # over the ranks touching it) and 'sum' (every occurrence of every rank applied like a duplicate: diverges from four ranks on)
+        self.sparse_exact = False
         self._model = None
         self._dist = None
         self._cpu_store = False
@@ -321,8 +333,12 @@ class GRU4Rec:
             adapt_p0=float(self.adapt_params[0]) if len(self.adapt_params) > 0 else 0.0,
             adapt_p1=float(self.adapt_params[1]) if len(self.adapt_params) > 1 else 0.0, grad_cap=float(self.grad_cap),
             dropout_p_hidden=self.dropout_p_hidden, dropout_p_embed=self.dropout_p_embed,
-            sample_store=int(sample_store), seed=int(self.seed) + 7919 * rank, device=int(self.device),
-            rank=rank, nranks=nranks, use_graph=1 if self.use_graph else 0)
+            # sample stream: every rank its own (GPU-local mode: more distinct negatives per global step), or -- exact-replica mode --
+            # ONE stream for all ranks: the global batch then shares one row of negatives per step, as the reference's batch does
+            # (gru4rec.py:436-437), and every sampled item is touched by all ranks, whose increments are averaged
+            sample_store=int(sample_store), seed=int(self.seed) + (0 if self.sparse_exact else 7919 * rank), device=int(self.device),
+            rank=rank, nranks=nranks, use_graph=1 if self.use_graph else 0,
+            sparse_exact=({'sum': 1, 'mean': 2, 'reduce': 3}.get(self.sparse_exact, 3) if (self.sparse_exact and nranks > 1) else 0))
         if self._dist and self._dist['unique_id'] is not None:
             m.comm_init(self._dist['unique_id'], nranks, rank)
             if nranks > 1:
@@ -588,6 +604,8 @@ class GRU4Rec:
         `sync_every` attribute, 'auto' resolved as documented there; 0 = only at the end of an epoch."""
         if nranks is None:
             nranks = self._dist['nranks'] if self._dist else 1
+        if self.sparse_exact:
+            return 0      # exact replicas: nothing to reconcile
         k = self.sync_every
         if k == 'auto':
             return 4 if nranks == 2 else 16
@@ -710,7 +728,7 @@ class GRU4Rec:
                                   'exposes the same computation through gru4rec_amd.evaluation.evaluate_gpu')
 
     # ------------------------------------------------------------------ (de)serialisation (gru4rec.py:742-781)
-    _EXTRAS = dict(seed=12345, device=0, use_graph=True, steps_per_call=16384, sync_every='auto')     # attributes the reference does not have
+    _EXTRAS = dict(seed=12345, device=0, use_graph=True, steps_per_call=16384, sync_every='auto', sparse_exact=False)     # attributes the reference does not have
 
     def __getstate__(self):
         st = dict(self.__dict__)

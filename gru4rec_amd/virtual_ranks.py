@@ -33,28 +33,32 @@ def reconcile(models, groups=(0,), dense=False):
     return rows
 
 
-def fit_virtual_ranks(params, data, nranks, sample_store=10000000, sync_every='default', chunk=64, on_chunk=None, rule=None, replicate=False):
+def fit_virtual_ranks(params, data, nranks, sample_store=10000000, sync_every='default', chunk=64, on_chunk=None, rule=None, replicate=False,
+                       sparse_exact=False):
     """Train `params['n_epochs']` epochs as `nranks` virtual ranks.  Returns (the rank objects -- rank 0 holds the reconciled weights
     on the host, ready for evaluate_gpu / predict_next_batch --, stats dict).  sync_every: reconcile the item tables every that
     many steps ('default': GRU4Rec.sync_every, what fit() does; None: only at the end of each epoch).  rule: (parameter rule, statistic rule) of the reconciliation,
     'sum' / 'mean' each (None: the library's default, g4r_sync_set_rule).  replicate: every rank gets ALL sessions and rank 0's
-    sample stream instead of its shard -- N identical ranks must then reproduce the single-rank run (a check of this machinery)."""
+    sample stream instead of its shard -- N identical ranks must then reproduce the single-rank run (a check of this machinery).
+    sparse_exact: the exact-replica mode (GRU4Rec.sparse_exact): per-occurrence gradient rows exchanged every step, nothing to reconcile."""
     grus = []
     for r in range(nranks):
         g = GRU4Rec(**params)
+        g.sparse_exact = sparse_exact      # False / True (= 'reduce') / 'reduce' / 'mean' / 'sum'
         g.set_distributed(r, nranks, None)
         if replicate:
             g.seed -= 7919 * r      # _create_model adds 7919 * rank
         g.prepare(data.copy(), sample_store=sample_store)
-        if nranks > 1:
+        exact = bool(getattr(g, 'sparse_exact', False)) and nranks > 1
+        if nranks > 1 and not exact:
             g._model.sync_enable()
             if rule is not None:
                 g._model.sync_set_rule(*rule)
         grus.append(g)
     if sync_every == 'default':
         sync_every = grus[0].sync_steps(nranks)
-    if nranks <= 1:
-        sync_every = None      # nothing to reconcile
+    if nranks <= 1 or exact:
+        sync_every = None      # nothing to reconcile (one rank; or sparse_exact: the replicas never diverge)
     models = [g._model for g in grus]
     groups = (0,) if grus[0].constrained_embedding or not grus[0].embedding else (0, 1)
     stats = dict(steps=[], events=[], loss=[], sync_rows=0, syncs=0)
@@ -87,7 +91,7 @@ def fit_virtual_ranks(params, data, nranks, sample_store=10000000, sync_every='d
         stats.setdefault('step_costs', []).append(costs)
         if any(np.isnan(c).any() for c in costs):
             raise FloatingPointError('NaN cost in a virtual-rank epoch')
-        if nranks > 1:
+        if nranks > 1 and not exact:
             stats['sync_rows'] += reconcile(models, groups)
             stats['syncs'] += 1
         Ms = [p['M'][:T] for p in plans]

@@ -68,7 +68,22 @@ typedef struct g4r_config {
     int32_t adapt;               /* G4R_ADAPT_* */
     float   adapt_p0, adapt_p1;  /* adapt_params (rmsprop / adadelta: decay; adam: beta1, beta2), gru4rec.py:301-304,342,368 */
     float   grad_cap;            /* global gradient-norm clip, 0 = off, gru4rec.py:386-389 */
-    int32_t reserved[2];
+    int32_t sparse_exact;        /* N > 1 only.  0: item rows stay GPU-local between reconciliations (north_star; g4r_comm_sync_sparse /
+                                    g4r_set_sync_every).  1: EXACT replicas -- every step each rank's per-occurrence gradient rows of the
+                                    gathered item rows are all-gathered and every rank applies all of them in rank order, with the
+                                    reference's duplicate semantics over the concatenated occurrence list (gru4rec.py:335-340,407-431):
+                                    replicas never diverge, no base copies, no sync_every (SURVEY 8e option 3).  Measured with virtual
+                                    ranks: applying ALL ranks' per-occurrence Adagrad steps diverges from four
+                                    ranks on, like summed deltas did in round 3 -- the popular items receive N full-size steps.
+                                    2: the same exchange, MEAN form: an item's parameter increment is the mean over the ranks that
+                                    touch it of each rank's own increment, its Adagrad accumulator the sum of those ranks'
+                                    last-occurrence increments -- the GPU-local mode's reconciliation rule taken every step.
+                                    3 (what GRU4Rec.sparse_exact = True selects): REDUCE form.  All ranks draw the same negatives; the
+                                    gradient rows of those shared columns are summed over the ranks, the ranks' input / target
+                                    occurrences are listed one rank behind the other, all scaled by 1 / nranks: the occurrence list of
+                                    ONE batch of nranks x batch_size rows sharing one row of negatives (gru4rec.py:436-437), updated
+                                    with the reference's rule.  Modes 1-3 want the same `seed` on every rank (one sample stream) */
+    int32_t reserved;
 } g4r_config;
 
 typedef struct g4r_model g4r_model;

@@ -494,11 +494,17 @@ class OracleGRU4Rec:
             self._dense_update('Wrz', i, dWrz)
             self._dense_update('Bh', i, dBh)
         if self.constrained_embedding:
-            self._sparse_update('Wy', Xc, np.vstack([dSx, dSy]).astype(self.dtype))
+            sparse = [('Wy', Xc, np.vstack([dSx, dSy]).astype(self.dtype))]
         else:
-            self._sparse_update('Wx0' if self.onehot else 'E', in_idx, dSx.astype(self.dtype))
-            self._sparse_update('Wy', Yp, dSy.astype(self.dtype))
-        self._sparse_update('By', Yp, dSBy.astype(self.dtype))
+            sparse = [('Wx0' if self.onehot else 'E', in_idx, dSx.astype(self.dtype)), ('Wy', Yp, dSy.astype(self.dtype))]
+        sparse.append(('By', Yp, dSBy.astype(self.dtype)))
+        # data-parallel hook (not in the reference; the product's exact-replica mode, g4r_config::sparse_exact): the per-occurrence
+        # (index, gradient row) lists of ALL ranks, concatenated in rank order, are applied on every replica with the reference's
+        # duplicate semantics -- the hook receives this rank's lists and returns the lists to apply
+        if getattr(self, 'sparse_grad_hook', None) is not None:
+            sparse = self.sparse_grad_hook(sparse)
+        for (name, idx, g) in sparse:
+            self._sparse_update(name, idx, g)
         self.H = newH
         self.global_step += 1
         if return_debug:

@@ -37,6 +37,7 @@ OPTIONS = [
     ('-tk', '--time_key', dict(metavar='TK', default='Time', help='timestamp column (default Time)')),
     ('-pm', '--primary_metric', dict(metavar='METRIC', choices=['recall', 'mrr'], default='recall', help='metric reported on the PRIMARY METRIC line (default recall)')),
     ('-lpm', '--log_primary_metric', dict(action='store_true', help='print the PRIMARY METRIC line after every evaluation')),
+    (None, '--sparse_exact', dict(action='store_true', help='with --gpus N: keep the replicas bit-identical by exchanging every rank\'s per-occurrence gradient rows of the item tables every step (RCCL all-gather; an item\'s increment is the mean over the ranks touching it) instead of reconciling GPU-local rows every sync_every steps; for small catalogues')),
     (None, '--gpus', dict(metavar='N', type=int, default=1, help='train on N GPUs of this node (not in the reference): one process per GPU, sessions sharded over '
                           'the ranks, dense GRU gradients all-reduced by RCCL every step, item rows GPU-local and reconciled every sync_every steps (4 at two ranks, 16 from three on) and at every epoch end; rank 0 saves / evaluates')),
 ]
@@ -112,6 +113,7 @@ def train(model_cls, opts):
             print('ERROR. The model class {} does not support --gpus'.format(model_cls.__module__))
             sys.exit(1)
         model.device = local_rank
+        model.sparse_exact = bool(opts.sparse_exact)
         model.set_distributed(rank, world, launch.unique_id(rank, world))
     print('Loading training data...')
     events = read_events(opts.path, opts, model_cls)

@@ -79,6 +79,7 @@ def make_pair(I, B, ns, store_rows, seed=3, **kw):
     """An oracle and a device model with identical weights / popularity / sample store."""
     use_graph = kw.pop('use_graph', 0)
     rank, nranks = kw.pop('rank', 0), kw.pop('nranks', 1)      # a handle that is one rank of several (same weights, same sample stream)
+    sparse_exact = kw.pop('sparse_exact', 0)
     o = OracleGRU4Rec(n_items=I, batch_size=B, n_sample=ns, dtype=np.float32, seed=seed, **kw)
     rng = np.random.RandomState(seed)
     support = rng.randint(1, 40, size=I)
@@ -97,7 +98,7 @@ def make_pair(I, B, ns, store_rows, seed=3, **kw):
         adapt_p1=float(o.adapt_params[1]) if len(o.adapt_params) > 1 else 0.0, grad_cap=float(o.grad_cap),
         sample_alpha=o.sample_alpha, dropout_p_hidden=o.dropout_p_hidden, dropout_p_embed=o.dropout_p_embed,
         sample_store=store_rows * ns if ns else 0, seed=seed, device=0, rank=rank, nranks=nranks,
-        use_graph=use_graph)
+        use_graph=use_graph, sparse_exact=sparse_exact)
     # non-trivial biases / hidden state so that every term is exercised
     for i, D in enumerate(o.layers):
         o.Bh[i] = (rng.randn(3 * D) * 0.1).astype(np.float32)
