@@ -526,10 +526,11 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel (one copy of a score row must fit the 160 KB of LDS)"); }
     if (m->smem_sparse > (size_t)big) { g4r_destroy(m); return fail("2 * batch_size + n_sample too large for the sparse update (the step's list of gathered rows must fit the 160 KB of LDS)"); }
     if (m->exact) {
-        m->smem_exact = (size_t)((((size_t)d.R * d.xn + 255) & ~(size_t)255) + 256) * sizeof(int) + 64 * SP_WAVES * sizeof(int);
+        const size_t rlist = d.xmode == 3 ? (size_t)d.xn * 2 * B + d.ns : (size_t)d.R * d.xn;      // xlist_len: entries of the exchanged list
+        m->smem_exact = (size_t)(((rlist + 255) & ~(size_t)255) + 256) * sizeof(int) + 64 * SP_WAVES * sizeof(int);
         if (m->smem_exact > (size_t)big) {
             g4r_destroy(m);
-            return fail("sparse_exact: nranks * (2 * batch_size + n_sample) occurrences do not fit the 160 KB of LDS the update stages the concatenated list in -- use the GPU-local mode (sync_every) at this shape");
+            return fail("sparse_exact: the exchanged occurrence list (REDUCE form: nranks * 2 * batch_size + n_sample entries; MEAN / SUM: nranks * (2 * batch_size + n_sample)) does not fit the 160 KB of LDS the update stages it in -- use the GPU-local mode (sync_every) at this shape");
         }
     }
     { float* z = nullptr; if (dalloc(m, &z, ZROW_FLOATS)) { g4r_destroy(m); return -1; } d.zrow = z; }

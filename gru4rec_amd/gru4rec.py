@@ -608,6 +608,15 @@ class GRU4Rec:
             return 0      # exact replicas: nothing to reconcile
         k = self.sync_every
         if k == 'auto':
+            # catalogues too large for the on-stream dense reconciliation (item tables > 64 MB per group: the packed-parts exchange moves
+            # the rows touched since the last call): every 64 steps.  Measured at a configs[3]-like shape (1 M items, layers [256],
+            # B = 512, 8192 negatives, 8 virtual ranks; profiles/r04_virtual_ranks_large.json): Recall@20 0.092 / 0.094 / 0.093 / 0.091 at
+            # every 4 / 16 / 64 steps / epoch end -- the ranks' rows rarely collide on a catalogue of that size, what is lost against
+            # one rank (0.385) is the 8 x larger global batch (one rank at B = 4096: 0.098) -- while a reconciliation moves 0.20 / 0.55 /
+            # 1.21 / 1.57 M rows: 64 keeps the exchange at ~19 K rows per step.
+            width = max(_pad4(int(self.layers[-1])), 1)
+            if getattr(self, 'n_items', 0) and int(self.n_items) * (2 * width + 2 + 1) * 4 > 64 * 1024 * 1024:
+                return 64
             return 4 if nranks == 2 else 16
         if not k:
             return 0

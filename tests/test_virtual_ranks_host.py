@@ -132,3 +132,23 @@ def test_run_epoch_reconciles_every_sync_every_steps_on_every_rank(sync_every, s
     if every:
         assert m.dev_k == every
     assert m.maxes == len(m.calls) + 1            # one collective NaN check per call + one for the epoch loss
+
+
+def test_sync_every_auto_follows_rank_count_catalogue_size_and_the_exact_mode():
+    """'auto': 4 steps at two ranks, 16 from three on (round-3 study, 2.5 K items); 64 for catalogues whose item tables do not fit
+    the on-stream dense reconciliation (round-4 study at 1 M items x 256: the frequency does not move Recall@20 there, the volume
+    grows with the interval); the exact-replica mode reconciles nothing."""
+    from gru4rec_amd.gru4rec import GRU4Rec
+    g = GRU4Rec(layers=[100])
+    g.n_items = 37483
+    assert (g.sync_steps(2), g.sync_steps(4), g.sync_steps(8)) == (4, 16, 16)
+    g.n_items = 10_000_000
+    g.layers = [256]
+    assert (g.sync_steps(2), g.sync_steps(8)) == (64, 64)
+    g.sync_every = 8
+    assert g.sync_steps(8) == 8
+    g.sync_every = 0
+    assert g.sync_steps(8) == 0
+    g.sync_every = 'auto'
+    g.sparse_exact = True
+    assert g.sync_steps(8) == 0
