@@ -2382,7 +2382,7 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     if (G4R_DBGCLK(m) && lane == 0 && k < R) {
         const long long t_end = wall_clock64();
         GAS long long* tr = G4R_DBGCLK(m) + 64 + 8 * k;
-        tr[0] = t_start; tr[1] = t_own; tr[2] = t_col; tr[3] = t_app; tr[4] = t_end; tr[5] = (owner ? fl.z : 0) | ((t_h[0] ? t_h[0] - t_app : 0) << 20); tr[6] = 0;
+        tr[0] = t_start; tr[1] = t_own; tr[2] = t_col; tr[3] = t_app; tr[4] = t_end; tr[5] = (owner ? fl.z : 0) | ((t_h[0] ? t_h[0] - t_app : 0) << 20); tr[6] = load_ctx(st).t;
         tr[7] = (t_h[1] - t_h[0]) | ((t_h[2] - t_h[1]) << 16) | ((t_h[3] - t_h[2]) << 32) | ((t_h[4] - t_h[3]) << 48);
     }
 }
