@@ -127,12 +127,26 @@ def make_plan(cfg, n_steps, rank, nranks, seed=42, session_items=0):
     B = cfg['batch_size']
     n_sessions = int(n_steps * B / 2.6) + 8 * B           # ~2.9 scoring events per session
     n_items = min(cfg['n_items'], session_items) if session_items > 0 else cfg['n_items']
-    data = synth.make_sessions(n_sessions * nranks, n_items=n_items, seed=seed)
-    sizes = data.groupby('SessionId').size().values
+    # the generator is deterministic; its output for a 10 M-item catalogue takes ~20 s of host time, so consecutive invocations on
+    # one box (profile passes) share it through a file in the temp directory
+    import tempfile
+    cache = os.path.join(tempfile.gettempdir(), 'g4r_synth_%d_%d_%d_v1.npz' % (n_sessions * nranks, n_items, seed))
+    if os.path.exists(cache):
+        z = np.load(cache)
+        sizes, ids, items_all = z['sizes'], z['ids'], z['items_all']
+    else:
+        data = synth.make_sessions(n_sessions * nranks, n_items=n_items, seed=seed)
+        sizes = data.groupby('SessionId').size().values
+        ids, inv = np.unique(data.ItemId.values, return_inverse=True)
+        items_all = inv.astype(np.int32)
+        try:
+            tmp = cache + '.%d.npz' % os.getpid()
+            np.savez(tmp, sizes=sizes, ids=ids, items_all=items_all)
+            os.replace(tmp, cache)
+        except OSError:
+            pass
     offs = np.zeros(len(sizes) + 1, dtype=np.int64)
     offs[1:] = np.cumsum(sizes)
-    ids, inv = np.unique(data.ItemId.values, return_inverse=True)
-    items_all = inv.astype(np.int32)
     if cfg['n_items'] > len(ids):
         # the sessions name len(ids) distinct items (np.unique made them consecutive): spread them over the full catalogue with a
         # fixed random injection, so that their rows lie all over the table and not in its first pages
@@ -150,7 +164,7 @@ def make_plan(cfg, n_steps, rank, nranks, seed=42, session_items=0):
     return plan, support
 
 
-def create_model(cfg, support, rank, nranks, device, unique_id, use_graph=True, seed=12345, sample_store=10000000):
+def create_model(cfg, support, rank, nranks, device, unique_id, use_graph=True, seed=12345, sample_store=10000000, sparse_exact=False):
     from gru4rec_amd import _native
     from gru4rec_amd.gru4rec import _parse_act
     fa = _parse_act(cfg['final_act'], True)
@@ -160,8 +174,8 @@ def create_model(cfg, support, rank, nranks, device, unique_id, use_graph=True, 
         hidden_act=_native.ACT_IDS['tanh'], embed_mode=_native.EMBED_CONSTRAINED, embedding=0,
         learning_rate=cfg['learning_rate'], momentum=cfg['momentum'], lmbd=0.0, bpreg=cfg['bpreg'], logq=cfg['logq'],
         sample_alpha=cfg['sample_alpha'], dropout_p_hidden=cfg['dropout_p_hidden'],
-        dropout_p_embed=cfg['dropout_p_embed'], sample_store=sample_store, seed=seed + 7919 * rank, device=device,
-        rank=rank, nranks=nranks, use_graph=1 if use_graph else 0)
+        dropout_p_embed=cfg['dropout_p_embed'], sample_store=sample_store, seed=seed + (0 if sparse_exact else 7919 * rank), device=device,
+        rank=rank, nranks=nranks, use_graph=1 if use_graph else 0, sparse_exact=3 if sparse_exact else 0)
     if nranks > 1:
         m.comm_init(unique_id, nranks, rank)
     elif os.environ.get('G4R_FORCE_STAGED'):      # diagnostic: the N > 1 data path with a one-rank communicator
@@ -233,6 +247,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-micro', action='store_true', help='skip the row gather / scatter micro-benchmark object')
+    ap.add_argument('--sparse-exact', action='store_true', help='N > 1 (or G4R_FORCE_STAGED=1): the exact-replica mode (REDUCE form) instead of GPU-local '
+                    'item rows + reconciliation: per-occurrence gradient rows all-gathered every step, nothing to reconcile')
     ap.add_argument('--session-items', type=int, default=0, help='distinct items the synthetic sessions are drawn from (0 = the whole catalogue of the '
                     'config; rounds 1-3 used 200000 for cfg3 / cfg4)')
     ap.add_argument('--long-steps', type=int, default=2000, help='a run of --steps below this also times that many steps behind the timed region and '
@@ -259,7 +275,7 @@ def main():
     plan, support = make_plan(cfg, total_steps, rank, world, session_items=args.session_items)
     assert plan['T'] >= total_steps, 'synthetic plan too short: %d < %d' % (plan['T'], total_steps)
     assert (plan['M'][:total_steps] == cfg['batch_size']).all()
-    m = create_model(cfg, support, rank, world, local_rank if world > 1 else 0, unique_id, use_graph=not args.no_graph)
+    m = create_model(cfg, support, rank, world, local_rank if world > 1 else 0, unique_id, use_graph=not args.no_graph, sparse_exact=args.sparse_exact)
     n_ranks = m.comm_nranks()      # what RCCL reports for the communicator (1 without one): n_gpus in the output is THIS number
     if n_ranks != world:
         raise SystemExit('RCCL communicator has %d rank(s), expected %d' % (n_ranks, world))
@@ -312,6 +328,7 @@ def main():
                                    cfg['n_items'], cfg['layers'], cfg['batch_size'], cfg['n_sample'], cfg['loss'])
                    if args.config == 'cfg2' else args.config,
                    'global_batch': cfg['batch_size'] * world, 'parallelism': 'session-sharded dp%d' % world,
+                   'item_rows': 'exact replicas (REDUCE form: gradient rows exchanged every step)' if args.sparse_exact else ('gpu-local, reconciled every sync_every steps' if world > 1 else 'single GPU'),
                    'hip_graph': not args.no_graph,
                    'session_items': int(min(cfg['n_items'], args.session_items) if args.session_items > 0 else cfg['n_items']),
                    'distinct_items_in_plan': int(len(np.unique(np.concatenate([plan['in_idx'].ravel(), plan['out_idx'].ravel()]))))},
@@ -327,7 +344,7 @@ def main():
         m.train_steps(args.warmup + args.steps + n_long, n_profile)
         m.profile(False)
         kt = m.kernel_times()
-    staged = world > 1 or bool(os.environ.get('G4R_FORCE_STAGED'))
+    staged = (world > 1 or bool(os.environ.get('G4R_FORCE_STAGED'))) and not args.sparse_exact
     kt_split = {}
     if n_profile > 0 and world == 1 and not staged:
         # the same again with the update launch split into its two roles (g4r_profile(m, 2)): the embedding gather / scatter -- the
@@ -417,6 +434,38 @@ def main():
                     'all-reduce time includes the skew between ranks)' % n_profile}
     if world == 1 and reconcile is not None:
         out['reconciliation_one_rank_communicator'] = reconcile
+    if world == 1 and os.environ.get('G4R_FORCE_STAGED'):
+        # What 8 GPUs would do, from the pieces one GPU can measure + the two numbers it cannot (stated, with a range): the latency of
+        # the 8-rank collectives over xGMI.  The driver's SCALE run replaces this with a measurement.
+        step_us = 1000.0 * dt / args.steps
+        dense_bytes = 4 * int(m.get_debug('dense_count', (1,))[0])
+        R, D = 2 * cfg['batch_size'] + cfg['n_sample'], cfg['layers'][-1]
+        proj = {'n_gpus': 8, 'one_gpu_fused_step_us_reference': None, 'measured_on_this_gpu': {'step_us_with_one_rank_collectives': step_us},
+                'assumed': {'allreduce_dense_gradients_8_ranks_us': [10.0, 20.0], 'dense_gradient_bytes': dense_bytes,
+                            'note': 'a %d KB all-reduce is latency bound (2 x 7 ring hops or one LL round); the one-rank collective inside the measured '
+                                    'step already costs its launch' % (dense_bytes // 1024)}}
+        if args.sparse_exact:
+            blk = (R * D + R + cfg['batch_size'] * 2) * 4
+            proj['assumed']['allgather_occurrence_blocks_8_ranks_us'] = [20.0, 40.0]
+            proj['assumed']['allgather_bytes_received_per_rank'] = 7 * blk
+            lo = step_us + 10.0 + 20.0
+            hi = step_us + 20.0 + 40.0
+            proj['mode'] = 'exact replicas (REDUCE form)'
+        else:
+            per_call_ms = reconcile.get('ms_per_reconciliation') if reconcile and 'error' not in reconcile else None
+            K = reconcile.get('sync_every') if reconcile and 'error' not in reconcile else None
+            tab = cfg['n_items'] * (2 * D + 3) * 4
+            proj['measured_on_this_gpu']['reconciliation_ms_per_call_one_rank'] = per_call_ms
+            proj['measured_on_this_gpu']['sync_every'] = K
+            proj['assumed']['dense_reconciliation_allreduce_8_ranks_ms'] = [tab / 200e9 * 1e3, tab / 100e9 * 1e3]
+            proj['assumed']['reconciliation_bytes'] = tab
+            am = [(per_call_ms or 0.0) * 1000.0 / max(K or 16, 1) + x * 1000.0 / max(K or 16, 1) for x in proj['assumed']['dense_reconciliation_allreduce_8_ranks_ms']]
+            lo = step_us + 10.0 + am[0]
+            hi = step_us + 20.0 + am[1]
+            proj['mode'] = 'gpu-local item rows, reconciled every %s steps' % K
+        proj['step_us_8_gpus'] = [lo, hi]
+        proj['mini_batches_per_s_8_gpus'] = [8e6 / hi, 8e6 / lo]
+        out['projection_8_gpus'] = proj
     if rank == 0 and world == 1 and n_profile > 0:
         alg = algorithmic_cost(cfg)
         kern = {}
@@ -457,6 +506,14 @@ def main():
                 if k == name or k.startswith(name):
                     return v.get('traffic_bytes')
             return None
+        pmc2_path = newest_profile('pmc_traffic_%s_no_merge.json' % args.config)
+        pmc2 = json.load(open(pmc2_path))['kernels'] if os.path.exists(pmc2_path) else {}
+
+        def traffic_split(name):      # the same counters from the passes run with G4R_NO_MERGE=1 (the update launch as its two roles)
+            for k, v in pmc2.items():
+                if k == name or k.startswith(name):
+                    return v.get('traffic_bytes')
+            return None
         # the roofline entry: the DOMINANT kernel of the step (largest time per step), priced with its algorithmic flops / bytes
         dk, dv = dom
         if 'bound' in dv:
@@ -492,7 +549,7 @@ def main():
                 moved = (3 + mom_planes(cfg)) * (2 * cfg['batch_size'] + cfg['n_sample']) * cfg['layers'][-1] * 4
                 alone = {'kernel': 'k_sparse_update', 'avg_us': us_a, 'launches': n_a,
                          'achieved': sparse_bytes / (us_a * 1e-6) / 1e9, 'frac': sparse_bytes / (us_a * 1e-6) / 1e9 / 8000.0, 'unit': 'GB/s',
-                         'traffic': traffic_of('k_sparse_update'),
+                         'traffic': traffic_split('k_sparse_update'),
                          'rows_moved_bytes': moved, 'achieved_on_rows_moved': moved / (us_a * 1e-6) / 1e9,
                          'k_dense_grad_alone_us': (1000.0 * ms_d / n_d) if n_d else None,
                          'note': 'g4r_profile(m, 2): the sparse row update as a launch of its own (k_sparse_update; the dense-gradient tiles '

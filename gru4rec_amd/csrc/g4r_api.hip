@@ -300,7 +300,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     d.smoothing = cfg->smoothing;
     d.adapt = cfg->adapt; d.ap0 = cfg->adapt_p0; d.ap1 = cfg->adapt_p1; d.grad_cap = cfg->grad_cap;
     // exact-replica mode of N > 1: raw per-occurrence gradients (the generic path's producers), exchanged every step
-    const bool exact = cfg->sparse_exact != 0 && cfg->nranks > 1;
+    // (G4R_FORCE_STAGED=1: the N > 1 data path with a one-rank communicator -- what a 1-GPU box can run and time of it)
+    const bool exact = cfg->sparse_exact != 0 && (cfg->nranks > 1 || getenv("G4R_FORCE_STAGED") != nullptr);
     if (cfg->sparse_exact != 0 && cfg->grad_cap > 0.f) { g4r_destroy(m); return fail("sparse_exact does not support grad_cap (the norm would be per rank)"); }
     m->exact = exact;
     d.generic = (cfg->adapt != G4R_ADAPT_ADAGRAD || cfg->grad_cap > 0.f || exact) ? 1 : 0;
