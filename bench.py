@@ -361,7 +361,9 @@ def main():
         # replicas drift apart); that cost is measured here, separately, over the rows the next `sync_every` steps touch, and
         # reported next to `value` -- never inside it, never hidden.
         from gru4rec_amd.gru4rec import GRU4Rec
-        K = GRU4Rec().sync_steps(max(world, 1)) or 16
+        g_ = GRU4Rec(layers=list(cfg['layers']))
+        g_.n_items = cfg['n_items']
+        K = g_.sync_steps(world if world > 1 else 8) or 16      # what fit() uses at this rank count (one-rank communicator: as for 8) and catalogue size ('auto')
         try:
             t_sync = []
             base_t = args.warmup + args.steps + n_long + n_profile + max(8, n_profile // 4)
@@ -437,7 +439,7 @@ def main():
     if world == 1 and os.environ.get('G4R_FORCE_STAGED'):
         # What 8 GPUs would do, from the pieces one GPU can measure + the two numbers it cannot (stated, with a range): the latency of
         # the 8-rank collectives over xGMI.  The driver's SCALE run replaces this with a measurement.
-        step_us = 1000.0 * dt / args.steps
+        step_us = 1e6 * dt / args.steps
         dense_bytes = 4 * int(m.get_debug('dense_count', (1,))[0])
         R, D = 2 * cfg['batch_size'] + cfg['n_sample'], cfg['layers'][-1]
         proj = {'n_gpus': 8, 'one_gpu_fused_step_us_reference': None, 'measured_on_this_gpu': {'step_us_with_one_rank_collectives': step_us},
@@ -457,9 +459,21 @@ def main():
             tab = cfg['n_items'] * (2 * D + 3) * 4
             proj['measured_on_this_gpu']['reconciliation_ms_per_call_one_rank'] = per_call_ms
             proj['measured_on_this_gpu']['sync_every'] = K
-            proj['assumed']['dense_reconciliation_allreduce_8_ranks_ms'] = [tab / 200e9 * 1e3, tab / 100e9 * 1e3]
-            proj['assumed']['reconciliation_bytes'] = tab
-            am = [(per_call_ms or 0.0) * 1000.0 / max(K or 16, 1) + x * 1000.0 / max(K or 16, 1) for x in proj['assumed']['dense_reconciliation_allreduce_8_ranks_ms']]
+            if tab <= 64 * 1024 * 1024:
+                # small item tables: the on-stream dense form, one all-reduce of [n_items][widths + 1] floats per call
+                proj['assumed']['dense_reconciliation_allreduce_8_ranks_ms'] = [tab / 200e9 * 1e3, tab / 100e9 * 1e3]
+                proj['assumed']['reconciliation_bytes'] = tab
+                am = [(per_call_ms or 0.0) * 1000.0 / max(K or 16, 1) + x * 1000.0 / max(K or 16, 1) for x in proj['assumed']['dense_reconciliation_allreduce_8_ranks_ms']]
+            else:
+                # catalogues beyond the dense form: the packed-parts exchange moves the rows touched since the last call -- on a
+                # catalogue this size nearly every gathered row is a new one, so the volume per STEP does not shrink with the interval
+                row_bytes = (2 * D + 2) * 4
+                vol = R * row_bytes
+                proj['assumed']['exchange_bytes_per_rank_and_step'] = vol
+                proj['assumed']['allgather_rate_GBps'] = [200.0, 400.0]
+                proj['assumed']['note_exchange'] = ('rows touched per step x (parameter + accumulator row): every rank receives 7 x that; only a reconciliation '
+                                                    'rare enough for the touched set to saturate (epoch end) amortises it -- DESIGN.md section 7')
+                am = [7 * vol / (r * 1e3) for r in (400.0, 200.0)]
             lo = step_us + 10.0 + am[0]
             hi = step_us + 20.0 + am[1]
             proj['mode'] = 'gpu-local item rows, reconciled every %s steps' % K
