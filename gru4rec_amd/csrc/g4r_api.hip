@@ -955,9 +955,12 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
             hipLaunchKernelGGL(k_grad_sqsum, dim3(G4R_NORM_BLOCKS), dim3(256), 0, cs, dmp, stp);
             hipLaunchKernelGGL(k_grad_clip, dim3(1), dim3(64), 0, cs, dmp);
         }
-        if (!overlap) begin(KN_DENSE_APPLY);
-        LK(k_dense_apply, dim3(cdiv(d.dense_count, 256)), dim3(256), 0, cs, (const DevModel*)m->d_dm);
-        if (!overlap) end();
+        // (generic optimizer path: the dense rule runs as extra workgroups of the sparse update's launch below)
+        if (!d.generic) {
+            if (!overlap) begin(KN_DENSE_APPLY);
+            LK(k_dense_apply, dim3(cdiv(d.dense_count, 256)), dim3(256), 0, cs, (const DevModel*)m->d_dm);
+            if (!overlap) end();
+        }
         if (dist && overlap) HIPCHK(hipEventRecord(m->ev_join, cs));
     }
     if (d.generic) {
@@ -971,16 +974,16 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
                 if (!m->comm_ready) return fail("sparse_exact needs the RCCL communicator (g4r_comm_init)");
                 NCCLCHK(ncclAllGather((const float*)d.xbase + (size_t)m->cfg.rank * (size_t)d.xstride, (float*)d.xbase, (size_t)d.xstride, ncclFloat, m->comm, s));
             }
-            hipLaunchKernelGGL(k_exact_clear, dim3(cdiv(d.R, 256)), dim3(256), 0, s, dmp);
             const long long rlist = d.xmode == 3 ? (long long)d.xn * 2 * B + d.ns : (long long)d.R * d.xn;      // xlist_len
             hipLaunchKernelGGL(k_exact_occ, dim3(cdiv(rlist, 256)), dim3(256), 0, s, dmp);
             nblk_g = cdiv(rlist, SP_WAVES);
             smem_g = m->smem_exact;
         }
         begin(KN_SPARSE);
-        if (row_chunks(d) == 1) LK(k_sparse_update_generic<1>, dim3(nblk_g + 1), dim3(SP_WAVES * 64), smem_g, s, dmp, stp, nblk_g);
-        else if (row_chunks(d) == 2) LK(k_sparse_update_generic<2>, dim3(nblk_g + 1), dim3(SP_WAVES * 64), smem_g, s, dmp, stp, nblk_g);
-        else LK(k_sparse_update_generic<4>, dim3(nblk_g + 1), dim3(SP_WAVES * 64), smem_g, s, dmp, stp, nblk_g);
+        const int nda = d.apply_dense_inplace ? 0 : cdiv(d.dense_count, SP_WAVES * 64);      // workgroups of the dense rule behind the row blocks
+        if (row_chunks(d) == 1) LK(k_sparse_update_generic<1>, dim3(nblk_g + 1 + nda), dim3(SP_WAVES * 64), smem_g, s, dmp, stp, nblk_g, nda);
+        else if (row_chunks(d) == 2) LK(k_sparse_update_generic<2>, dim3(nblk_g + 1 + nda), dim3(SP_WAVES * 64), smem_g, s, dmp, stp, nblk_g, nda);
+        else LK(k_sparse_update_generic<4>, dim3(nblk_g + 1 + nda), dim3(SP_WAVES * 64), smem_g, s, dmp, stp, nblk_g, nda);
         end();
         HIPCHK(hipGetLastError());
         return 0;

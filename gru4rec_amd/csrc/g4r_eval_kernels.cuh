@@ -241,13 +241,13 @@ template __global__ void k_sparse_update<1, false>(const DevModel*, StepState*, 
 template __global__ void k_sparse_update<1, true>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update<2, false>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update<2, true>(const DevModel*, StepState*, int);
-template __global__ void k_sparse_update_generic<1>(const DevModel*, StepState*, int);
-template __global__ void k_sparse_update_generic<2>(const DevModel*, StepState*, int);
+template __global__ void k_sparse_update_generic<1>(const DevModel*, StepState*, int, int);
+template __global__ void k_sparse_update_generic<2>(const DevModel*, StepState*, int, int);
 template __global__ void k_loss_rows<false>(const DevModel*, StepState*);
 template __global__ void k_loss_rows<true>(const DevModel*, StepState*);
 template __global__ void k_sparse_update<4, false>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update<4, true>(const DevModel*, StepState*, int);
-template __global__ void k_sparse_update_generic<4>(const DevModel*, StepState*, int);
+template __global__ void k_sparse_update_generic<4>(const DevModel*, StepState*, int, int);
 template __global__ void k_update<1, 32, false>(const DevModel*, StepState*, const DenseTile*, int, int);
 template __global__ void k_update<1, 32, true>(const DevModel*, StepState*, const DenseTile*, int, int);
 template __global__ void k_update<2, 32, false>(const DevModel*, StepState*, const DenseTile*, int, int);

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_p1(const DevModel* __restric
         sRow[tid] = item;
         if (train && l == 0 && blockIdx.x == 0 && row < m.B) {
             m.occ_idx[row] = item;
-            if (item >= 0) {      // first / last occurrence of the item in this step's gathered-row list (k_sparse_update)
+            if (item >= 0 && m.xmode == 0) {      // first / last occurrence of the item in this step's gathered-row list (k_sparse_update); exact-replica mode: k_exact_occ publishes the exchanged list instead
                 int* fl = (int*)m.occ_fl + 4 * ((m.embed_mode == G4R_EMBED_CONSTRAINED ? 0 : (size_t)m.n_items) + item);
                 atomicMax(fl, row + 1);
                 atomicMax(fl + 1, m.R - row);
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(512) void k_gru_fwd_fused(const DevModel* __restric
         sRow[tid] = item;
         if (l == 0 && blockIdx.x == 0 && rrow < B) {
             m.occ_idx[rrow] = item;
-            if (item >= 0) {      // first / last occurrence of the item in this step's gathered-row list (k_update)
+            if (item >= 0 && m.xmode == 0) {      // first / last occurrence of the item in this step's gathered-row list (k_update)
                 int* fl = (int*)m.occ_fl + 4 * ((m.embed_mode == G4R_EMBED_CONSTRAINED ? 0 : (size_t)m.n_items) + item);
                 atomicMax(fl, rrow + 1);
                 atomicMax(fl + 1, m.R - rrow);
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
             m.col_item[n] = item;
             if (n < N) {
                 m.occ_idx[B + n] = item;
-                if (item >= 0) {
+                if (item >= 0 && m.xmode == 0) {
                     int* fl = (int*)m.occ_fl + 4 * (size_t)item;
                     atomicMax(fl, B + n + 1);
                     atomicMax(fl + 1, m.R - (B + n));
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : 2) void k_score_fwd_sk(const De
                 m.col_item[n] = item;
                 if (n < N) {
                     m.occ_idx[B + n] = item;
-                    if (item >= 0) {
+                    if (item >= 0 && m.xmode == 0) {
                         int* fl = (int*)m.occ_fl + 4 * (size_t)item;
                         atomicMax(fl, B + n + 1);
                         atomicMax(fl + 1, m.R - (B + n));
@@ -1965,11 +1965,8 @@ __global__ __launch_bounds__(64) void k_grad_clip(const DevModel* __restrict__ m
     }
 }
 
-// after the RCCL all-reduce: element-wise dense Adagrad on the averaged gradient
-__global__ __launch_bounds__(256) void k_dense_apply(const DevModel* __restrict__ mp) {
-    const DevModel& m = *mp;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= m.dense_count) return;
+// after the RCCL all-reduce: element-wise dense rule on the averaged gradient (element i of the flat dense buffers)
+__device__ __forceinline__ void dense_apply_elem(const DevModel& m, int i) {
     if (!m.generic) { dense_adagrad(m, (size_t)i, m.dense_g[i] * m.grad_scale); return; }
     const float g = m.dense_g[i] * m.grad_scale * m.gclip[0];
     const float a0 = m.dense_acc[i], u0 = m.dense_acc2 ? m.dense_acc2[i] : 0.f, c0 = m.dense_cnt ? m.dense_cnt[i] : 0.f;
@@ -1985,6 +1982,11 @@ __global__ __launch_bounds__(256) void k_dense_apply(const DevModel* __restrict_
     } else {
         m.dense_p[i] = p * (1.0f - m.lr * m.lmbd) - m.lr * o.G;
     }
+}
+__global__ __launch_bounds__(256) void k_dense_apply(const DevModel* __restrict__ mp) {
+    const DevModel& m = *mp;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < m.dense_count) dense_apply_elem(m, i);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2415,17 +2417,8 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_update(const DevModel* __r
 
 // ---------------------------------------------------------------------------------------------
 // Exact-replica mode (g4r_config::sparse_exact): the (last, first, count) table of the CONCATENATED occurrence list.  The forward
-// kernels published this rank's own occurrences with their local positions: k_exact_clear takes those entries back to zero,
-// k_exact_occ (behind it in stream order, after the all-gather) publishes all xn * R occurrences with their global positions.
-__global__ __launch_bounds__(256) void k_exact_clear(const DevModel* __restrict__ mp) {
-    const DevModel& m = *mp;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= m.R) return;
-    const int item = m.occ_idx[k];
-    if (item < 0) return;
-    const bool tableE = (k < m.B && m.embed_mode != G4R_EMBED_CONSTRAINED);
-    *(GAS int4*)(m.occ_fl + 4 * ((tableE ? (size_t)m.n_items : 0) + item)) = make_int4(0, 0, 0, 0);
-}
+// kernels do not publish their own occurrences in this mode (`xmode != 0`); k_exact_occ, behind the all-gather in stream order,
+// publishes all xn * R occurrences with their global positions, and the owners in k_sparse_update_generic take the entries back to zero.
 // Position K of the exchanged occurrence list -> (rank block q, occurrence k of that rank's X | Y | samples list).
 //   xmode 1 / 2 (SUM / MEAN forms): the ranks' lists one behind the other, K = q * R + k, xn * R entries;
 //   xmode 3 (REDUCE form; all ranks draw the SAME negatives): X | Y of rank 0, X | Y of rank 1, ..., then the sample part ONCE
@@ -2471,13 +2464,21 @@ __global__ __launch_bounds__(256) void k_exact_occ(const DevModel* __restrict__ 
 // statistics / velocity take the LAST occurrence -- hold over the concatenated list, i.e. ranks count as later occurrences in rank
 // order.  xn == 1 is the single-rank generic path.
 template <int MAXCH>
-__global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const DevModel* __restrict__ mp, StepState* st, int nblk_occ) {
+__global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const DevModel* __restrict__ mp, StepState* st, int nblk_occ, int nda) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const StepCtx c = load_ctx(st);
     const int B = m.B, Rl = m.R, xn = m.xn, R = xlist_len(m);      // Rl: occurrences per rank, R: of the whole (exchanged) list
-    if ((int)blockIdx.x == nblk_occ) {       // bookkeeping block, as in k_sparse_update
+    // grid: [0, nda) the dense rule on the (all-reduced) flat gradient -- it shares the launch, independent of the item rows, and is
+    // dispatched first --, then nblk_occ row blocks, then the bookkeeping block
+    if ((int)blockIdx.x < nda) {
+        const int i = (int)blockIdx.x * (SP_WAVES * 64) + tid;
+        if (i < m.dense_count) dense_apply_elem(m, i);
+        return;
+    }
+    const int bid = (int)blockIdx.x - nda;
+    if (bid == nblk_occ) {       // bookkeeping block, as in k_sparse_update
+        const StepCtx c = load_ctx(st);
         const int Mn = m.Mplan[c.t + 1];
         if (wid == 0) {
             float s = 0.f;
@@ -2501,27 +2502,20 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
     const int Rpad = ((R + 255) & ~255) + 256;
     int* sOcc = reinterpret_cast<int*>(smem);
     int* myList = sOcc + Rpad + 64 * wid;
-    for (int j = tid; j < Rpad; j += SP_WAVES * 64) {
-        const XPos pj = xlist_pos(m, min(j, R - 1));
-        sOcc[j] = j < R ? ((const GAS int*)(xb + (long long)max(pj.q, 0) * xs))[pj.k] : -2;
-    }
-    __syncthreads();
-    const int k = blockIdx.x * SP_WAVES + wid;
-    if (k >= R) return;
-    const int item = sOcc[k];
-    if (item < 0) return;
-    const int kl = xlist_pos(m, k).k;             // local occurrence of k (position in its rank's X | Y | samples list)
+    // Occurrences are strided over the workgroups (wave w of workgroup b takes k = w * nblk + b), as in k_sparse_update: the owners
+    // of the popular items -- last occurrences, at the end of the list -- do not share a few workgroups.  The item of k comes straight
+    // from the exchanged list in memory; the list is staged in LDS only by workgroups in which some wave owns a REPEATED item (one
+    // barrier-or), so the common wave -- owner of a single occurrence -- makes two round trips (item; entry + rows) and stores.
+    const int k = wid * nblk_occ + bid;
+    const XPos pk = xlist_pos(m, min(k, R - 1));
+    const int item = k < R ? ((const GAS int*)(xb + (long long)max(pk.q, 0) * xs))[pk.k] : -1;
+    const int kl = pk.k;                          // local occurrence of k (position in its rank's X | Y | samples list)
     auto is_x = [&](int j) { return xlist_pos(m, j).k < B; };      // an input occurrence (table E when the tables are separate; no output bias)
     const float xscale = (m.xmode == 3) ? 1.0f / (float)xn : 1.0f;      // REDUCE form: gradients of the GLOBAL batch (cost / (xn * B))
     const bool constrained = (m.embed_mode == G4R_EMBED_CONSTRAINED);
     const bool tableE = (kl < B && !constrained);
-    GAS int* flp = m.occ_fl + 4 * ((tableE ? (size_t)m.n_items : 0) + item);
+    GAS int* flp = m.occ_fl + 4 * ((tableE ? (size_t)m.n_items : 0) + max(item, 0));
     const int4 fl = ldi4(flp);
-    if (fl.x != k + 1) return;               // not the last occurrence of the item
-    if (lane == 0) {
-        *(GAS int4*)flp = make_int4(0, 0, 0, 0);
-        if (m.touched) m.touched[(tableE ? (size_t)m.n_items : 0) + item] = 1;
-    }
     // occurrence range sharing a table with k: constrained -> everything; separate tables -> the X parts (table E) or the
     // Y | samples parts (table Wy) of all blocks: `same_table(j)` filters the scan below
     const int lo = (constrained || kl < B || xn > 1) ? 0 : B;
@@ -2568,21 +2562,36 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int q = 0; q < MAXCH; ++q) {
-        const size_t o = (size_t)item * W + 4 * min(lane + 64 * q, nc4 - 1);
+        const size_t o = (size_t)max(item, 0) * W + 4 * min(lane + 64 * q, nc4 - 1);      // (a wave without an occurrence reads row 0 and drops out below)
         p0[q] = ld4(P + o); a0[q] = ld4(A + o);
         u0[q] = A2 ? ld4(A2 + o) : z4; c0[q] = Cn ? ld4(Cn + o) : z4; w0[q] = mom ? ld4(V + o) : z4;
-        gk[q] = grow(k, q);
+        gk[q] = grow(min(k, R - 1), q);
         S[q] = z4; Q[q] = z4; T1[q] = z4;
     }
     float bp0 = 0.f, ba0 = 0.f, bu0 = 0.f, bc0 = 0.f, bw0 = 0.f, bgk = 0.f, bS = 0.f, bQ = 0.f, bT1 = 0.f;
     int lastb = bias_own ? k : -1;      // last bias occurrence of the item found so far
-    if (bias_maybe) {
-        bp0 = m.By[item]; ba0 = m.accBy[item]; bgk = bias_own ? bgrad(k) : 0.f;
-        if (m.acc2By) bu0 = m.acc2By[item];
-        if (m.cntBy) bc0 = m.cntBy[item];
-        if (mom) bw0 = m.velBy[item];
+    if (bias_own || (xn > 1 && constrained)) {      // (a superset of bias_maybe that does not wait for the entry)
+        const int it0 = max(item, 0);
+        bp0 = m.By[it0]; ba0 = m.accBy[it0]; bgk = bias_own ? bgrad(min(k, R - 1)) : 0.f;
+        if (m.acc2By) bu0 = m.acc2By[it0];
+        if (m.cntBy) bc0 = m.cntBy[it0];
+        if (mom) bw0 = m.velBy[it0];
     }
-    // earlier occurrences in [first, k), 64 per pass, 4 rows per round trip
+    // (the row state, the gradient row of k and the bias state above are in flight: requested together with the entry)
+    const bool owner = item >= 0 && fl.x == k + 1;      // the last occurrence of the item
+    if (__syncthreads_or((owner && fl.z > 1) ? 1 : 0)) {
+        for (int j = tid; j < Rpad; j += SP_WAVES * 64) {
+            const XPos pj = xlist_pos(m, min(j, R - 1));
+            sOcc[j] = j < R ? ((const GAS int*)(xb + (long long)max(pj.q, 0) * xs))[pj.k] : -2;
+        }
+        __syncthreads();
+    }
+    if (!owner) return;
+    if (lane == 0) {
+        *(GAS int4*)flp = make_int4(0, 0, 0, 0);
+        if (m.touched) m.touched[(tableE ? (size_t)m.n_items : 0) + item] = 1;
+    }
+    // earlier occurrences in [first, k), 64 per pass, NB rows per round trip
     int n = 1, nb = bias_own ? 1 : 0;
     // MEAN form of the exact-replica mode (sparse_exact = 2; what the GPU-local mode's reconciliation does, taken every step): the
     // item's parameter increment is the MEAN over the ranks that touch it of each rank's own increment (N full-size Adagrad steps
@@ -2637,16 +2646,19 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
                     bAadd += wave_sum(lastbias ? g * g : 0.f);
                 }
             }
-            for (int i0 = 0; i0 < cnt; i0 += 4) {
-                float4 g[4][MAXCH];
+            // NB gradient rows per round trip: the sampler repeats the head of the catalogue 20-50 x per step, and the owner walks
+            // its occurrences alone -- with 4 rows per trip the hottest item's 13 dependent trips set the launch's length
+            constexpr int NB = 4;      // (16 rows per trip at MAXCH = 1 cost 40 registers -> one workgroup per CU instead of two: the launch got slower)
+            for (int i0 = 0; i0 < cnt; i0 += NB) {
+                float4 g[NB][MAXCH];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < NB; ++u) {
                     const int jj = __builtin_amdgcn_readlane(myj, min(i0 + u, cnt - 1) & 63);
 #pragma unroll
                     for (int q = 0; q < MAXCH; ++q) g[u][q] = grow(jj, q);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < NB; ++u) {
                     if (i0 + u < cnt) {
                         const bool lr_u = __builtin_amdgcn_readlane(lastrow, min(i0 + u, cnt - 1) & 63) != 0;
 #pragma unroll
