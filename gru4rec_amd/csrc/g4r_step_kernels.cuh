@@ -2464,7 +2464,7 @@ __global__ __launch_bounds__(256) void k_exact_occ(const DevModel* __restrict__ 
 // statistics / velocity take the LAST occurrence -- hold over the concatenated list, i.e. ranks count as later occurrences in rank
 // order.  xn == 1 is the single-rank generic path.
 template <int MAXCH>
-__global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const DevModel* __restrict__ mp, StepState* st, int nblk_occ, int nda) {
+__global__ __launch_bounds__(SP_WAVES * 64, MAXCH == 1 ? 4 : 2) void k_sparse_update_generic(const DevModel* __restrict__ mp, StepState* st, int nblk_occ, int nda) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -2524,6 +2524,11 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
     GAS float *P = tableE ? m.E : m.Wy, *A = tableE ? m.accE : m.accWy, *A2 = tableE ? m.acc2E : m.acc2Wy,
               *Cn = tableE ? m.cntE : m.cntWy, *V = tableE ? m.velE : m.velWy;
     const int W = tableE ? m.Ein : m.Dtop, nc4 = W >> 2;
+    // Narrow rows (one quad per lane, nc4 <= 32): a row needs only LW = 16 / 32 lanes, so every load instruction of the repeated-item
+    // walk fetches RPI = 64 / LW occurrences, lane group `sub` taking occurrence i0 + u * RPI + sub; the groups' partial sums are
+    // combined with lane shuffles.  All row accesses use the lane's column `col`; the result is written by group 0 (col == lane).
+    const int LW = (MAXCH == 1) ? (nc4 <= 16 ? 16 : (nc4 <= 32 ? 32 : 64)) : 64;
+    const int RPI = 64 / LW, sub = lane / LW, col = lane & (LW - 1);
     // output bias (gru4rec.py:486-489: By is indexed by Y | samples only).  In one rank's list the X occurrences come first, so an
     // item whose LAST occurrence is an input has no bias occurrence at all; in a concatenated list (xn > 1) a later rank's input may
     // follow an earlier rank's target / negative: the owner then still updates the bias, from the bias occurrences the scan finds,
@@ -2537,14 +2542,14 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
     float4 p0[MAXCH], a0[MAXCH], u0[MAXCH], c0[MAXCH], w0[MAXCH], S[MAXCH], Q[MAXCH], T1[MAXCH], gk[MAXCH];
     auto sq = [](float4 x) { return make_float4(x.x * x.x, x.y * x.y, x.z * x.z, x.w * x.w); };
     auto add4 = [](float4& a, float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
-    auto ada = [](float4 g, float4 a) {      // g / sqrt(a + g^2 + eps), per component
-        return make_float4(g.x / sqrtf(a.x + g.x * g.x + G4R_EPS_ADAGRAD), g.y / sqrtf(a.y + g.y * g.y + G4R_EPS_ADAGRAD),
-                           g.z / sqrtf(a.z + g.z * g.z + G4R_EPS_ADAGRAD), g.w / sqrtf(a.w + g.w * g.w + G4R_EPS_ADAGRAD));
+    auto ada = [](float4 g, float4 a) {      // g / sqrt(a + g^2 + eps), per component (v_rsq_f32, ~1 ulp, as in the Adagrad producers)
+        return make_float4(g.x * frsq(a.x + g.x * g.x + G4R_EPS_ADAGRAD), g.y * frsq(a.y + g.y * g.y + G4R_EPS_ADAGRAD),
+                           g.z * frsq(a.z + g.z * g.z + G4R_EPS_ADAGRAD), g.w * frsq(a.w + g.w * g.w + G4R_EPS_ADAGRAD));
     };
     const float gsc = clip * xscale;
     auto grow = [&](int j, int q) {          // clipped gradient row chunk of occurrence j (of the exchanged list)
         const XPos pj = xlist_pos(m, j);
-        const int jl = pj.k, c = 4 * min(lane + 64 * q, nc4 - 1);
+        const int jl = pj.k, c = 4 * min(col + 64 * q, nc4 - 1);
         const size_t ro = (jl < B) ? (size_t)oSx + (size_t)jl * W : (size_t)oSy + (size_t)(jl - B) * W;
         float4 g = ld4(xb + (long long)max(pj.q, 0) * xs + ro + c);
         if (pj.q < 0)                          // REDUCE form, a shared negative: the sum over the ranks' rows of this column, in rank order
@@ -2562,7 +2567,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int q = 0; q < MAXCH; ++q) {
-        const size_t o = (size_t)max(item, 0) * W + 4 * min(lane + 64 * q, nc4 - 1);      // (a wave without an occurrence reads row 0 and drops out below)
+        const size_t o = (size_t)max(item, 0) * W + 4 * min(col + 64 * q, nc4 - 1);      // (a wave without an occurrence reads row 0 and drops out below)
         p0[q] = ld4(P + o); a0[q] = ld4(A + o);
         u0[q] = A2 ? ld4(A2 + o) : z4; c0[q] = Cn ? ld4(Cn + o) : z4; w0[q] = mom ? ld4(V + o) : z4;
         gk[q] = grow(min(k, R - 1), q);
@@ -2608,13 +2613,35 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
     if (fl.z > 1) {
         for (int pass = 0;; ++pass) {
             int idx = 0;
-            for (int base = first_j & ~63; base < k; base += 64) {
-                const int j = base + lane;
-                const bool hit = j >= first_j && j < k && sOcc[j] == item && same_table(j);
-                const unsigned long long mask = __ballot(hit);
-                const int ord = idx - 64 * pass + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                if (hit && ord >= 0 && ord < 64) myList[ord] = j;
-                idx += __popcll(mask);
+            // 256 list entries per step (one 16-byte LDS read per lane; reads past the list stay inside Rpad and never match); the
+            // table filter -- an integer division per entry -- only where the tables are separate
+            for (int base = first_j & ~255; base < k; base += 256) {
+                const int4 v = *reinterpret_cast<const int4*>(sOcc + base + 4 * lane);
+                const int j = base + 4 * lane;
+                bool hh[4] = {v.x == item && j >= first_j && j < k, v.y == item && j + 1 >= first_j && j + 1 < k,
+                              v.z == item && j + 2 >= first_j && j + 2 < k, v.w == item && j + 3 >= first_j && j + 3 < k};
+                if (__ballot(hh[0] || hh[1] || hh[2] || hh[3]) == 0) continue;
+                if (!constrained) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hh[e] = hh[e] && same_table(j + e);
+                }
+                // ascending occurrence order = lane-major: all matches of lower lanes first, then this lane's earlier entries
+                int below = 0, total = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned long long mk = __ballot(hh[e]);
+                    below += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                    total += __popcll(mk);
+                }
+                int ord = idx - 64 * pass + below;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (hh[e]) {
+                        if (ord >= 0 && ord < 64) myList[ord] = j + e;
+                        ++ord;
+                    }
+                }
+                idx += total;
             }
             const int cnt = min(idx - 64 * pass, 64);
             const int myj = lane < cnt ? myList[lane] : -1;
@@ -2649,18 +2676,19 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
             // NB gradient rows per round trip: the sampler repeats the head of the catalogue 20-50 x per step, and the owner walks
             // its occurrences alone -- with 4 rows per trip the hottest item's 13 dependent trips set the launch's length
             constexpr int NB = 4;      // (16 rows per trip at MAXCH = 1 cost 40 registers -> one workgroup per CU instead of two: the launch got slower)
-            for (int i0 = 0; i0 < cnt; i0 += NB) {
+            for (int i0 = 0; i0 < cnt; i0 += NB * RPI) {
                 float4 g[NB][MAXCH];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    const int jj = __builtin_amdgcn_readlane(myj, min(i0 + u, cnt - 1) & 63);
+                    const int jj = __shfl(myj, min(i0 + u * RPI + sub, cnt - 1) & 63);
 #pragma unroll
                     for (int q = 0; q < MAXCH; ++q) g[u][q] = grow(jj, q);
                 }
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    if (i0 + u < cnt) {
-                        const bool lr_u = __builtin_amdgcn_readlane(lastrow, min(i0 + u, cnt - 1) & 63) != 0;
+                    const int ri = i0 + u * RPI + sub;
+                    const bool lr_u = __shfl(lastrow, min(ri, cnt - 1) & 63) != 0;
+                    if (ri < cnt) {
 #pragma unroll
                         for (int q = 0; q < MAXCH; ++q) {
                             add4(S[q], g[u][q]); add4(Q[q], sq(g[u][q]));
@@ -2672,6 +2700,16 @@ __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_update_generic(const D
             }
             n += cnt;
             if (idx <= 64 * (pass + 1)) break;
+        }
+    }
+    if constexpr (MAXCH == 1) {
+        if (RPI > 1 && fl.z > 1) {      // the lane groups' partial sums -> every lane (group 0 writes the row)
+            auto comb = [&](float4& v) {
+                for (int off = LW; off < 64; off <<= 1) {
+                    v.x += __shfl_xor(v.x, off); v.y += __shfl_xor(v.y, off); v.z += __shfl_xor(v.z, off); v.w += __shfl_xor(v.w, off);
+                }
+            };
+            comb(S[0]); comb(Q[0]); comb(T1[0]); comb(Aadd[0]);
         }
     }
 #pragma unroll
