@@ -447,12 +447,18 @@ def main():
                             'note': 'a %d KB all-reduce is latency bound (2 x 7 ring hops or one LL round); the one-rank collective inside the measured '
                                     'step already costs its launch' % (dense_bytes // 1024)}}
         if args.sparse_exact:
-            blk = (R * D + R + cfg['batch_size'] * 2) * 4
-            proj['assumed']['allgather_occurrence_blocks_8_ranks_us'] = [20.0, 40.0]
-            proj['assumed']['allgather_bytes_received_per_rank'] = 7 * blk
-            lo = step_us + 10.0 + 20.0
-            hi = step_us + 20.0 + 40.0
-            proj['mode'] = 'exact replicas (REDUCE form)'
+            # ONE collective per step: the all-gather of the ranks' blocks (occurrence list, gradient rows, bias gradients, raw dense
+            # gradients); every rank receives 7 blocks over its 7 xGMI links
+            blk = (R * D + 2 * R) * 4 + dense_bytes
+            rates = [100.0, 50.0]      # GB/s per link actually sustained by a message of this size (peak 153)
+            ag = [blk / (r * 1e3) + 5.0 for r in rates]      # each link carries one block; + launch / handshake
+            proj['assumed'] = {'allgather_block_bytes_per_rank': blk, 'allgather_bytes_received_per_rank': 7 * blk,
+                               'per_link_GBps': rates, 'allgather_8_ranks_us': ag,
+                               'note': 'no separate all-reduce in this mode: the dense gradients ride in the block and every rank sums the eight copies itself; '
+                                       'the one-rank all-gather inside the measured step already costs its launch'}
+            lo = step_us + ag[0]
+            hi = step_us + ag[1]
+            proj['mode'] = 'exact replicas (REDUCE form), one all-gather per step'
         else:
             per_call_ms = reconcile.get('ms_per_reconciliation') if reconcile and 'error' not in reconcile else None
             K = reconcile.get('sync_every') if reconcile and 'error' not in reconcile else None

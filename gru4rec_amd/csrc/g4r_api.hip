@@ -361,7 +361,10 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         d.xoffSx = (int)nOcc;
         d.xoffSy = (int)(nOcc + up64((size_t)B * d.Ein));
         d.xoffSBy = (int)(d.xoffSy + up64((size_t)d.ldSc * d.Dtop));
-        d.xstride = (long long)(d.xoffSBy + up64((size_t)d.ldSc));
+        // exact-replica mode: the rank's raw dense gradients ride in the same block (ONE collective per step: the all-gather
+        // replaces the all-reduce, every rank adds the ranks' gradients up itself, in rank order -- dense_apply_elem)
+        d.xoffDg = (int)(d.xoffSBy + up64((size_t)d.ldSc));
+        d.xstride = (long long)(d.xoffDg + (exact ? up64((size_t)d.dense_count) : 0));
         d.xn = exact ? cfg->nranks : 1;
         d.xmode = exact ? std::min(std::max(cfg->sparse_exact, 1), 3) : 0;
         float* xb = nullptr;
@@ -369,6 +372,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         d.xbase = xb;
         float* own = xb + (size_t)(exact ? cfg->rank : 0) * (size_t)d.xstride;
         d.occ_idx = (int*)own; d.dSx = own + d.xoffSx; d.dSy = own + d.xoffSy; d.dSBy = own + d.xoffSBy;
+        if (exact) d.dense_g = own + d.xoffDg;      // (the buffer allocated above stays unused)
     }
     DA(d.dAx, (size_t)B * d.Ein); DA(d.dAy, (size_t)d.ldSc * d.Dtop); DA(d.dABy, d.ldSc);
     DA(d.lossrow, B);
@@ -944,7 +948,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         const bool dist = !m->virtual_ranks && (m->cfg.nranks > 1 || m->comm_ready || m->p2p_ready);
         if (m->cfg.nranks > 1 && !m->comm_ready && !m->p2p_ready && !m->virtual_ranks) return fail("nranks > 1 but g4r_comm_init was not called");
         hipStream_t cs = overlap ? m->comm_stream : s;
-        if (dist) {
+        if (dist && !m->exact) {      // (exact-replica mode: the dense gradients travel with the all-gather of the occurrence blocks below)
             if (overlap) { HIPCHK(hipEventRecord(m->ev_fork, s)); HIPCHK(hipStreamWaitEvent(cs, m->ev_fork, 0)); }
             if (!overlap) { begin(KN_ALLREDUCE); if (recs) (void)hipEventRecord(cur_a, cs); }
             if (m->p2p_ready) hipLaunchKernelGGL(k_p2p_allreduce, dim3(m->p2p_nblk), dim3(256), 0, cs, m->p2p_args, (float*)d.dense_g);
@@ -1222,9 +1226,11 @@ int g4r_virtual_train_steps(g4r_model* const* ms, int32_t n, int64_t t0, int64_t
             // (the next step's kernels of handle p rewrite p's block: every copy out of it must have run before p's tail is queued)
             for (int q = 0; q < n; ++q) HIPCHK(hipStreamSynchronize(ms[q]->stream));
         }
-        hipLaunchKernelGGL(k_virtual_sum, dim3(cdiv(cnt, 256)), dim3(256), 0, m0->stream, va, n, cnt, m0->d_vsum);
-        hipLaunchKernelGGL(k_virtual_bcast, dim3(cdiv(cnt, 256)), dim3(256), 0, m0->stream, va, n, cnt, (const float*)m0->d_vsum);
-        HIPCHK(hipStreamSynchronize(m0->stream));
+        if (!m0->exact) {      // (exact-replica mode: the blocks carry the dense gradients, every handle sums them itself)
+            hipLaunchKernelGGL(k_virtual_sum, dim3(cdiv(cnt, 256)), dim3(256), 0, m0->stream, va, n, cnt, m0->d_vsum);
+            hipLaunchKernelGGL(k_virtual_bcast, dim3(cdiv(cnt, 256)), dim3(256), 0, m0->stream, va, n, cnt, (const float*)m0->d_vsum);
+            HIPCHK(hipStreamSynchronize(m0->stream));
+        }
         for (int q = 0; q < n; ++q) {
             if (launch_step(ms[q], nullptr, 2)) return -1;
             ms[q]->gstep += 1;

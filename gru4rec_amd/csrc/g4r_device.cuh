@@ -158,7 +158,7 @@ struct DevModel {
     GP(float) xbase;
     long long xstride;
     int xn, xoffSx, xoffSy, xoffSBy;      // float offsets of dSx / dSy / dSBy inside a block (occ_idx sits at offset 0, as ints)
-    int xmode, xpad;                      // g4r_config::sparse_exact when xn > 1 (1 SUM, 2 MEAN, 3 REDUCE form of the exact-replica mode), else 0
+    int xmode, xoffDg;                      // g4r_config::sparse_exact when xn > 1 (1 SUM, 2 MEAN, 3 REDUCE form of the exact-replica mode), else 0
 };
 
 // In-kernel phase traces (tools/clk*.py) exist only in builds made with G4R_BUILD_CLK=1 (-DG4R_CLK_TRACE): a test of a

@@ -1968,7 +1968,11 @@ __global__ __launch_bounds__(64) void k_grad_clip(const DevModel* __restrict__ m
 // after the RCCL all-reduce: element-wise dense rule on the averaged gradient (element i of the flat dense buffers)
 __device__ __forceinline__ void dense_apply_elem(const DevModel& m, int i) {
     if (!m.generic) { dense_adagrad(m, (size_t)i, m.dense_g[i] * m.grad_scale); return; }
-    const float g = m.dense_g[i] * m.grad_scale * m.gclip[0];
+    float gs = 0.f;
+    if (m.xmode != 0) {      // exact-replica mode: the ranks' raw gradients out of the all-gathered blocks, in rank order
+        for (int q = 0; q < m.xn; ++q) gs += (m.xbase + (long long)q * m.xstride)[m.xoffDg + i];
+    } else gs = m.dense_g[i];
+    const float g = gs * m.grad_scale * m.gclip[0];
     const float a0 = m.dense_acc[i], u0 = m.dense_acc2 ? m.dense_acc2[i] : 0.f, c0 = m.dense_cnt ? m.dense_cnt[i] : 0.f;
     const OptOut o = opt_rule(m.adapt, m.ap0, m.ap1, true, a0, u0, c0, g, g * g, g / sqrtf(a0 + g * g + G4R_EPS_ADAGRAD), g, 1.f);
     m.dense_acc[i] = o.A;
