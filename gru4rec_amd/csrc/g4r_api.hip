@@ -526,8 +526,10 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_store, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+#define G4R_LOSS_ATTR(L, S) HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<L, S>, hipFuncAttributeMaxDynamicSharedMemorySize, big))
+    G4R_LOSS_ATTR(false, 0); G4R_LOSS_ATTR(false, 1); G4R_LOSS_ATTR(false, 2); G4R_LOSS_ATTR(false, 3);
+    G4R_LOSS_ATTR(true, 0); G4R_LOSS_ATTR(true, 1); G4R_LOSS_ATTR(true, 2); G4R_LOSS_ATTR(true, 3);
+#undef G4R_LOSS_ATTR
     if (m->smem_loss > (size_t)big) { g4r_destroy(m); return fail("batch_size + n_sample too large for the row-loss kernel (one copy of a score row must fit the 160 KB of LDS)"); }
     if (m->smem_sparse > (size_t)big) { g4r_destroy(m); return fail("2 * batch_size + n_sample too large for the sparse update (the step's list of gathered rows must fit the 160 KB of LDS)"); }
     if (m->exact) {
@@ -872,8 +874,23 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     else LK(k_score_fwd_k128, dim3(cdiv(d.ldSc, GT_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF, s, dmp, stp);
     end();
     begin(KN_LOSS);
-    if (m->loss_long) LK(k_loss_rows<true>, dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
-    else LK(k_loss_rows<false>, dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);
+    {
+        // the (final activation, loss) pairs of BASELINE's configurations run compile-time specialised builds of the kernel
+        static const bool nospec = getenv("G4R_LOSS_GENERIC") != nullptr;
+        const int spec = nospec ? 0
+                       : (d.final_act == G4R_ACT_ELU && d.loss == G4R_LOSS_BPR_MAX) ? 1
+                       : (d.final_act == G4R_ACT_SOFTMAX && d.loss == G4R_LOSS_XE) ? 2
+                       : (d.final_act == G4R_ACT_ELU && d.loss == G4R_LOSS_TOP1_MAX) ? 3 : 0;
+#define G4R_LK_LOSS(L)                                                                              \
+        do {                                                                                        \
+            if (spec == 1) LK((k_loss_rows<L, 1>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);      \
+            else if (spec == 2) LK((k_loss_rows<L, 2>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp); \
+            else if (spec == 3) LK((k_loss_rows<L, 3>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp); \
+            else LK((k_loss_rows<L, 0>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);                \
+        } while (0)
+        if (m->loss_long) G4R_LK_LOSS(true); else G4R_LK_LOSS(false);
+#undef G4R_LK_LOSS
+    }
     end();
     begin(KN_SCORE_BWD);
     if (score_bwd2(d)) {

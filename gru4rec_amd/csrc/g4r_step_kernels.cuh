@@ -886,13 +886,18 @@ __device__ __forceinline__ float softplusf_(float x) {      // log(1 + e^x), sta
 
 // LONG_ROW (score rows whose two copies do not fit the LDS, > ~19 K columns): `se` lives in the row's own memory instead -- a thread
 // has read its columns' scores before it writes anything there, and only ever revisits its own columns.
-template <bool LONG_ROW>
+// SPEC: the (final activation, loss) pair as a compile-time constant for the pairs BASELINE's configurations use -- 1 elu + bpr-max,
+// 2 softmax + cross-entropy, 3 elu + top1-max; 0 = any pair, read from the descriptor.  The element loops below switch on both for
+// every element (eight scalar branches per element and pass in the generic build); with constants the switches fold away.
+template <bool LONG_ROW, int SPEC>
 __global__ __launch_bounds__(LOSS_T) void k_loss_rows(const DevModel* __restrict__ mp, StepState* st) {
     const DevModel& m = *mp;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int B = m.B, N = m.N, i = blockIdx.x;
-    const int fact = m.final_act, lossk = m.loss, ldSc = m.ldSc;    // snapshot: used inside the loops below
+    const int fact = SPEC == 1 || SPEC == 3 ? (int)G4R_ACT_ELU : (SPEC == 2 ? (int)G4R_ACT_SOFTMAX : m.final_act);
+    const int lossk = SPEC == 1 ? (int)G4R_LOSS_BPR_MAX : (SPEC == 2 ? (int)G4R_LOSS_XE : (SPEC == 3 ? (int)G4R_LOSS_TOP1_MAX : m.loss));
+    const int ldSc = m.ldSc;
     const float fp0 = m.fa_p0, fp1 = m.fa_p1, invB = m.inv_B, bpreg = m.bpreg, smooth = m.smoothing;
     GAS float* row = m.Sc + (size_t)i * ldSc;
     float* sy = smem;                  // [ldSc] yhat
