@@ -306,7 +306,9 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     m->exact = exact;
     d.generic = (cfg->adapt != G4R_ADAPT_ADAGRAD || cfg->grad_cap > 0.f || exact) ? 1 : 0;
     d.drop_h = cfg->dropout_p_hidden; d.drop_e = cfg->dropout_p_embed;
-    d.seed = cfg->seed;
+    // dropout masks are keyed by (seed, step, row, column) with LOCAL rows: in exact-replica mode the ranks share cfg->seed (ONE stream of
+    // negatives: refill_store), so the masks take a rank-specific key -- the nranks x B rows of the joint batch must not repeat one pattern
+    d.seed = cfg->seed + ((cfg->sparse_exact != 0 && cfg->nranks > 1) ? 7919ull * (unsigned long long)cfg->rank : 0ull);
     d.Dtop = cfg->layers[L - 1];
     // width of the layer-0 input rows: shared Wy rows, E rows, or (one-hot input) rows of Wx[0] = [cand|r|z] pre-activations
     d.Ein = (cfg->embed_mode == G4R_EMBED_CONSTRAINED) ? d.Dtop : (cfg->embed_mode == G4R_EMBED_ONEHOT ? 3 * cfg->layers[0] : cfg->embedding);
@@ -633,7 +635,7 @@ static int refill_store(g4r_model* m) {
     const long long n = (long long)m->gl * m->dm.ns;
     const int blocks = cdiv(cdiv(n, 4), 256);
     hipLaunchKernelGGL(k_sample_refill, dim3(blocks), dim3(256), 0, m->stream, m->d_ST, n, m->d_P, m->dm.n_items,
-                       m->dm.seed, m->refills);
+                       (unsigned long long)m->cfg.seed, m->refills);
     m->refills++;
     HIPCHK(hipGetLastError());
     return 0;

@@ -25,11 +25,14 @@ from test_gpu_parity import compare_params, make_pair, random_plan, report, clos
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('case', ['bprmax_constrained', 'xe_separate_momentum'])
+@pytest.mark.parametrize('case', ['bprmax_constrained', 'xe_separate_momentum', 'bprmax_dropout'])
 def test_exact_mode_against_the_oracle_run_as_replicas(case):
     kw = dict(bprmax_constrained=dict(layers=(16,), loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, learning_rate=0.1, bpreg=1.0),
               xe_separate_momentum=dict(layers=(12,), loss='cross-entropy', final_act='softmax', constrained_embedding=False, embedding=8,
-                                        learning_rate=0.05, momentum=0.2, logq=1.0))[case]
+                                        learning_rate=0.05, momentum=0.2, logq=1.0),
+              # dropout: the ranks share the seed of the negatives, their masks are keyed by seed + 7919 * rank (rows of ONE joint batch)
+              bprmax_dropout=dict(layers=(16,), loss='bpr-max', final_act='linear', constrained_embedding=True, learning_rate=0.1, bpreg=1.0,
+                                  dropout_p_hidden=0.3, dropout_p_embed=0.2))[case]
     N, I, B, ns, T = 3, 40, 8, 16, 8      # 40 items, 3 x 32 occurrences per step: every step has items several ranks touch
     pairs = [make_pair(I, B, ns, store_rows=T, seed=3, rank=r, nranks=N, sparse_exact=1, **dict(kw)) for r in range(N)]      # 1 = the SUM form: what the oracle's concatenated lists compute
     plans = [random_plan(I, B, T, seed=100 + r) for r in range(N)]
@@ -37,6 +40,7 @@ def test_exact_mode_against_the_oracle_run_as_replicas(case):
     for r, (o, m) in enumerate(pairs):
         o.ST = rng.randint(0, I, size=(T, ns)).astype(np.int64)      # every rank its own negatives
         o.generate_length = T
+        o.seed = 3 + 7919 * r      # (the oracle keys its dropout masks by its seed; its negatives are injected)
         m.set_sample_store(o.ST.astype(np.int32))
         m.set_plan(plans[r])
     oracles, models = [p[0] for p in pairs], [p[1] for p in pairs]
