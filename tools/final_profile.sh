@@ -33,6 +33,7 @@ for c in $CFGS; do
   cp /tmp/out_s/*/*kernel_stats.csv $OUT/${TAG}_kernel_stats_rocprofv3_$c.csv 2>/dev/null
   echo "== $c"; head -12 $OUT/${TAG}_kernel_stats_rocprofv3_$c.csv
 done
+[ -n "$STATS_ONLY" ] && exit 0      # STATS_ONLY=1: bench lines + rocprofv3 kernel statistics, no counter passes
 for c in $CFGS; do
   for nm in merged split; do
     rm -rf /tmp/out_f /tmp/out_w
