@@ -136,6 +136,9 @@ struct g4r_model {
     unsigned char* d_rowcnt = nullptr;           // [n_items] scratch: number of parts that hold a row (MEAN rule)
     int sync_every_dev = 0;                      // > 0: g4r_train_steps reconciles the (dense-form) item tables itself every that many steps
     int64_t since_sync = 0, n_dev_syncs = 0;
+    // scratch of the packed-parts reconciliation, kept between calls (a call used to pay five hipMalloc / hipFree pairs)
+    struct Scratch { void* p = nullptr; size_t cap = 0; bool host = false; };
+    Scratch sc_ids, sc_blk, sc_cnt, sc_all, sc_send, sc_pack, sc_recv, sc_hall;      // sc_hall: pinned host copy of the gathered id lists
     float* d_dense[2] = {nullptr, nullptr};      // dense reconciliation buffers [n_items][sum of plane widths + 1] per table group (small catalogues)
     bool sync_on = false;
 };
@@ -563,6 +566,10 @@ void g4r_destroy(g4r_model* m) {
     for (void* q : m->p2p_peer) if (q) (void)hipIpcCloseMemHandle(q);
     if (m->p2p_region) (void)hipFree(m->p2p_region);
     for (auto e : m->evs) (void)hipEventDestroy(e);
+    for (g4r_model::Scratch* sc : {&m->sc_ids, &m->sc_blk, &m->sc_cnt, &m->sc_all, &m->sc_send, &m->sc_pack, &m->sc_recv, &m->sc_hall}) {
+        if (sc->p) { if (sc->host) (void)hipHostFree(sc->p); else (void)hipFree(sc->p); }
+        sc->p = nullptr; sc->cap = 0;
+    }
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
@@ -1785,13 +1792,45 @@ int g4r_sync_enable(g4r_model* m) {
 }
 
 // sorted ids of the rows of `group` this rank rewrote since the last reconciliation
+// grow-only scratch (device, or pinned host memory): 0 / -1
+static int scratch_ensure(g4r_model::Scratch& sc, size_t bytes, bool host = false) {
+    if (bytes == 0) bytes = 16;
+    if (sc.p && sc.cap >= bytes) return 0;
+    if (sc.p) { if (sc.host) (void)hipHostFree(sc.p); else (void)hipFree(sc.p); sc.p = nullptr; sc.cap = 0; }
+    const size_t want = bytes + bytes / 4;      // headroom: the touched set grows and shrinks from call to call
+    sc.host = host;
+    if (host) HIPCHK(hipHostMalloc(&sc.p, want, hipHostMallocDefault));
+    else HIPCHK(hipMalloc(&sc.p, want));
+    sc.cap = want;
+    return 0;
+}
+// the rows this rank rewrote since the last reconciliation, as a sorted id list ON THE DEVICE (m->sc_ids): the touched bitmap is
+// compacted there (k_touched_count / _scan / _write); only the count comes back
+static int sync_local_ids_dev(g4r_model* m, int group, long long* n_out) {
+    const long long I = m->dm.n_items;
+    const int nb = (int)cdiv(I, TC_CHUNK);
+    hipStream_t s = m->stream;
+    if (scratch_ensure(m->sc_blk, (size_t)(2 * nb + 2) * sizeof(int))) return -1;
+    int* d_blk = (int*)m->sc_blk.p;
+    int* d_off = d_blk + nb;
+    const unsigned char* t = m->d_touched + (size_t)group * I;
+    hipLaunchKernelGGL(k_touched_count, dim3(nb), dim3(256), 0, s, t, I, d_blk);
+    hipLaunchKernelGGL(k_touched_scan, dim3(1), dim3(1024), 0, s, (const int*)d_blk, nb, d_off);
+    int total = 0;
+    HIPCHK(hipMemcpyAsync(&total, d_off + nb, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (scratch_ensure(m->sc_ids, (size_t)std::max(total, 1) * sizeof(int))) return -1;
+    if (total > 0) hipLaunchKernelGGL(k_touched_write, dim3(nb), dim3(256), 0, s, t, I, (const int*)d_off, (int*)m->sc_ids.p);
+    HIPCHK(hipGetLastError());
+    *n_out = total;
+    return 0;
+}
 static int sync_local_ids(g4r_model* m, int group, std::vector<int>& ids) {
-    const size_t I = m->dm.n_items;
-    std::vector<unsigned char> t(I);
+    long long n = 0;
+    if (sync_local_ids_dev(m, group, &n)) return -1;
+    ids.resize((size_t)n);
+    if (n > 0) HIPCHK(hipMemcpyAsync(ids.data(), m->sc_ids.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
-    HIPCHK(hipMemcpy(t.data(), m->d_touched + (size_t)group * I, I, hipMemcpyDeviceToHost));
-    ids.clear();
-    for (size_t i = 0; i < I; ++i) if (t[i]) ids.push_back((int)i);
     return 0;
 }
 int64_t g4r_sync_row_floats(g4r_model* m, int32_t group) {
@@ -2007,44 +2046,36 @@ int g4r_comm_sync_sparse(g4r_model* m) {
             sync_dense_apply(m, group);
             continue;
         }
-        std::vector<int> loc;
-        if (sync_local_ids(m, group, loc)) return -1;
+        long long mine = 0;
+        if (sync_local_ids_dev(m, group, &mine)) return -1;      // sorted ids of this rank's rows in m->sc_ids (device)
         // counts
         std::vector<long long> cnt(nr, 0);
-        long long* d_cnt = nullptr;
-        HIPCHK(hipMalloc((void**)&d_cnt, (size_t)(nr + 1) * sizeof(long long)));
-        long long mine = (long long)loc.size();
+        if (scratch_ensure(m->sc_cnt, (size_t)(nr + 1) * sizeof(long long))) return -1;
+        long long* d_cnt = (long long*)m->sc_cnt.p;
         HIPCHK(hipMemcpyAsync(d_cnt + nr, &mine, sizeof(long long), hipMemcpyHostToDevice, s));
         ncclResult_t r = ncclAllGather(d_cnt + nr, d_cnt, 1, ncclInt64, m->comm, s);
-        if (r != ncclSuccess) { (void)hipFree(d_cnt); return fail(std::string("ncclAllGather: ") + ncclGetErrorString(r)); }
+        if (r != ncclSuccess) return fail(std::string("ncclAllGather: ") + ncclGetErrorString(r));
         HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)nr * sizeof(long long), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        (void)hipFree(d_cnt);
         const long long maxn = *std::max_element(cnt.begin(), cnt.end());
         if (maxn == 0) continue;
-        // id lists: [nr][maxn], padded with INT_MAX so that every list stays sorted
-        int *d_all = nullptr, *d_send = nullptr;
-        HIPCHK(hipMalloc((void**)&d_all, (size_t)nr * maxn * sizeof(int)));
-        HIPCHK(hipMalloc((void**)&d_send, (size_t)maxn * sizeof(int)));
-        std::vector<int> pad(maxn, 0x7fffffff);
-        std::copy(loc.begin(), loc.end(), pad.begin());
-        HIPCHK(hipMemcpyAsync(d_send, pad.data(), (size_t)maxn * sizeof(int), hipMemcpyHostToDevice, s));
+        // id lists: [nr][maxn], padded with INT_MAX so that every list stays sorted; the host keeps a (pinned) copy for the range walk
+        if (scratch_ensure(m->sc_all, (size_t)nr * maxn * sizeof(int)) || scratch_ensure(m->sc_send, (size_t)maxn * sizeof(int)) ||
+            scratch_ensure(m->sc_hall, (size_t)nr * maxn * sizeof(int), true)) return -1;
+        int *d_all = (int*)m->sc_all.p, *d_send = (int*)m->sc_send.p;
+        if (mine < maxn) hipLaunchKernelGGL(k_fill_i32, dim3(nblk256(maxn - mine)), dim3(256), 0, s, d_send + mine, maxn - mine, 0x7fffffff);
+        if (mine > 0) HIPCHK(hipMemcpyAsync(d_send, m->sc_ids.p, (size_t)mine * sizeof(int), hipMemcpyDeviceToDevice, s));
         r = ncclAllGather(d_send, d_all, (size_t)maxn, ncclInt32, m->comm, s);
-        std::vector<int> all((size_t)nr * maxn);
-        if (r == ncclSuccess && hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess &&
-            hipStreamSynchronize(s) == hipSuccess) {
-        } else { (void)hipFree(d_all); (void)hipFree(d_send); return fail("id list all-gather failed"); }
-        (void)hipFree(d_send);
+        const int* all = (const int*)m->sc_hall.p;
+        if (r != ncclSuccess || hipMemcpyAsync(m->sc_hall.p, d_all, (size_t)nr * maxn * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) return fail("id list all-gather failed");
         int wmax = 1;
         for (auto& pl : m->planes[group]) wmax = std::max(wmax, pl.W);
         // item-id ranges: at most `cap` rows per rank and range (bounds the scratch: nr * cap * wmax floats <= ~1 GiB)
         const long long cap = std::max<long long>(1024, (1LL << 28) / ((long long)nr * wmax));
-        float *d_pack = nullptr, *d_recv = nullptr;
         const long long rows_cap = std::min<long long>(cap, maxn);
-        if (hipMalloc((void**)&d_pack, (size_t)rows_cap * wmax * sizeof(float)) != hipSuccess ||
-            hipMalloc((void**)&d_recv, (size_t)nr * rows_cap * wmax * sizeof(float)) != hipSuccess) {
-            (void)hipFree(d_all); (void)hipFree(d_pack); return fail("sync scratch");
-        }
+        if (scratch_ensure(m->sc_pack, (size_t)rows_cap * wmax * sizeof(float)) || scratch_ensure(m->sc_recv, (size_t)nr * rows_cap * wmax * sizeof(float))) return -1;
+        float *d_pack = (float*)m->sc_pack.p, *d_recv = (float*)m->sc_recv.p;
         std::vector<long long> lo(nr, 0), hi(nr, 0), c(nr);
         std::vector<const int*> pid(nr);
         std::vector<const float*> pdl(nr);
@@ -2056,7 +2087,7 @@ int g4r_comm_sync_sparse(g4r_model* m) {
                 if (lo[q] + cap < cnt[q]) i1 = std::min<long long>(i1, all[(size_t)q * maxn + lo[q] + cap]);
             long long cmax = 0;
             for (int q = 0; q < nr; ++q) {
-                const int* b = all.data() + (size_t)q * maxn;
+                const int* b = all + (size_t)q * maxn;
                 hi[q] = std::lower_bound(b + lo[q], b + cnt[q], (int)std::min<long long>(i1, 0x7fffffffLL)) - b;
                 if (i1 >= (long long)I) hi[q] = cnt[q];
                 c[q] = hi[q] - lo[q];
@@ -2079,7 +2110,6 @@ int g4r_comm_sync_sparse(g4r_model* m) {
             for (int q = 0; q < nr; ++q) lo[q] = hi[q];
             i0 = i1;
         }
-        (void)hipFree(d_all); (void)hipFree(d_pack); (void)hipFree(d_recv);
         if (!ok || hipGetLastError() != hipSuccess) return fail("sparse reconciliation failed");
         HIPCHK(hipMemsetAsync(m->d_touched + (size_t)group * I, 0, I, s));
     }

@@ -55,6 +55,70 @@ __global__ __launch_bounds__(256) void k_sync_rebase(const float* cur, float* ba
     base[o] = cur[o];
 }
 
+// ---- the touched bitmap -> a sorted id list, on the device (round 4: the 10 M-item bitmap used to be copied to the host and walked
+// there, 5-8 ms of a 10.7 ms reconciliation at the configs[3] shape).  TC_CHUNK bytes per workgroup: count, exclusive scan of the
+// workgroup counts (one workgroup, running carry), then every workgroup writes its ids behind its offset, in item order.
+#define TC_PER_THREAD 16
+#define TC_CHUNK (256 * TC_PER_THREAD)
+__global__ __launch_bounds__(256) void k_touched_count(const unsigned char* t, long long I, int* blockcnt) {
+    __shared__ int red[4];
+    const long long i0 = (long long)blockIdx.x * TC_CHUNK + (long long)threadIdx.x * TC_PER_THREAD;
+    int c = 0;
+#pragma unroll
+    for (int e = 0; e < TC_PER_THREAD; ++e) c += (i0 + e < I && t[i0 + e]) ? 1 : 0;
+    c = (int)wave_sum((float)c);      // (<= 1024 per wave: exact in fp32)
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// offsets[b] = sum of blockcnt[0 .. b), offsets[nb] = total
+__global__ __launch_bounds__(1024) void k_touched_scan(const int* blockcnt, int nb, int* offsets) {
+    __shared__ int part[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        const int v = b < nb ? blockcnt[b] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {      // inclusive scan (Hillis-Steele)
+            const int add = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (b < nb) offsets[b] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[nb] = carry;
+}
+__global__ __launch_bounds__(256) void k_touched_write(const unsigned char* t, long long I, const int* offsets, int* ids) {
+    __shared__ int pre[256];
+    const long long i0 = (long long)blockIdx.x * TC_CHUNK + (long long)threadIdx.x * TC_PER_THREAD;
+    unsigned bits = 0;
+#pragma unroll
+    for (int e = 0; e < TC_PER_THREAD; ++e) bits |= (i0 + e < I && t[i0 + e]) ? (1u << e) : 0u;
+    const int c = __popc(bits);
+    pre[threadIdx.x] = c;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int add = threadIdx.x >= d ? pre[threadIdx.x - d] : 0;
+        __syncthreads();
+        pre[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int o = offsets[blockIdx.x] + pre[threadIdx.x] - c;
+#pragma unroll
+    for (int e = 0; e < TC_PER_THREAD; ++e) if (bits & (1u << e)) ids[o++] = (int)(i0 + e);
+}
+__global__ __launch_bounds__(256) void k_fill_i32(int* p, long long n, int v) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 // ---- dense form of the reconciliation (item tables of up to a few tens of MB: all device side, no host round trip) -----------
 // One buffer row per item: [delta of plane 0 | delta of plane 1 | ... | touched (1 / 0)], zero for rows this rank did not rewrite;
 // the buffer is all-reduced (sum) as it stands, then every rank applies  cur = base + sum / count  (MEAN planes) or  base + sum
