@@ -489,8 +489,14 @@ def main():
                                'per_link_GBps': rates, 'allgather_8_ranks_us': ag,
                                'note': 'no separate all-reduce in this mode: the dense gradients ride in the block and every rank sums the eight copies itself; '
                                        'the one-rank all-gather inside the measured step already costs its launch'}
-            lo = step_us + ag[0]
-            hi = step_us + ag[1]
+            # the joint update walks 8 x 2B + n_sample list entries at eight ranks where the one-rank run walks 2B + n_sample, and sums eight
+            # rows per shared negative: scale the measured launch with the list length
+            ksp = 1000.0 * kt['k_sparse_update'][0] / max(kt['k_sparse_update'][1], 1) if 'k_sparse_update' in kt else 0.0
+            grow = (8 * 2 * cfg['batch_size'] + cfg['n_sample']) / float(R) - 1.0
+            proj['measured_on_this_gpu']['joint_update_us_one_rank'] = ksp
+            proj['assumed']['joint_update_extra_us_8_ranks'] = ksp * grow
+            lo = step_us + ag[0] + ksp * grow
+            hi = step_us + ag[1] + ksp * grow
             proj['mode'] = 'exact replicas (REDUCE form), one all-gather per step'
         else:
             per_call_ms = reconcile.get('ms_per_reconciliation') if reconcile and 'error' not in reconcile else None

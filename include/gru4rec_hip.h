@@ -82,7 +82,9 @@ typedef struct g4r_config {
                                     gradient rows of those shared columns are summed over the ranks, the ranks' input / target
                                     occurrences are listed one rank behind the other, all scaled by 1 / nranks: the occurrence list of
                                     ONE batch of nranks x batch_size rows sharing one row of negatives (gru4rec.py:436-437), updated
-                                    with the reference's rule.  Modes 1-3 want the same `seed` on every rank (one sample stream) */
+                                    with the reference's rule.  Modes 1-3 want the same `seed` on every rank (one sample stream; dropout
+                                    masks are keyed by seed + 7919 * rank inside the library); the ranks' raw dense gradients travel in
+                                    the same all-gathered block and every rank sums them in rank order: ONE collective per step */
     int32_t reserved;
 } g4r_config;
 

@@ -20,6 +20,7 @@ for c in cfg3 cfg4 cfg1 cfg5; do timeout 240 $B --config $c --steps 1500 --warmu
 G4R_FORCE_STAGED=1 timeout 200 $B --steps 3000 --warmup 300 --no-cpu-baseline --no-micro > $OUT/${TAG}_bench_staged_1rank.json 2> $OUT/bench_staged.err; echo "== staged, gpu-local rows"; python tools/benchsum.py $OUT/${TAG}_bench_staged_1rank.json
 G4R_FORCE_STAGED=1 timeout 200 $B --steps 3000 --warmup 300 --no-cpu-baseline --no-micro --sparse-exact > $OUT/${TAG}_bench_staged_1rank_exact.json 2> $OUT/bench_staged_exact.err; echo "== staged, exact replicas"; python tools/benchsum.py $OUT/${TAG}_bench_staged_1rank_exact.json
 G4R_FORCE_STAGED=1 timeout 240 $B --config cfg4 --steps 600 --warmup 100 --no-cpu-baseline --no-micro > $OUT/${TAG}_bench_staged_1rank_cfg4.json 2> $OUT/bench_staged_cfg4.err; echo "== staged cfg4"; python tools/benchsum.py $OUT/${TAG}_bench_staged_1rank_cfg4.json
+G4R_FORCE_STAGED=1 timeout 240 $B --config cfg4 --steps 600 --warmup 100 --no-cpu-baseline --no-micro --sparse-exact > $OUT/${TAG}_bench_staged_1rank_cfg4_exact.json 2> $OUT/bench_staged_cfg4_exact.err; echo "== staged cfg4, exact replicas"; python tools/benchsum.py $OUT/${TAG}_bench_staged_1rank_cfg4_exact.json
 [ -n "$BENCH_ONLY" ] && exit 0      # BENCH_ONLY=1: the bench lines alone (they read the committed profiles/ traffic files)
 cd /tmp && export TMPDIR=/tmp
 COMMON="--no-cpu-baseline --no-micro --profile-steps 0 --long-steps 0"
