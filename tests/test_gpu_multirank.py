@@ -220,3 +220,28 @@ def test_reconciliation_inside_train_steps_with_a_one_rank_communicator(monkeypa
         m.close()
     for a, b in zip(outs[0], outs[1]):
         np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-6)
+
+
+def test_touched_rows_of_a_4_5_M_item_catalogue_come_back_as_the_sorted_id_list():
+    """The touched bitmap is compacted ON THE DEVICE (k_touched_count / _scan / _write, g4r_sync_kernels.cuh): per 4096 items a
+    workgroup count, an exclusive scan of the counts that runs in chunks of 1024 workgroups (4.5 M items = 1099 of them: the
+    carry between chunks is exercised), ids written in item order.  Items at chunk and catalogue boundaries are planted among the
+    inputs, targets and negatives; the exported list must be exactly the sorted set of rows the steps touched."""
+    I, B, ns, T = 4_500_000, 8, 16, 6
+    o, m = make_pair(I, B, ns, store_rows=T, layers=(4,), loss='bpr-max', final_act='linear', constrained_embedding=True, learning_rate=0.05)
+    m.sync_enable()
+    rng = np.random.RandomState(5)
+    edge = np.array([0, 1, 4095, 4096, 4097, 8191, 1024 * 4096 - 1, 1024 * 4096, 1024 * 4096 + 1, 1025 * 4096 - 1, I - 4097, I - 2, I - 1], dtype=np.int64)
+    plan = random_plan(I, B, T, seed=11)
+    plan['in_idx'][0, :] = edge[:B]
+    plan['out_idx'][1, :5] = edge[B:]
+    ST = rng.randint(0, I, size=(T, ns)).astype(np.int32)
+    ST[2, :edge.size] = edge
+    m.set_sample_store(ST)
+    m.set_plan(plan)
+    m.train_steps(0, T)
+    ids, rows = m.sync_export(0)
+    want = np.unique(np.concatenate([plan['in_idx'][:T].ravel(), plan['out_idx'][:T].ravel(), ST[:T].ravel()]))
+    np.testing.assert_array_equal(ids, want.astype(np.int32))
+    assert rows.size == ids.size * int(_native.lib().g4r_sync_row_floats(m.h, 0))
+    m.close()
