@@ -1057,13 +1057,21 @@ static int apply_compaction(g4r_model* m, int64_t ci) {
 #define G4R_GRAPH_STEPS_SMALL 4
 // N > 1 (or the one-rank staged mode): the all-reduce is captured with the step, so that a replay covers 16 whole steps
 // (kernels, RCCL all-reduce, dense apply) with no host work in between; G4R_RCCL_EAGER=1 keeps RCCL out of the graph
+// one GPU, staged dense path without a communicator (the generic optimizers: rmsprop / adadelta / adam / plain SGD / grad_cap): no
+// collective in the step, so the whole step is captured like the fused single-GPU step (it used to replay a head graph and launch
+// its tail eagerly; G4R_NO_LOCAL_GRAPH=1 keeps that)
+static inline bool local_staged(const g4r_model* m) {
+    static const bool off = getenv("G4R_NO_LOCAL_GRAPH") != nullptr;
+    return !off && !m->dm.apply_dense_inplace && m->cfg.nranks <= 1 && !m->comm_ready && !m->p2p_ready && !m->virtual_ranks;
+}
 static inline bool dist_graph_wanted(const g4r_model* m) {
     static const bool eager = getenv("G4R_RCCL_EAGER") != nullptr;
-    return !m->dm.apply_dense_inplace && !m->dist_graph_failed && (m->p2p_ready || (m->comm_ready && !eager && !getenv("G4R_OVERLAP")));
+    return !m->dm.apply_dense_inplace && !m->dist_graph_failed &&
+           (m->p2p_ready || (m->comm_ready && !eager && !getenv("G4R_OVERLAP")) || local_staged(m));
 }
 static int ensure_graph(g4r_model* m) {
     if (m->gexec) return 0;
-    const bool dist = !m->dm.apply_dense_inplace;
+    const bool dist = !m->dm.apply_dense_inplace && !local_staged(m);
     if (dist && !m->p2p_ready) {
         // RCCL sets its channels up on first use: that must not happen inside a capture (dense_g is scratch between steps)
         NCCLCHK(ncclAllReduce(m->dm.dense_g, m->dm.dense_g, m->dm.dense_count, ncclFloat, ncclSum, m->comm, m->stream));
