@@ -1075,6 +1075,9 @@ static int ensure_graph(g4r_model* m) {
     if (dist && !m->p2p_ready) {
         // RCCL sets its channels up on first use: that must not happen inside a capture (dense_g is scratch between steps)
         NCCLCHK(ncclAllReduce(m->dm.dense_g, m->dm.dense_g, m->dm.dense_count, ncclFloat, ncclSum, m->comm, m->stream));
+        if (m->exact)      // the exact-replica step's collective is an all-gather: connect what THAT needs outside the capture, too
+            NCCLCHK(ncclAllGather((const float*)m->dm.xbase + (size_t)m->cfg.rank * (size_t)m->dm.xstride, (float*)m->dm.xbase, (size_t)m->dm.xstride,
+                                  ncclFloat, m->comm, m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));
     }
     hipGraph_t graph = nullptr;
