@@ -14,6 +14,7 @@ mkdir -p $OUT
 B="python $ROOT/bench.py"
 cd $ROOT
 python -c "from gru4rec_amd import _native; print(_native.lib().g4r_version().decode())" > $OUT/${TAG}_library_version.txt
+if [ -z "$PMC_ONLY" ]; then      # PMC_ONLY=1: only the counter passes at the end of this script
 timeout 300 $B > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err; python tools/benchsum.py $OUT/${TAG}_bench_default.json
 timeout 120 $B --steps 20 --warmup 5 --no-micro > $OUT/${TAG}_bench_driver_shape.json 2> $OUT/bench_driver_shape.err; python tools/benchsum.py $OUT/${TAG}_bench_driver_shape.json
 for c in cfg3 cfg4 cfg1 cfg5; do timeout 240 $B --config $c --steps 1500 --warmup 200 --no-cpu-baseline > $OUT/${TAG}_bench_$c.json 2> $OUT/bench_$c.err; echo "== $c"; python tools/benchsum.py $OUT/${TAG}_bench_$c.json; done
@@ -21,10 +22,13 @@ G4R_FORCE_STAGED=1 timeout 200 $B --steps 3000 --warmup 300 --no-cpu-baseline --
 G4R_FORCE_STAGED=1 timeout 200 $B --steps 3000 --warmup 300 --no-cpu-baseline --no-micro --sparse-exact > $OUT/${TAG}_bench_staged_1rank_exact.json 2> $OUT/bench_staged_exact.err; echo "== staged, exact replicas"; python tools/benchsum.py $OUT/${TAG}_bench_staged_1rank_exact.json
 G4R_FORCE_STAGED=1 timeout 240 $B --config cfg4 --steps 600 --warmup 100 --no-cpu-baseline --no-micro > $OUT/${TAG}_bench_staged_1rank_cfg4.json 2> $OUT/bench_staged_cfg4.err; echo "== staged cfg4"; python tools/benchsum.py $OUT/${TAG}_bench_staged_1rank_cfg4.json
 G4R_FORCE_STAGED=1 timeout 240 $B --config cfg4 --steps 600 --warmup 100 --no-cpu-baseline --no-micro --sparse-exact > $OUT/${TAG}_bench_staged_1rank_cfg4_exact.json 2> $OUT/bench_staged_cfg4_exact.err; echo "== staged cfg4, exact replicas"; python tools/benchsum.py $OUT/${TAG}_bench_staged_1rank_cfg4_exact.json
+fi
 [ -n "$BENCH_ONLY" ] && exit 0      # BENCH_ONLY=1: the bench lines alone (they read the committed profiles/ traffic files)
 cd /tmp && export TMPDIR=/tmp
 COMMON="--no-cpu-baseline --no-micro --profile-steps 0 --long-steps 0"
+[ -n "$PMC_ONLY" ] && SKIP_STATS=1
 for c in $CFGS; do
+  [ -n "$SKIP_STATS" ] && break
   rm -rf /tmp/out_s
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/out_s -- $B --config $c --steps 600 --warmup 100 $COMMON > $OUT/stats_$c.log 2>&1
   if ! ls /tmp/out_s/*/*kernel_stats.csv > /dev/null 2>&1; then
