@@ -16,6 +16,7 @@
 #include "g4r_eval_kernels.cuh"
 #include "g4r_sync_kernels.cuh"
 #include "g4r_micro_kernels.cuh"
+#include "g4r_wide_kernels.cuh"
 
 // Host code below is compiled in the host pass only: on the device pass the descriptor pointer fields are
 // address-space qualified (g4r_device.cuh) and the template kernels are instantiated explicitly.
@@ -88,6 +89,16 @@ struct g4r_model {
     unsigned* sk_flags = nullptr;
     size_t smem_sk = 0;
     bool loss_long = false;      // k_loss_rows<true>: score rows too long for two LDS copies
+    // wide layers (g4r_wide_kernels.cuh): per layer which kernels run (bit 1 k_gru_p1w, 2 k_gru_p2w, 4 k_gru_bwd_aw, 8 k_gru_bwd_bw) and
+    // their K-slice geometry; bit 16 of wide_mask: the 64 x 64 dense-gradient tiles (k_dense_grad2) for the whole model
+    struct WideGeo { int use = 0, ny = 1, nh = 1, kys = 0, khs = 0, p2n = 1, p2k = 0, ban = 1, bak = 0, bbn = 1, bbk = 0; };
+    WideGeo wg[G4R_MAX_LAYERS];
+    bool wide_dense = false;
+    float* wk_ws = nullptr;      // split-K partial sums: [tile][slice][4096] floats (shared by the kernels: they run one after the other)
+    unsigned* wk_cnt = nullptr;  // [tile] arrival counters
+    int wk_ntile = 0;
+    DenseTile* d_tiles64 = nullptr;
+    int ntiles64 = 0;
     float* d_tmpH = nullptr;
     // graph
     hipGraphExec_t gexec = nullptr;
@@ -227,6 +238,8 @@ static inline bool score_fwd_dma(const DevModel& d) {
     return wide_scores(d) || (d.Dtop >= 256 && d.B >= 64 && d.ldSc >= 1024);
 }
 static const size_t SMEM_SF = tile_smem<SF_BM, GT_BN, GT_BK, false, true>() + GT_BN * sizeof(int);
+static const size_t SMEM_T2K = (size_t)(4 * 64 * 16) * sizeof(float);                               // gemm_tile2k: two 16-deep buffers per operand
+static const size_t SMEM_T3 = (size_t)Tile3Cfg<3, 32>::SMEM_FLOATS * sizeof(float);                 // gemm_tile3: ring of three 32-deep stages
 // publish the host descriptor to the device copy (stream-ordered; pageable source is staged before return)
 static int sync_dm(g4r_model* m) {
     HIPCHK(hipMemcpyAsync(m->d_dm, &m->dm, sizeof(DevModel), hipMemcpyHostToDevice, m->stream));
@@ -486,6 +499,85 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
             g4r_destroy(m); return fail("tile upload");
         }
         if (hipStreamSynchronize(m->stream) != hipSuccess) { g4r_destroy(m); return fail("sync"); }
+    }
+    // wide layers: split-K kernels of g4r_wide_kernels.cuh.  G4R_WIDE2 (read per model: tests and A/B runs toggle it between models)
+    // is a bit mask -- 1 k_gru_p1w, 2 k_gru_p2w, 4 k_gru_bwd_aw, 8 k_gru_bwd_bw, 16 k_dense_grad2 -- default all (31); 0 = the round-1
+    // kernels.  Slice lengths: the longest one that still gives the launch enough workgroups (the product of a wide layer is a few
+    // dozen 64 x 64 tiles; a workgroup's latency hardly depends on its slice length until the chip is full), overridable for A/B runs:
+    // G4R_P1_KS / G4R_P2_KS / G4R_BA_KS / G4R_BB_KS.
+    {
+        const int mask = env_int("G4R_WIDE2", 31);
+        const int nrt = cdiv(B, 64);
+        int max_slots = 0, max_tiles = 0;
+        // slices of a K range: the fewest (longest) that bring tiles * slices to `want` workgroups, of at least `min_len`, multiples of `gran`
+        auto slices = [&](int K, int tiles, int want, int gran, int min_len, int forced, int* len) {
+            int n = std::max(1, cdiv(want, std::max(tiles, 1)));
+            n = std::min(n, std::max(1, K / min_len));
+            int ks = ((cdiv(K, n) + gran - 1) / gran) * gran;
+            if (forced > 0) ks = std::max(gran, (forced / gran) * gran);
+            *len = ks;
+            return cdiv(K, ks);
+        };
+        for (int l = 0; l < L; ++l) {
+            const int D = d.D[l], IN = d.IN[l];
+            g4r_model::WideGeo& G = m->wg[l];
+            const bool ok = wide_layer(D) && D % 64 == 0 && IN % 16 == 0 && IN >= 64 && !(l == 0 && cfg->embed_mode == G4R_EMBED_ONEHOT);
+            if (!ok || !(mask & 15)) continue;
+            G.use = mask & 15;
+            const int nct = D / 64;
+            // phase 1: 3 nct column tiles over K = IN (+ D for the r / z columns): one slice length for both parts
+            {
+                const int forced = env_int("G4R_P1_KS", 0);
+                int ks = 512;
+                for (; ks > 128; ks >>= 1) {
+                    const int ny = cdiv(IN, ks), nh = cdiv(D, ks);
+                    if (nct * nrt * (3 * ny + 2 * nh) >= (3 * m->n_cu) / 4) break;
+                }
+                if (forced > 0) ks = std::min(512, std::max(16, forced / 16 * 16));
+                G.ny = cdiv(IN, ks); G.kys = ((cdiv(IN, G.ny) + 15) / 16) * 16; G.ny = cdiv(IN, G.kys);
+                G.nh = cdiv(D, ks); G.khs = ((cdiv(D, G.nh) + 15) / 16) * 16; G.nh = cdiv(D, G.khs);
+                max_slots = std::max(max_slots, 3 * nct * nrt * (G.ny + G.nh));
+                max_tiles = std::max(max_tiles, 3 * nct * nrt);
+            }
+            G.p2n = slices(D, nct * nrt, m->n_cu / 2, 16, 64, env_int("G4R_P2_KS", 0), &G.p2k);
+            G.ban = slices(D, nct * nrt, m->n_cu / 2, 32, 64, env_int("G4R_BA_KS", 0), &G.bak);
+            const int nctb = cdiv(IN, 64);
+            G.bbn = slices(3 * D, nctb * nrt, (3 * m->n_cu) / 4, 32, 128, env_int("G4R_BB_KS", 0), &G.bbk);
+            max_slots = std::max(max_slots, std::max(nct * nrt * std::max(G.p2n, G.ban), nctb * nrt * G.bbn));
+            max_tiles = std::max(max_tiles, std::max(nct, nctb) * nrt);
+        }
+        if (max_slots > 0) {
+            DA(m->wk_ws, (size_t)max_slots * 4096);
+            DA(m->wk_cnt, (size_t)max_tiles);
+            m->wk_ntile = max_tiles;
+        }
+        int dmax = 0;
+        for (int l = 0; l < L; ++l) dmax = std::max(dmax, d.D[l]);
+        m->wide_dense = (mask & 16) && wide_layer(dmax) && !(cfg->embed_mode == G4R_EMBED_ONEHOT);
+        if (m->wide_dense) {
+            std::vector<DenseTile> tiles;
+            for (int l = 0; l < L; ++l) {
+                const int D = d.D[l], IN = d.IN[l];
+                auto add = [&](const float* x0, const float* x1, int ldx, int nrows, int ncols, int coff, int ldo, long long base) {
+                    for (int r = 0; r < nrows; r += 64)
+                        for (int c = 0; c < ncols; c += 64) {
+                            DenseTile t;
+                            t.X0 = x0; t.X1 = x1; t.dV = d.dV[l]; t.base = base; t.ldx = ldx; t.ldv = 3 * D; t.nrows = nrows;
+                            t.ncols = ncols; t.coff = coff; t.ldo = ldo; t.r0 = r; t.c0 = c; t.gather = (x0 == nullptr && nrows > 1) ? 1 : 0; t.pad = 0;
+                            tiles.push_back(t);
+                        }
+                };
+                const float* yin = (l == 0) ? nullptr : d.hd[l - 1];
+                add(yin, yin, IN, IN, 3 * D, 0, 3 * D, d.offWx[l]);
+                add(d.Hr[l], d.Hr[l], D, D, D, 0, D, d.offWh[l]);
+                add(d.H[l][0], d.H[l][1], D, D, 2 * D, D, 2 * D, d.offWrz[l]);
+                add(nullptr, nullptr, 0, 1, 3 * D, 0, 3 * D, d.offBh[l]);      // nrows == 1: the column-sum role
+            }
+            m->ntiles64 = (int)tiles.size();
+            DA(m->d_tiles64, tiles.size());
+            if (hipMemcpyAsync(m->d_tiles64, tiles.data(), tiles.size() * sizeof(DenseTile), hipMemcpyHostToDevice, m->stream) != hipSuccess ||
+                hipStreamSynchronize(m->stream) != hipSuccess) { g4r_destroy(m); return fail("tile upload"); }
+        }
     }
 #undef DA
     // LDS opt-in
@@ -803,7 +895,8 @@ static inline bool no_merge_tail() { static const bool v = getenv("G4R_NO_MERGE"
 // float4 chunks per lane a gathered row needs in the sparse update: rows of <= 256 / 512 / 1024 floats
 static inline int row_chunks(const DevModel& d) { const int w = std::max(d.Dtop, d.Ein); return w <= 256 ? 1 : (w <= 512 ? 2 : 4); }
 // (rows wider than 512 floats take the two-launch form: k_update's register budget is sized for two chunks per lane)
-static inline bool merged_update(const g4r_model* m) { return !m->dm.generic && !no_merge_tail() && row_chunks(m->dm) <= 2; }
+// (wide layers: the dense gradients run as 64 x 64 tiles in a launch of their own, k_dense_grad2, ahead of the sparse row update)
+static inline bool merged_update(const g4r_model* m) { return !m->dm.generic && !no_merge_tail() && row_chunks(m->dm) <= 2 && !m->wide_dense; }
 // part: 0 = the whole step; 1 = head (everything up to the dense gradients); 2 = tail (all-reduce, dense apply, sparse update)
 static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     DevModel& d = m->dm;
@@ -865,12 +958,16 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
             end();
             continue;
         }
+        const g4r_model::WideGeo& G = m->wg[l];
+        const int nrt64 = cdiv(B, 64), nct64 = d.D[l] / 64;
         begin(KN_GRU_P1);
-        if (wide_layer(d.D[l])) LK(k_gru_p1_n64, dim3(cdiv(3 * d.D[l], 64), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1_N64, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
+        if (G.use & 1) LK(k_gru_p1w, dim3(nct64 * nrt64 * (3 * G.ny + 2 * G.nh)), dim3(256), SMEM_T2K, s, dmp, stp, l, l == 0 ? 1 : 0, m->wk_ws, m->wk_cnt, G.ny, G.nh, G.kys, G.khs);
+        else if (wide_layer(d.D[l])) LK(k_gru_p1_n64, dim3(cdiv(3 * d.D[l], 64), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1_N64, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
         else LK(k_gru_p1_n32, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
         end();
         begin(KN_GRU_P2);
-        LK(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH), SMEM_NN, s, dmp, stp, l, 1, nopa);
+        if (G.use & 2) LK(k_gru_p2w, dim3(nct64 * nrt64 * G.p2n), dim3(256), SMEM_T2K, s, dmp, stp, l, m->wk_ws, m->wk_cnt, G.p2n, G.p2k);
+        else LK(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH), SMEM_NN, s, dmp, stp, l, 1, nopa);
         end();
     }
     if (syc_fork) HIPCHK(hipStreamWaitEvent(s, m->ev_join2, 0));
@@ -922,11 +1019,15 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         begin(KN_BWD_PRE);
         LK(k_gru_bwd_pre, dim3(cdiv((long long)B * d.D[l], 256)), dim3(256), 0, s, dmp, stp, l);
         end();
+        const g4r_model::WideGeo& G = m->wg[l];
+        const int nrt64 = cdiv(B, 64);
         begin(KN_BWD_A);
-        LK(k_gru_bwd_a, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH), SMEM_NT, s, dmp, stp, l);
+        if (G.use & 4) LK(k_gru_bwd_aw, dim3((d.D[l] / 64) * nrt64 * G.ban), dim3(256), SMEM_T3, s, dmp, stp, l, m->wk_ws, m->wk_cnt, G.ban, G.bak);
+        else LK(k_gru_bwd_a, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH), SMEM_NT, s, dmp, stp, l);
         end();
         begin(KN_BWD_B);
         if (l == 0 && d.embed_mode == G4R_EMBED_ONEHOT) LK(k_onehot_step, dim3(cdiv((long long)B * d.Ein, 4 * 256)), dim3(256), 0, s, dmp, stp);
+        else if (G.use & 8) LK(k_gru_bwd_bw, dim3(cdiv(d.IN[l], 64) * nrt64 * G.bbn), dim3(256), SMEM_T3, s, dmp, stp, l, m->wk_ws, m->wk_cnt, G.bbn, G.bbk);
         else LK(k_gru_bwd_b, dim3(cdiv(d.IN[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_BB, s, dmp, stp, l);
         end();
     }
@@ -954,7 +1055,8 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         if (d.apply_dense_inplace || part == 1) { HIPCHK(hipGetLastError()); return 0; }
     } else {
     begin(KN_DENSE);
-    if (m->dt == 0) LK(k_dense_grad<0>, dim3(m->ntiles), dim3(GT_NTH_FEW), SMEM_DIRECT, s, dmp, stp, (const DenseTile*)m->d_tiles);
+    if (m->wide_dense) LK(k_dense_grad2, dim3(m->ntiles64), dim3(256), SMEM_T2K, s, dmp, stp, (const DenseTile*)m->d_tiles64, m->ntiles64);
+    else if (m->dt == 0) LK(k_dense_grad<0>, dim3(m->ntiles), dim3(GT_NTH_FEW), SMEM_DIRECT, s, dmp, stp, (const DenseTile*)m->d_tiles);
     else LK(k_dense_grad<32>, dim3(m->ntiles), dim3(GT_NTH_FEW), SMEM_TN, s, dmp, stp, (const DenseTile*)m->d_tiles);
     end();
     }
@@ -1141,6 +1243,7 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
     if (t0 < 0 || n_steps < 0 || t0 + n_steps > m->T) return fail("step range outside the plan");
     if (m->dm.ns > 0 && !m->have_pop && !m->store_frozen) return fail("negative sampling needs g4r_set_popularity first");
     HIPCHK(hipSetDevice(m->cfg.device));
+    if (m->wk_cnt) HIPCHK(hipMemsetAsync(m->wk_cnt, 0, (size_t)m->wk_ntile * sizeof(unsigned), m->stream));      // split-K arrival counters (every launch leaves them at zero; a poisoned call must not outlive itself)
     hipLaunchKernelGGL(k_set_state, dim3(1), dim3(512), 0, m->stream, (const DevModel*)m->d_dm, (StepState*)m->dm.st, (long long)t0, (long long)m->gstep);
     bool use_graph = m->cfg.use_graph && !m->profiling && !getenv("G4R_TRACE") && (m->dm.apply_dense_inplace || dist_graph_wanted(m));
     if (use_graph && !m->dm.apply_dense_inplace) {
@@ -1239,7 +1342,8 @@ int g4r_virtual_train_steps(g4r_model* const* ms, int32_t n, int64_t t0, int64_t
     for (int q = 0; q < n; ++q) {
         g4r_model* m = ms[q];
         va.src[q] = m->dm.dense_g; va.dst[q] = m->dm.dense_g;
-        hipLaunchKernelGGL(k_set_state, dim3(1), dim3(512), 0, m->stream, (const DevModel*)m->d_dm, (StepState*)m->dm.st, (long long)t0, (long long)m->gstep);
+        if (m->wk_cnt) HIPCHK(hipMemsetAsync(m->wk_cnt, 0, (size_t)m->wk_ntile * sizeof(unsigned), m->stream));      // split-K arrival counters (every launch leaves them at zero; a poisoned call must not outlive itself)
+    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(512), 0, m->stream, (const DevModel*)m->d_dm, (StepState*)m->dm.st, (long long)t0, (long long)m->gstep);
         ci[q] = std::lower_bound(m->compact_steps.begin(), m->compact_steps.end(), t0) - m->compact_steps.begin();
     }
     for (int64_t t = t0; t < t0 + n_steps; ++t) {
@@ -2162,6 +2266,12 @@ int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
     else if (s == "dbgtile") { if (!d.dbgtile) return fail("G4R_CLK not set"); p = (const float*)d.dbgtile; n = 2 * 8 * (int64_t)8192; }      // [0, 4096): dense tiles, [4096, 8192): k_score_fwd tiles
     else if (s == "ntiles") { if (count < 1) return fail("count"); host[0] = (float)m->ntiles; return 0; }
     else if (s == "ldSc") { if (count < 1) return fail("count"); host[0] = (float)d.ldSc; return 0; }
+    else if (s == "wide_mask") {      // which wide-layer kernels run (bits 1 / 2 / 4 / 8 per layer OR-ed, 16 = k_dense_grad2)
+        if (count < 1) return fail("count");
+        int mk = m->wide_dense ? 16 : 0;
+        for (int l = 0; l < d.n_layers; ++l) mk |= m->wg[l].use;
+        host[0] = (float)mk; return 0;
+    }
     else if (s == "ksplit") { if (count < 1) return fail("count"); host[0] = (float)d.ksplit; return 0; }
     else if (s == "streamk_workers") { if (count < 1) return fail("count"); host[0] = (float)m->sk_W; return 0; }
     else if (s == "dev_syncs") { if (count < 1) return fail("count"); host[0] = (float)m->n_dev_syncs; return 0; }
