@@ -32,7 +32,8 @@ COMMON_FLAGS = ['-mllvm', '-amdgpu-kernarg-preload-count=16']
 
 MUTANTS = {1: 'sparse accumulator increments x 1.01', 2: 'sparse Adagrad steps x 1.01', 3: 'dense accumulator increments x 1.01',
            4: "round 3's stale-register pipeline of gemm_tile2k (tied wait operands in two branches): fails the ISA audit, so it is the "
-              "one library built with audit=False"}
+              "one library built with audit=False",
+           5: 'the 1 / nranks factor of the exact-replica joint update (REDUCE / MEAN forms) x 1.01'}
 
 
 def mutant_path(k):

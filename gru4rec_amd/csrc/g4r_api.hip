@@ -143,6 +143,7 @@ struct g4r_model {
     struct SyncPlane { float* cur; float* base; int W; int kind; };      // kind: 0 parameter / velocity, 1 optimizer statistic
     std::vector<SyncPlane> planes[2];
     int sync_rule[2] = {G4R_SYNC_MEAN, G4R_SYNC_SUM};      // combine rule of the parameter planes / of the statistic planes
+    bool sync_rule_user = false;                           // set through g4r_sync_set_rule: g4r_sync_enable keeps it
     unsigned char* d_touched = nullptr;
     unsigned char* d_rowcnt = nullptr;           // [n_items] scratch: number of parts that hold a row (MEAN rule)
     int sync_every_dev = 0;                      // > 0: g4r_train_steps reconciles the (dense-form) item tables itself every that many steps
@@ -239,7 +240,7 @@ static inline bool score_fwd_dma(const DevModel& d) {
 }
 static const size_t SMEM_SF = tile_smem<SF_BM, GT_BN, GT_BK, false, true>() + GT_BN * sizeof(int);
 static const size_t SMEM_T2K = (size_t)(4 * 64 * 16) * sizeof(float);                               // gemm_tile2k: two 16-deep buffers per operand
-static const size_t SMEM_T3 = (size_t)Tile3Cfg<3, 32>::SMEM_FLOATS * sizeof(float);                 // gemm_tile3: ring of three 32-deep stages
+static const size_t SMEM_T3 = (size_t)Tile3Cfg<G4R_WIDE_NST, 32>::SMEM_FLOATS * sizeof(float);                 // gemm_tile3: ring of three 32-deep stages
 // publish the host descriptor to the device copy (stream-ordered; pageable source is staged before return)
 static int sync_dm(g4r_model* m) {
     HIPCHK(hipMemcpyAsync(m->d_dm, &m->dm, sizeof(DevModel), hipMemcpyHostToDevice, m->stream));
@@ -506,7 +507,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     // dozen 64 x 64 tiles; a workgroup's latency hardly depends on its slice length until the chip is full), overridable for A/B runs:
     // G4R_P1_KS / G4R_P2_KS / G4R_BA_KS / G4R_BB_KS.
     {
-        const int mask = env_int("G4R_WIDE2", 31);
+        const int mask = env_int("G4R_WIDE2", 0);
         const int nrt = cdiv(B, 64);
         int max_slots = 0, max_tiles = 0;
         // slices of a K range: the fewest (longest) that bring tiles * slices to `want` workgroups, of at least `min_len`, multiples of `gran`
@@ -621,6 +622,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_update<1, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_aw, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_bw, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_store, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
 #define G4R_LOSS_ATTR(L, S) HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<L, S>, hipFuncAttributeMaxDynamicSharedMemorySize, big))
@@ -871,8 +874,18 @@ int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
         if (dalloc(m, &m->d_loss, (size_t)T)) return -1;
         m->loss_cap = T;
     }
-    for (int64_t t = 0; t < T; ++t)
-        if (M[t] < 0 || M[t] > B) return fail("plan M out of range");      // 0 = padding step (multi-rank plans of unequal length)
+    {
+        // ids of the ACTIVE rows must name catalogue rows: the kernels gather / update table rows by them without a bounds check
+        // (rows >= M[t] are never read).  One pass over the host arrays, ~10 ms for an RSC15-sized epoch.
+        const int nI = m->dm.n_items;
+        for (int64_t t = 0; t < T; ++t) {
+            if (M[t] < 0 || M[t] > B) return fail("plan M out of range");      // 0 = padding step (multi-rank plans of unequal length)
+            const int32_t *pi = in_idx + t * B, *po = out_idx + t * B;
+            unsigned bad = 0;
+            for (int b = 0; b < M[t]; ++b) bad |= (unsigned)((unsigned)pi[b] >= (unsigned)nI) | (unsigned)((unsigned)po[b] >= (unsigned)nI);
+            if (bad) return fail("plan: item id outside [0, n_items) in an active row of step " + std::to_string(t));
+        }
+    }
     m->T = T;
     m->dm.in_idx = m->d_in; m->dm.out_idx = m->d_out; m->dm.reset = m->d_reset; m->dm.Mplan = m->d_M;
     m->dm.loss_steps = m->d_loss;
@@ -1174,16 +1187,17 @@ static inline bool dist_graph_wanted(const g4r_model* m) {
 static int ensure_graph(g4r_model* m) {
     if (m->gexec) return 0;
     const bool dist = !m->dm.apply_dense_inplace && !local_staged(m);
-    if (dist && !m->p2p_ready) {
+    const bool rccl_in_graph = dist && (!m->p2p_ready || (m->exact && m->comm_ready));      // (exact replicas: the step's collective is RCCL's all-gather even when the peer-memory all-reduce is attached)
+    if (dist) {
         // RCCL sets its channels up on first use: that must not happen inside a capture (dense_g is scratch between steps)
-        NCCLCHK(ncclAllReduce(m->dm.dense_g, m->dm.dense_g, m->dm.dense_count, ncclFloat, ncclSum, m->comm, m->stream));
-        if (m->exact)      // the exact-replica step's collective is an all-gather: connect what THAT needs outside the capture, too
+        if (!m->p2p_ready) NCCLCHK(ncclAllReduce(m->dm.dense_g, m->dm.dense_g, m->dm.dense_count, ncclFloat, ncclSum, m->comm, m->stream));
+        if (m->exact && m->comm_ready)      // the exact-replica step's collective is an all-gather: connect what THAT needs outside the capture, too
             NCCLCHK(ncclAllGather((const float*)m->dm.xbase + (size_t)m->cfg.rank * (size_t)m->dm.xstride, (float*)m->dm.xbase, (size_t)m->dm.xstride,
                                   ncclFloat, m->comm, m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));
     }
     hipGraph_t graph = nullptr;
-    HIPCHK(hipStreamBeginCapture(m->stream, dist && !m->p2p_ready ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
+    HIPCHK(hipStreamBeginCapture(m->stream, rccl_in_graph ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
     int rc = 0;
     for (int i = 0; i < G4R_GRAPH_STEPS && !rc; ++i) rc = launch_step(m, nullptr);
     hipError_t e = hipStreamEndCapture(m->stream, &graph);
@@ -1896,7 +1910,7 @@ int g4r_sync_enable(g4r_model* m) {
     // leaves a0 (1 - N (1 - v^k)) + ... -- negative for rows several ranks touched (v = 0.95, 8 ranks, 16 steps: -3.5 a0), i.e. a
     // NaN in the next sqrt; Adam's first moment would be inflated up to N-fold.  Those statistics take the MEAN over the touching
     // ranks (an average of averages stays inside the range of its inputs), like parameters and velocities.
-    m->sync_rule[1] = (m->cfg.adapt == G4R_ADAPT_ADAGRAD) ? G4R_SYNC_SUM : G4R_SYNC_MEAN;
+    if (!m->sync_rule_user) m->sync_rule[1] = (m->cfg.adapt == G4R_ADAPT_ADAGRAD) ? G4R_SYNC_SUM : G4R_SYNC_MEAN;
     if (const char* e = getenv("G4R_SYNC_RULE")) {      // "<param><stat>", s = sum, m = mean: experiments (tools/virtual_ranks_study.py)
         if (e[0]) m->sync_rule[0] = e[0] == 's' ? G4R_SYNC_SUM : G4R_SYNC_MEAN;
         if (e[0] && e[1]) m->sync_rule[1] = e[1] == 's' ? G4R_SYNC_SUM : G4R_SYNC_MEAN;
@@ -2006,7 +2020,7 @@ static void sync_count(g4r_model* m, int nparts, const int* const* d_ids, const 
 }
 int g4r_sync_set_rule(g4r_model* m, int32_t param_rule, int32_t stat_rule) {
     if (!m || param_rule < 0 || param_rule > G4R_SYNC_MEAN || stat_rule < 0 || stat_rule > G4R_SYNC_MEAN) return fail("bad argument");
-    m->sync_rule[0] = param_rule; m->sync_rule[1] = stat_rule;
+    m->sync_rule[0] = param_rule; m->sync_rule[1] = stat_rule; m->sync_rule_user = true;
     return 0;
 }
 // test hook: apply the parts of all ranks (in rank order; this rank's own part included) as g4r_comm_sync_sparse does after its

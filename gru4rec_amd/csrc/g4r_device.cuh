@@ -30,6 +30,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define G4R_MUT_DACC(x) (x)
 #endif
 
+#if defined(G4R_MUTATE) && G4R_MUTATE == 5      // the 1 / nranks factor of the exact-replica joint update (REDUCE / MEAN forms) x 1.01
+#define G4R_MUT_XSCALE(x) ((x) * 1.01f)
+#else
+#define G4R_MUT_XSCALE(x) (x)
+#endif
+
 // Philox stream ids (counter word 3); twin of oracle/philox.py
 #define G4R_STREAM_SAMPLE 0x53414D50u
 #define G4R_STREAM_DROP_EMBED 0x44454D42u

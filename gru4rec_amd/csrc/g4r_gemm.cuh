@@ -418,13 +418,21 @@ __device__ __forceinline__ void wait_vm_barrier() {      // my LDS-DMA pieces ex
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N) : "memory");
 }
 
+// `behind` stages of LPS pieces each may stay in flight behind the stage that is waited for (counted wait + barrier)
+template <int LPS, int MAXB>
+__device__ __forceinline__ void wait_vm_behind(int behind) {
+    if constexpr (MAXB > 0) {
+        if (behind >= MAXB) { wait_vm_barrier<MAXB * LPS>(); return; }
+        wait_vm_behind<LPS, MAXB - 1>(behind);
+    } else wait_vm_barrier<0>();
+}
 // BKS = 32: a row of a stage is 8 quads, a DMA piece (1 KiB) 8 rows, 2 pieces per wave and operand, f(row) = (row >> 1) & 7;
 // BKS = 16: 4 quads, 16 rows per piece, 1 piece per wave and operand, f(row) = (row >> 2) & 3 (8 KiB stages: more workgroups per CU).
 template <int NST, int BKS, bool PRE_COL, class ARow, class BRow, class Pre, class Epi, class Join = NoJoin>
 __device__ __forceinline__ void gemm_tile3(int m0, int n0, int K, ARow arow, BRow brow, const GAS float* zrow, Pre pre, Epi epi, float* smem,
                                            GAS long long* trc = nullptr, Join join = Join()) {
     using C = Tile3Cfg<NST, BKS>;
-    static_assert(NST >= 3 && NST <= 5, "ring depth");
+    static_assert(NST >= 3 && NST <= 9, "ring depth");
     static_assert(BKS == 16 || BKS == 32, "stage depth");
     constexpr int QPR = BKS / 4, RPP = 64 / QPR, NP = 64 / RPP / 4;      // quads per row, rows per piece, pieces per wave and operand
     constexpr int FSH = BKS == 32 ? 1 : 2, FMASK = QPR - 1;              // f(row) = (row >> FSH) & FMASK
@@ -476,10 +484,7 @@ __device__ __forceinline__ void gemm_tile3(int m0, int n0, int K, ARow arow, BRo
     for (int i = 0; i < nchunk; ++i) {
         // stages i + 1 .. i + NST - 2 may stay in flight (LPS pieces each); at the tail fewer are behind stage i
         const int behind = min(NST - 2, nchunk - 1 - i);
-        if (NST >= 5 && behind == 3) wait_vm_barrier<3 * LPS>();
-        else if (NST >= 4 && behind == 2) wait_vm_barrier<2 * LPS>();
-        else if (behind == 1) wait_vm_barrier<LPS>();
-        else wait_vm_barrier<0>();
+        wait_vm_behind<LPS, NST - 2>(behind);
         if (trc && tid == 0 && i == 0) trc[2] = wall_clock64();          // first stage landed
         if (i + NST - 1 < nchunk) issue(nbuf);            // into the buffer stage i - 1 was read from (everyone is past the barrier)
         const float* fa = fa0 + buf * C::STAGE;

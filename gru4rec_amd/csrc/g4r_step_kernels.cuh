@@ -1430,7 +1430,7 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_bwd_b(const DevModel* __rest
             const float an = p.x + G4R_MUT_ACC(v * v);
             dSx[(size_t)row * IN + n] = generic ? v : G4R_MUT_STEP(lr * v * frsq(an + G4R_EPS_ADAGRAD));
             // single-occurrence item: new accumulator in place (see k_score_bwd), else through dA and the update kernel's owner wave
-            if (!generic && __float_as_int(p.y) == 1) accT[(size_t)sRow[row - m0] * IN + n] = an;
+            if (!generic && __float_as_int(p.y) == 1 && sRow[row - m0] >= 0) accT[(size_t)sRow[row - m0] * IN + n] = an;      // (item >= 0: the count read for a negative id is item 0's)
             else dAx[(size_t)row * IN + n] = an;
         } else {
             dylo[(size_t)row * IN + n] = v;
@@ -1673,7 +1673,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd_fused(const DevModel* __restric
             if (drop_e > 0.f) v *= drop_mult(seed, (unsigned)c.g, G4R_STREAM_DROP_EMBED, row, n, 1.0f - drop_e);
             const float an = a2[rg] + G4R_MUT_ACC(v * v);
             dSx[(size_t)row * IN + n] = generic ? v : G4R_MUT_STEP(lr * v * frsq(an + G4R_EPS_ADAGRAD));
-            if (!generic && cnt2[rg] == 1) accT[(size_t)sRow[4 * lg + rg] * IN + n] = an;      // single occurrence: in place (see k_score_bwd)
+            if (!generic && cnt2[rg] == 1 && sRow[4 * lg + rg] >= 0) accT[(size_t)sRow[4 * lg + rg] * IN + n] = an;      // single occurrence: in place (see k_score_bwd)
             else dAx[(size_t)row * IN + n] = an;
         } else {
             dylo[(size_t)row * IN + n] = v;
@@ -1701,6 +1701,7 @@ __global__ __launch_bounds__(256) void k_onehot_step(const DevModel* __restrict_
     const int row = (int)(q / nc4), c4 = (int)(q % nc4);
     if (row >= c.M) return;
     const int item = m.occ_idx[row];
+    if (item < 0) return;      // (g4r_set_plan refuses ids outside the catalogue in active rows; belt and braces)
     const float lr = m.lr;
     const float4 g = ld4(m.dV[0] + (size_t)row * W + 4 * c4);
     const float4 a = ld4(m.accE + (size_t)item * W + 4 * c4);
@@ -2445,13 +2446,34 @@ __device__ __forceinline__ XPos xlist_pos(const DevModel& m, int K) {
     } else { p.q = K / m.R; p.k = K - p.q * m.R; }
     return p;
 }
+// Item of an entry of the exchanged list.  A shared negative of the REDUCE form (q < 0) stands for one score column of EVERY rank: its
+// id is taken from the first block that holds it (a rank in the padded tail of its plan -- M = 0 -- stages -1 for its sample
+// columns while the other ranks still train; round 4 read rank 0's block only and dropped every rank's update of the negatives then).
+__device__ __forceinline__ int xlist_item(const DevModel& m, XPos p) {
+    if (p.q >= 0) return ((const GAS int*)(m.xbase + (long long)p.q * m.xstride))[p.k];
+    int item = -1;
+    for (int r = 0; r < m.xn; ++r) {
+        const int v = ((const GAS int*)(m.xbase + (long long)r * m.xstride))[p.k];
+        if (item < 0) item = v;
+    }
+    return item;
+}
 __global__ __launch_bounds__(256) void k_exact_occ(const DevModel* __restrict__ mp) {
     const DevModel& m = *mp;
     const int K = blockIdx.x * 256 + threadIdx.x, R = xlist_len(m);
     if (K >= R) return;
     const XPos ps = xlist_pos(m, K);
     const int k = ps.k;
-    const int item = ((const GAS int*)(m.xbase + (long long)max(ps.q, 0) * m.xstride))[k];
+    const int item = xlist_item(m, ps);
+    if (ps.q < 0) {
+        // the ranks must have drawn the SAME negatives (one sample stream: GRU4Rec._create_model seeds every rank alike in this mode;
+        // a C-API caller may not): their gradient rows are summed under ONE id.  A mismatch poisons the step's cost (NaN: the
+        // host's NaN check stops the run, gru4rec.py:626) instead of silently training items under other items' ids.
+        for (int r = 0; r < m.xn; ++r) {
+            const int v = ((const GAS int*)(m.xbase + (long long)r * m.xstride))[k];
+            if (v >= 0 && v != item) m.st->nan_flag = 2;
+        }
+    }
     if (item < 0) return;
     const bool tableE = (k < m.B && m.embed_mode != G4R_EMBED_CONSTRAINED);
     int* fl = (int*)m.occ_fl + 4 * ((tableE ? (size_t)m.n_items : 0) + item);
@@ -2494,10 +2516,10 @@ __global__ __launch_bounds__(SP_WAVES * 64, MAXCH == 1 ? 4 : 2) void k_sparse_up
             for (int i = lane; i < c.M; i += 64) s += m.lossrow[i];
             s = wave_sum(s);
             if (lane == 0) {
-                const float cost = s * m.inv_B;
-                m.loss_steps[c.t] = cost;
                 GAS StepState* sg = (GAS StepState*)st;
-                if (isnan(cost)) sg->nan_flag = 1;
+                const float cost = (sg->nan_flag == 2) ? __builtin_nanf("") : s * m.inv_B;      // 2: the ranks' negatives differ (k_exact_occ)
+                m.loss_steps[c.t] = cost;
+                if (isnan(cost) && sg->nan_flag == 0) sg->nan_flag = 1;
                 sg->t_a = c.t + 1;
                 sg->g_a = c.g + 1;
                 sg->M_a = Mn;
@@ -2517,10 +2539,10 @@ __global__ __launch_bounds__(SP_WAVES * 64, MAXCH == 1 ? 4 : 2) void k_sparse_up
     // barrier-or), so the common wave -- owner of a single occurrence -- makes two round trips (item; entry + rows) and stores.
     const int k = wid * nblk_occ + bid;
     const XPos pk = xlist_pos(m, min(k, R - 1));
-    const int item = k < R ? ((const GAS int*)(xb + (long long)max(pk.q, 0) * xs))[pk.k] : -1;
+    const int item = k < R ? xlist_item(m, pk) : -1;
     const int kl = pk.k;                          // local occurrence of k (position in its rank's X | Y | samples list)
     auto is_x = [&](int j) { return xlist_pos(m, j).k < B; };      // an input occurrence (table E when the tables are separate; no output bias)
-    const float xscale = (m.xmode == 3) ? 1.0f / (float)xn : 1.0f;      // REDUCE form: gradients of the GLOBAL batch (cost / (xn * B))
+    const float xscale = (m.xmode == 3) ? G4R_MUT_XSCALE(1.0f / (float)xn) : 1.0f;      // REDUCE form: gradients of the GLOBAL batch (cost / (xn * B))
     const bool constrained = (m.embed_mode == G4R_EMBED_CONSTRAINED);
     const bool tableE = (kl < B && !constrained);
     GAS int* flp = m.occ_fl + 4 * ((tableE ? (size_t)m.n_items : 0) + max(item, 0));
@@ -2596,7 +2618,7 @@ __global__ __launch_bounds__(SP_WAVES * 64, MAXCH == 1 ? 4 : 2) void k_sparse_up
     if (__syncthreads_or((owner && fl.z > 1) ? 1 : 0)) {
         for (int j = tid; j < Rpad; j += SP_WAVES * 64) {
             const XPos pj = xlist_pos(m, min(j, R - 1));
-            sOcc[j] = j < R ? ((const GAS int*)(xb + (long long)max(pj.q, 0) * xs))[pj.k] : -2;
+            sOcc[j] = j < R ? xlist_item(m, pj) : -2;
         }
         __syncthreads();
     }
@@ -2741,7 +2763,7 @@ __global__ __launch_bounds__(SP_WAVES * 64, MAXCH == 1 ? 4 : 2) void k_sparse_up
             an[e] = (xmean && adagrad) ? o.A + ad[e] : o.A; un[e] = o.U; cn[e] = o.C;
             const float inc = mom ? (fn * (momc * ww[e]) - dsum) : -dsum;      // the parameter increment of all occurrences together
             vn[e] = mom ? momc * ww[e] - lr * (o.gl + reg) : 0.f;
-            pn[e] = pp[e] + (xmean ? inc / (float)nq : inc);
+            pn[e] = pp[e] + (xmean ? G4R_MUT_XSCALE(inc / (float)nq) : inc);
         }
         const int c4 = lane + 64 * q;
         if (c4 < nc4) {
@@ -2765,7 +2787,7 @@ __global__ __launch_bounds__(SP_WAVES * 64, MAXCH == 1 ? 4 : 2) void k_sparse_up
         if (m.cntBy) m.cntBy[item] = o.C;
         const float inc = mom ? (fb * (momc * bw0) - dsum) : -dsum;
         if (mom) m.velBy[item] = momc * bw0 - lr * (o.gl + reg);
-        m.By[item] = bp0 + (xmean ? inc / (float)max(nqb, 1) : inc);
+        m.By[item] = bp0 + (xmean ? G4R_MUT_XSCALE(inc / (float)max(nqb, 1)) : inc);
     }
 }
 

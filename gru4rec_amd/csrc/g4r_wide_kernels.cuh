@@ -12,6 +12,10 @@
 #pragma once
 #include "g4r_step_kernels.cuh"
 
+#ifndef G4R_WIDE_NST
+#define G4R_WIDE_NST 3      // ring depth (stages of 32 k, 16 KB each) of the LDS-DMA fed wide kernels
+#endif
+
 // work item -> (column tile, K slice, row tile): row tiles innermost, so that the workgroups of one XCD (G4R_XCD_TILE) that share a
 // weight slab (same columns, same K slice) sit next to each other
 struct WideItem { int ct, s, rt; };
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_aw(const DevModel* __restric
         if (row < M) dV[(size_t)row * D3 + D + n] = v * p.y * p.x * (1.f - p.x);
     };
     const SplitKJoin join = {ws, cnt, w.ct * nrt + w.rt, w.s, nsp, nsp};
-    gemm_tile3<3, 32, false>(m0, n0, Klen, arow, brow, m.zrow, pre, epi, smem, nullptr, join);
+    gemm_tile3<G4R_WIDE_NST, 32, false>(m0, n0, Klen, arow, brow, m.zrow, pre, epi, smem, nullptr, join);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -280,13 +284,13 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_bw(const DevModel* __restric
                                                          G4R_MUT_STEP(lr * v.z * frsq(an.z + G4R_EPS_ADAGRAD)), G4R_MUT_STEP(lr * v.w * frsq(an.w + G4R_EPS_ADAGRAD)));
             st4(dSx + o, stp);
             // single-occurrence item: new accumulator in place (see k_score_bwd), else through dA and the update kernel's owner wave
-            if (!generic && pcnt[i] == 1) st4(accT + (size_t)item[i] * IN + ec, an);
+            if (!generic && pcnt[i] == 1 && item[i] >= 0) st4(accT + (size_t)item[i] * IN + ec, an);
             else st4(dAx + o, an);
         }
         return false;                // (the tile's generic per-element epilogue is not used)
     };
     auto epi = [&](int, int, float, float4) {};
-    gemm_tile3<3, 32, true>(m0, n0, Klen, arow, brow, m.zrow, NoPre(), epi, smem, nullptr, join);
+    gemm_tile3<G4R_WIDE_NST, 32, true>(m0, n0, Klen, arow, brow, m.zrow, NoPre(), epi, smem, nullptr, join);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

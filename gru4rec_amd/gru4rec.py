@@ -135,8 +135,9 @@ class GRU4Rec:
         # All ranks then draw the SAME negatives (one sample stream: the global batch shares its row of negatives, as the reference's
         # batch does, gru4rec.py:436-437).  True / 'reduce': the gradient rows of the shared negatives are SUMMED over the ranks (what
         # an all-reduce would give), the ranks' input / target occurrences are listed one rank behind the other, everything scaled to
-        # the global batch -- the occurrence list of ONE batch of nranks x batch_size rows, updated exactly as the reference updates
-        # its batch.  Kept for the A/B of DESIGN.md section 7: 'mean' (every rank's occurrences listed, an item's increment = the mean
+        # the global batch -- the occurrence list of ONE batch of nranks x batch_size rows, updated as the reference updates its batch
+        # EXCEPT that a row is scored against its own rank's batch_size in-batch negatives only (the hidden states live on their
+        # ranks), not against all nranks x batch_size targets.  Kept for the A/B of DESIGN.md section 7: 'mean' (every rank's occurrences listed, an item's increment = the mean
         # over the ranks touching it) and 'sum' (every occurrence of every rank applied like a duplicate: diverges from four ranks on)
         self.sparse_exact = False
         self._model = None

@@ -46,8 +46,8 @@ def fit_virtual_ranks(params, data, nranks, sample_store=10000000, sync_every='d
         g = GRU4Rec(**params)
         g.sparse_exact = sparse_exact      # False / True (= 'reduce') / 'reduce' / 'mean' / 'sum'
         g.set_distributed(r, nranks, None)
-        if replicate:
-            g.seed -= 7919 * r      # _create_model adds 7919 * rank
+        if replicate and not sparse_exact:
+            g.seed -= 7919 * r      # _create_model adds 7919 * rank (exact-replica mode: it does not -- one sample stream for all ranks)
         g.prepare(data.copy(), sample_store=sample_store)
         exact = bool(getattr(g, 'sparse_exact', False)) and nranks > 1
         if nranks > 1 and not exact:

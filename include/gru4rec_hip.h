@@ -84,7 +84,10 @@ typedef struct g4r_config {
                                     ONE batch of nranks x batch_size rows sharing one row of negatives (gru4rec.py:436-437), updated
                                     with the reference's rule.  Modes 1-3 want the same `seed` on every rank (one sample stream; dropout
                                     masks are keyed by seed + 7919 * rank inside the library); the ranks' raw dense gradients travel in
-                                    the same all-gathered block and every rank sums them in rank order: ONE collective per step */
+                                    the same all-gathered block and every rank sums them in rank order: ONE collective per step.
+                                    Mode 3 checks every step that the ranks' negatives are the same ids (a rank in the padded tail of
+                                    its plan holds none: the ids then come from the first rank that has them); a mismatch turns the
+                                    step's cost into NaN on every rank -- the run stops at the caller's NaN check */
     int32_t reserved;
 } g4r_config;
 

@@ -37,7 +37,7 @@ OPTIONS = [
     ('-tk', '--time_key', dict(metavar='TK', default='Time', help='timestamp column (default Time)')),
     ('-pm', '--primary_metric', dict(metavar='METRIC', choices=['recall', 'mrr'], default='recall', help='metric reported on the PRIMARY METRIC line (default recall)')),
     ('-lpm', '--log_primary_metric', dict(action='store_true', help='print the PRIMARY METRIC line after every evaluation')),
-    (None, '--sparse_exact', dict(action='store_true', help='with --gpus N: keep the replicas bit-identical by exchanging every rank\'s per-occurrence gradient rows of the item tables every step (RCCL all-gather; an item\'s increment is the mean over the ranks touching it) instead of reconciling GPU-local rows every sync_every steps; for small catalogues')),
+    (None, '--sparse_exact', dict(action='store_true', help='with --gpus N: keep the replicas bit-identical by exchanging every rank\'s per-occurrence gradient rows of the item tables every step (one RCCL all-gather) instead of reconciling GPU-local rows every sync_every steps.  REDUCE form: all ranks draw ONE stream of negatives, the gradient rows of a shared negative are summed over the ranks before the optimizer rule and every row is scaled by 1 / N -- the update of one batch of N x batch_size rows, except that a row meets only its own rank\'s in-batch negatives; for catalogues whose exchanged list fits the LDS')),
     (None, '--gpus', dict(metavar='N', type=int, default=1, help='train on N GPUs of this node (not in the reference): one process per GPU, sessions sharded over '
                           'the ranks, dense GRU gradients all-reduced by RCCL every step, item rows GPU-local and reconciled every sync_every steps (4 at two ranks, 16 from three on) and at every epoch end; rank 0 saves / evaluates')),
 ]

@@ -22,7 +22,7 @@ def _run(tag, I, B, ns, T, store_rows, dup=True, **kw):
     o, m = make_pair(I, B, ns, store_rows=store_rows, **kw)
     plan = random_plan(I, B, T, seed=101)
     if dup:      # repeated items inside the batch and against the negatives (duplicate semantics of the sparse update)
-        plan['in_idx'][:, :8] = o.ST[0][:8]
+        plan['in_idx'][:, :8] = o.ST[0][:8] if ns else plan['out_idx'][:, 24:32]
         plan['out_idx'][:, 8:16] = plan['in_idx'][:, :8]
         plan['out_idx'][:, 16:20] = plan['out_idx'][:, 20:24]
     m.set_plan(plan)
@@ -31,8 +31,30 @@ def _run(tag, I, B, ns, T, store_rows, dup=True, **kw):
     errs = []
     report('--- %s' % tag)
     close('loss curve', m.get_losses(0, T), np.array(want), atol=5e-6, rtol=5e-4, errs=errs)
-    np.testing.assert_array_equal(m.get_sample_store(ns), o.ST)
+    if ns:
+        np.testing.assert_array_equal(m.get_sample_store(ns), o.ST)
     compare_params(o, m, errs, tag)
+    m.close()
+    assert not errs, errs
+
+
+def test_cfg1_exact_shape():
+    """configs[0] (the reference's CPU-runnable plumbing case): layers=[100], batch=32, n_sample=0 -- in-batch negatives only --,
+    cross-entropy over softmax, the RSC15 catalogue of 37,483 items; 16 steps, with a tail of shrinking batches (M < B: the
+    reference's loop ends an epoch that way, gru4rec.py:647-651)."""
+    I, B, T = 37483, 32, 16
+    o, m = make_pair(I, B, 0, store_rows=0, loss='cross-entropy', final_act='softmax', constrained_embedding=True, layers=(100,),
+                     learning_rate=0.1)
+    plan = random_plan(I, B, T, seed=101, tail=True)
+    plan['in_idx'][:, :8] = plan['out_idx'][:, 24:32]      # inputs that are other rows' targets, repeated targets
+    plan['out_idx'][:, 8:12] = plan['out_idx'][:, 12:16]
+    m.set_plan(plan)
+    want = [o.train_step(plan['in_idx'][t], plan['out_idx'][t], int(plan['M'][t]), plan['reset'][t]) for t in range(T)]
+    m.train_steps(0, T)
+    errs = []
+    report('--- cfg1')
+    close('loss curve', m.get_losses(0, T), np.array(want), atol=5e-6, rtol=5e-4, errs=errs)
+    compare_params(o, m, errs, 'cfg1', Mrows=int(plan['M'].min()), loosen=2.0)
     m.close()
     assert not errs, errs
 

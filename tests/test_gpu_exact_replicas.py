@@ -81,6 +81,174 @@ def test_exact_mode_against_the_oracle_run_as_replicas(case):
     assert not errs, errs
 
 
+CASES = dict(bprmax_constrained=dict(layers=(16,), loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, learning_rate=0.1, bpreg=1.0),
+             xe_separate_momentum=dict(layers=(12,), loss='cross-entropy', final_act='softmax', constrained_embedding=False, embedding=8,
+                                       learning_rate=0.05, momentum=0.2, logq=1.0),
+             bprmax_dropout=dict(layers=(16,), loss='bpr-max', final_act='linear', constrained_embedding=True, learning_rate=0.1, bpreg=1.0,
+                                 dropout_p_hidden=0.3, dropout_p_embed=0.2))
+
+
+def _replica_setup(case, mode, N, I, B, ns, T, shared_negatives):
+    kw = CASES[case]
+    pairs = [make_pair(I, B, ns, store_rows=T, seed=3, rank=r, nranks=N, sparse_exact=mode, **dict(kw)) for r in range(N)]
+    plans = [random_plan(I, B, T, seed=100 + r) for r in range(N)]
+    rng = np.random.RandomState(9)
+    shared = rng.randint(0, I, size=(T, ns)).astype(np.int64)
+    for r, (o, m) in enumerate(pairs):
+        o.ST = shared.copy() if shared_negatives else rng.randint(0, I, size=(T, ns)).astype(np.int64)
+        o.generate_length = T
+        o.seed = 3 + 7919 * r      # (the oracle keys its dropout masks by its seed; its negatives are injected)
+        m.set_sample_store(o.ST.astype(np.int32))
+        m.set_plan(plans[r])
+    return kw, [p[0] for p in pairs], [p[1] for p in pairs], plans
+
+
+def _capture(oracles, plans, t, B):
+    """Pass 1 of a replica step: every rank's dense gradients and per-occurrence sparse lists at the common pre-step state (state rolled back)."""
+    import copy
+    dense, sparse = [], []
+    for r, o in enumerate(oracles):
+        keep = copy.deepcopy({k: v for k, v in o.__dict__.items() if k not in ('dense_grad_hook', 'sparse_grad_hook')})
+        cap = {}
+        o.dense_grad_hook = lambda g, cap=cap: cap.setdefault('d', g)
+        o.sparse_grad_hook = lambda s, cap=cap: cap.setdefault('s', s)
+        o.train_step(plans[r]['in_idx'][t], plans[r]['out_idx'][t], B, plans[r]['reset'][t], samples=o.ST[t])
+        dense.append(cap['d']); sparse.append(cap['s'])
+        o.__dict__.update(keep)
+    N = len(oracles)
+    avg = [(dense[0][j][0],) + tuple(None if dense[0][j][q] is None else sum(d[j][q] for d in dense) / N for q in range(1, 5))
+           for j in range(len(dense[0]))]
+    return avg, sparse
+
+
+def _check_replicas(tag, kw, oracles, models, want, I, T, loosen=4.0):
+    errs = []
+    N = len(models)
+    for r in range(N):
+        close('%s rank %d costs' % (tag, r), models[r].get_losses(0, T), np.array(want[r]), atol=5e-6, rtol=5e-4, errs=errs)
+        compare_params(oracles[r], models[r], errs, '%s r%d' % (tag, r), loosen=loosen)
+    D = kw['layers'][0]
+    names = [('Wy', (I, D)), ('By', (I,)), ('acc_Wy', (I, D)), ('acc_By', (I,))]
+    if not kw['constrained_embedding']:
+        names += [('E', (I, kw['embedding'])), ('acc_E', (I, kw['embedding']))]
+    for r in range(1, N):      # replicas: identical bits, nothing was reconciled
+        for nm, shape in names:
+            np.testing.assert_array_equal(models[0].get_param(nm, shape), models[r].get_param(nm, shape))
+    for m in models:
+        m.close()
+    return errs
+
+
+@pytest.mark.parametrize('case', sorted(CASES))
+def test_reduce_form_against_the_oracle_run_as_replicas(case):
+    """sparse_exact = 3, the form GRU4Rec.sparse_exact = True ships (g4r_step_kernels.cuh: k_exact_occ / k_sparse_update_generic with
+    xmode 3): all ranks share one row of negatives per step; the joint occurrence list is X | Y of rank 0, X | Y of rank 1, ..., then
+    the negatives ONCE, their gradient rows (and bias gradients) summed over the ranks in rank order; every row x 1 / N; then the
+    reference's duplicate rule (gru4rec.py:335-340,407-431) over that list, identically on every replica; dense gradients averaged.
+    The oracle computes exactly that from its own per-rank gradient lists: per-step costs of every rank, every parameter and
+    accumulator, replicas bit-identical."""
+    N, I, B, ns, T = 3, 40, 8, 16, 8
+    kw, oracles, models, plans = _replica_setup(case, 3, N, I, B, ns, T, shared_negatives=True)
+    _native.virtual_train_steps(models, 0, T)
+    want = [[] for _ in range(N)]
+    f32 = np.float32
+    for t in range(T):
+        avg, sparse = _capture(oracles, plans, t, B)
+        joint = []
+        for i, (nm, idx0, g0) in enumerate(sparse[0]):
+            # rows of the list that belong to the rank (inputs and / or targets) come first, the shared negatives are the last ns rows
+            own = len(idx0) - ns if nm != 'E' else len(idx0)
+            idx = np.concatenate([sp[i][1][:own] for sp in sparse] + ([idx0[own:]] if own < len(idx0) else []))
+            for sp in sparse:      # the premise of the form: every rank holds the same negatives
+                np.testing.assert_array_equal(sp[i][1][own:], idx0[own:])
+            parts = [sp[i][2][:own] for sp in sparse]
+            if own < len(idx0):
+                tot = sparse[0][i][2][own:].astype(f32)
+                for sp in sparse[1:]:
+                    tot = (tot + sp[i][2][own:]).astype(f32)      # rank order, fp32 (grow / bgrad in k_sparse_update_generic)
+                parts.append(tot)
+            g = (np.concatenate(parts).astype(f32) * f32(1.0 / N)).astype(f32)
+            joint.append((nm, idx, g))
+        for r, o in enumerate(oracles):
+            o.dense_grad_hook = lambda g, avg=avg: avg
+            o.sparse_grad_hook = lambda s, joint=joint: joint
+            want[r].append(o.train_step(plans[r]['in_idx'][t], plans[r]['out_idx'][t], B, plans[r]['reset'][t], samples=o.ST[t]))
+    errs = _check_replicas('reduce %s' % case, kw, oracles, models, want, I, T)
+    assert not errs, errs
+
+
+@pytest.mark.parametrize('case', ['bprmax_constrained', 'bprmax_dropout'])
+def test_mean_form_against_the_oracle_run_as_replicas(case):
+    """sparse_exact = 2 (kept for the A/B of DESIGN.md section 7): every rank's occurrences are listed; an item's parameter increment
+    is the MEAN over the ranks that touch it of each rank's own increment (each computed with the reference's duplicate rule from
+    the common pre-step row), its Adagrad accumulator the pre-step value plus the SUM of those ranks' last-occurrence increments.
+    Restated here with the oracle's own _sparse_update applied per rank to copies of the pre-step tables."""
+    N, I, B, ns, T = 3, 40, 8, 16, 8
+    kw, oracles, models, plans = _replica_setup(case, 2, N, I, B, ns, T, shared_negatives=False)
+    _native.virtual_train_steps(models, 0, T)
+    want = [[] for _ in range(N)]
+    for t in range(T):
+        avg, sparse = _capture(oracles, plans, t, B)
+        o0 = oracles[0]
+        new_tab = {}
+        for i, (nm, _, _) in enumerate(sparse[0]):
+            P0, A0 = getattr(o0, nm).copy(), o0.acc[nm].copy()
+            dP = np.zeros_like(P0, dtype=np.float64)
+            dA = np.zeros_like(A0, dtype=np.float64)
+            touch = np.zeros(P0.shape[0], dtype=np.int64)
+            for r, o in enumerate(oracles):
+                setattr(o, nm, P0.copy()); o.acc[nm] = A0.copy()
+                o._sparse_update(nm, sparse[r][i][1], sparse[r][i][2])      # this rank's own increment from the common pre-step row
+                dP += getattr(o, nm).astype(np.float64) - P0
+                dA += o.acc[nm].astype(np.float64) - A0
+                touch[np.unique(sparse[r][i][1])] += 1
+            nq = np.maximum(touch, 1).reshape((-1,) + (1,) * (P0.ndim - 1))
+            new_tab[nm] = ((P0 + dP / nq).astype(np.float32), (A0 + dA).astype(np.float32))
+            for o in oracles:
+                setattr(o, nm, P0.copy()); o.acc[nm] = A0.copy()
+        for r, o in enumerate(oracles):
+            o.dense_grad_hook = lambda g, avg=avg: avg
+            o.sparse_grad_hook = lambda s: []      # the item tables are set below
+            want[r].append(o.train_step(plans[r]['in_idx'][t], plans[r]['out_idx'][t], B, plans[r]['reset'][t], samples=o.ST[t]))
+            for nm, (P, A) in new_tab.items():
+                setattr(o, nm, P.copy()); o.acc[nm] = A.copy()
+    errs = _check_replicas('mean %s' % case, kw, oracles, models, want, I, T)
+    assert not errs, errs
+
+
+def test_reduce_form_poisons_the_cost_when_the_ranks_negatives_differ():
+    """REDUCE sums the ranks' gradient rows of a negative under ONE item id: ranks that drew different negatives must not train on.
+    The step's cost becomes NaN on every rank (k_exact_occ -> bookkeeping block); equal negatives with one rank in the padded tail of
+    its plan (M = 0: its sample columns are inactive) keep training the negatives from the other ranks' rows."""
+    N, I, B, ns, T = 2, 40, 8, 16, 4
+    kw, oracles, models, plans = _replica_setup('bprmax_constrained', 3, N, I, B, ns, T, shared_negatives=True)
+    st = oracles[1].ST.astype(np.int32).copy()
+    st[2, 5] = (st[2, 5] + 1) % I      # one id of step 2 differs on rank 1
+    models[1].set_sample_store(st)
+    _native.virtual_train_steps(models, 0, T)
+    for m in models:
+        c = m.get_losses(0, T)
+        assert np.isfinite(c[:2]).all() and np.isnan(c[2]), c
+        m.close()
+    # padded tail: RANK 0's last two steps are M = 0 (round 4 took the negatives' ids from rank 0's block alone and dropped them then)
+    kw, oracles, models, plans = _replica_setup('bprmax_constrained', 3, N, I, B, ns, T, shared_negatives=True)
+    plans[0]['M'][2:] = 0
+    models[0].set_plan(plans[0])
+    wy0 = models[0].get_param('Wy', (I, 16)).copy()
+    _native.virtual_train_steps(models, 0, 2)
+    wy2 = models[0].get_param('Wy', (I, 16)).copy()
+    _native.virtual_train_steps(models, 2, 2)
+    wy4 = models[0].get_param('Wy', (I, 16)).copy()
+    neg_only = np.setdiff1d(oracles[0].ST[2:].ravel(), np.concatenate([plans[1]['in_idx'][2:].ravel(), plans[1]['out_idx'][2:].ravel()]))
+    assert len(neg_only) > 0
+    assert (np.abs(wy4[neg_only] - wy2[neg_only]).max(axis=1) > 0).all(), 'negatives were not updated while rank 0 was padded'
+    assert np.isfinite(models[1].get_losses(0, T)).all()
+    np.testing.assert_array_equal(wy4, models[1].get_param('Wy', (I, 16)))
+    assert np.abs(wy2 - wy0).max() > 0
+    for m in models:
+        m.close()
+
+
 PARAMS = dict(loss='bpr-max', final_act='elu-0.5', layers=[100], batch_size=128, n_sample=2048, constrained_embedding=True,
               learning_rate=0.1, bpreg=1.0, momentum=0.0, sample_alpha=0.75, n_epochs=1)
 STORE = 2048 * 640

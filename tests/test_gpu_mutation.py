@@ -5,6 +5,7 @@ mutant; every one of those runs has to come back red, and the tensor it names ha
   mutant 1  every per-occurrence sparse accumulator increment x 1.01   -> acc_Wy / acc_By (1 % of an accumulator of ~1e-7)
   mutant 2  every sparse Adagrad step x 1.01                             -> dWy / dBy (1 % of a step)
   mutant 3  every dense accumulator increment x 1.01                     -> acc_Wx / acc_Wh / ...
+  mutant 5  the 1 / nranks factor of the exact-replica joint update x 1.01 -> the REDUCE / MEAN oracle-as-replicas tests
 
 (Round 2's `atol = 1e-4` on every tensor let an accumulator that is wrong by 100 x pass.)  The same selection runs green on the
 product library in the ordinary suite."""
@@ -52,6 +53,21 @@ def test_mutant_turns_the_parity_tests_red(mutants, k, tmp_path):
             must_fail, must_pass = FIRST_STEP[k]
             assert all(state[n] for n in must_fail), (k, {n: state[n] for n in must_fail})
             assert not any(state[n] for n in must_pass), (k, {n: state[n] for n in must_pass})
+
+
+EXACT_SELECTION = ['tests/test_gpu_exact_replicas.py::test_reduce_form_against_the_oracle_run_as_replicas[bprmax_constrained]',
+                   'tests/test_gpu_exact_replicas.py::test_mean_form_against_the_oracle_run_as_replicas[bprmax_constrained]']
+
+
+def test_mutant_5_turns_the_exact_replica_parity_red(mutants, tmp_path):
+    """The 1 / nranks factor of the joint update x 1.01 (REDUCE: the gradient scale; MEAN: the mean over the touching ranks): the
+    oracle-as-replicas tests of the forms that carry it must fail, the SUM form (no such factor) must still pass."""
+    for i, (sel, want_rc) in enumerate([(s_, 1) for s_ in EXACT_SELECTION] +
+                                       [('tests/test_gpu_exact_replicas.py::test_exact_mode_against_the_oracle_run_as_replicas[bprmax_constrained]', 0)]):
+        env = dict(os.environ, G4R_LIB=mutants[5], G4R_PARITY_REPORT=str(tmp_path / ('x%d.txt' % i)))
+        r = subprocess.run([sys.executable, '-m', 'pytest', sel, '-x', '-q', '-p', 'no:cacheprovider'], cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == want_rc, 'mutant 5 on %s: rc %d\n%s' % (sel, r.returncode, (r.stdout + r.stderr)[-3000:])
 
 
 def test_product_library_is_not_a_mutant():
