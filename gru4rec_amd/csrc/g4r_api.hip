@@ -543,10 +543,26 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
             G.p2n = slices(D, nct * nrt, m->n_cu / 2, 16, 64, env_int("G4R_P2_KS", 0), &G.p2k);
             G.ban = slices(D, nct * nrt, m->n_cu / 2, 32, 64, env_int("G4R_BA_KS", 0), &G.bak);
             const int nctb = cdiv(IN, 64);
-            G.bbn = slices(3 * D, nctb * nrt, (3 * m->n_cu) / 4, 32, 128, env_int("G4R_BB_KS", 0), &G.bbk);
+            G.bbn = slices(3 * D, nctb * nrt, m->n_cu, 32, 128, env_int("G4R_BB_KS", 0), &G.bbk);
             max_slots = std::max(max_slots, std::max(nct * nrt * std::max(G.p2n, G.ban), nctb * nrt * G.bbn));
             max_tiles = std::max(max_tiles, std::max(nct, nctb) * nrt);
         }
+        // dy of k_gru_bwd_bw as K-slice partial sums added up by its consumer (no in-launch join) where that consumer exists: the lower
+        // layer's k_gru_bwd_pre (not the fused backward), or -- layer 0 -- the row-finishing workgroups of k_dense_grad2.  G4R_BB_SLABS=0: join.
+        int dmax0 = 0;
+        for (int l = 0; l < L; ++l) dmax0 = std::max(dmax0, d.D[l]);
+        const bool wdense = (mask & 16) && wide_layer(dmax0) && !(cfg->embed_mode == G4R_EMBED_ONEHOT);
+        size_t dyp_floats = 0;
+        if (env_int("G4R_BB_SLABS", 1)) {
+            for (int l = 0; l < L; ++l) {
+                if (!(m->wg[l].use & 8) || m->wg[l].bbn > 16) continue;
+                const bool consumer = (l == 0) ? wdense : !fused_bwd(d, l - 1);
+                if (!consumer) continue;
+                d.bbn[l] = m->wg[l].bbn;
+                dyp_floats = std::max(dyp_floats, (size_t)d.bbn[l] * B * d.IN[l]);
+            }
+        }
+        if (dyp_floats) DA(d.dyp, dyp_floats);
         if (max_slots > 0) {
             DA(m->wk_ws, (size_t)max_slots * 4096);
             DA(m->wk_cnt, (size_t)max_tiles);
@@ -1040,7 +1056,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         end();
         begin(KN_BWD_B);
         if (l == 0 && d.embed_mode == G4R_EMBED_ONEHOT) LK(k_onehot_step, dim3(cdiv((long long)B * d.Ein, 4 * 256)), dim3(256), 0, s, dmp, stp);
-        else if (G.use & 8) LK(k_gru_bwd_bw, dim3(cdiv(d.IN[l], 64) * nrt64 * G.bbn), dim3(256), SMEM_T3, s, dmp, stp, l, m->wk_ws, m->wk_cnt, G.bbn, G.bbk);
+        else if (G.use & 8) LK(k_gru_bwd_bw, dim3(cdiv(d.IN[l], 64) * nrt64 * G.bbn), dim3(256), SMEM_T3, s, dmp, stp, l, m->wk_ws, m->wk_cnt, G.bbn, G.bbk, d.bbn[l] > 0 ? 1 : 0);
         else LK(k_gru_bwd_b, dim3(cdiv(d.IN[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_BB, s, dmp, stp, l);
         end();
     }
@@ -1068,7 +1084,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         if (d.apply_dense_inplace || part == 1) { HIPCHK(hipGetLastError()); return 0; }
     } else {
     begin(KN_DENSE);
-    if (m->wide_dense) LK(k_dense_grad2, dim3(m->ntiles64), dim3(256), SMEM_T2K, s, dmp, stp, (const DenseTile*)m->d_tiles64, m->ntiles64);
+    if (m->wide_dense) LK(k_dense_grad2, dim3(m->ntiles64 + (d.bbn[0] > 0 ? cdiv((long long)B * (d.IN[0] / 4), 256) : 0)), dim3(256), SMEM_T2K, s, dmp, stp, (const DenseTile*)m->d_tiles64, m->ntiles64);
     else if (m->dt == 0) LK(k_dense_grad<0>, dim3(m->ntiles), dim3(GT_NTH_FEW), SMEM_DIRECT, s, dmp, stp, (const DenseTile*)m->d_tiles);
     else LK(k_dense_grad<32>, dim3(m->ntiles), dim3(GT_NTH_FEW), SMEM_TN, s, dmp, stp, (const DenseTile*)m->d_tiles);
     end();

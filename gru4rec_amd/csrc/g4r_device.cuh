@@ -165,6 +165,11 @@ struct DevModel {
     long long xstride;
     int xn, xoffSx, xoffSy, xoffSBy;      // float offsets of dSx / dSy / dSBy inside a block (occ_idx sits at offset 0, as ints)
     int xmode, xoffDg;                      // g4r_config::sparse_exact when xn > 1 (1 SUM, 2 MEAN, 3 REDUCE form of the exact-replica mode), else 0
+    // wide layers (g4r_wide_kernels.cuh): dy = dV Wx^T of layer l leaves k_gru_bwd_bw as bbn[l] K-slice partial sums dyp[s][B][IN_l]
+    // (0: the layer's dy is complete where the consumer expects it); they are added up, in slice order, by the kernel that consumes
+    // dy anyway -- the lower layer's k_gru_bwd_pre, or (layer 0) the row-finishing workgroups of k_dense_grad2
+    GP(float) dyp;
+    int bbn[G4R_MAX_LAYERS];
 };
 
 // In-kernel phase traces (tools/clk*.py) exist only in builds made with G4R_BUILD_CLK=1 (-DG4R_CLK_TRACE): a test of a

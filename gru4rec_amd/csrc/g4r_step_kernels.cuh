@@ -1350,6 +1350,16 @@ __global__ __launch_bounds__(256) void k_gru_bwd_pre(const DevModel* __restrict_
 #pragma unroll
             for (int q = 0; q < 24; ++q) dh += (k0 + q < ks) ? v[q] : 0.f;      // fixed summation order
         }
+    } else if (m.bbn[l + 1] > 0) {
+        // the upper layer's dy arrives as K-slice partial sums of its k_gru_bwd_bw (<= 16 slices, one round trip, slice order)
+        const int nsl = m.bbn[l + 1];
+        const GAS float* pp = m.dyp + o;
+        const size_t ps = (size_t)B * D;
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = pp[(size_t)min(q, nsl - 1) * ps];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dh += (q < nsl) ? v[q] : 0.f;
     } else {
         dh = m.dyl[l][o];
     }

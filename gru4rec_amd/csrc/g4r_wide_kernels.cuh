@@ -219,7 +219,10 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_aw(const DevModel* __restric
 // Wx[n][k]: both K-contiguous -> gemm_tile3, `nsb` slices of `kss`.  The last arriver turns its accumulators around through LDS so
 // that a thread finishes four QUADS of consecutive columns (16-byte loads / stores of the accumulator rows, one Philox draw per quad
 // instead of one per element).
-__global__ __launch_bounds__(256, 2) void k_gru_bwd_bw(const DevModel* __restrict__ mp, StepState* st, int l, float* ws, unsigned* cnt, int nsb, int kss) {
+// slabs != 0: no join at all -- every slice stores its partial tile to dyp[slice][B][IN] and the kernel that consumes dy anyway adds the
+// slices up behind the kernel boundary (DevModel::bbn): the in-launch join measured ~7 us of write-through publish, ticket and re-read,
+// more than the K loop of a slice (profiles/r05_experiments.md)
+__global__ __launch_bounds__(256, 2) void k_gru_bwd_bw(const DevModel* __restrict__ mp, StepState* st, int l, float* ws, unsigned* cnt, int nsb, int kss, int slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const StepCtx c = load_ctx(st);
@@ -231,6 +234,16 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_bw(const DevModel* __restric
     if (m0 >= M) return;
     const GAS float* Wx = m.dense_p + m.offWx[l];
     const GAS float* dV = m.dV[l];
+    if (slabs) {
+        GAS float* dst = m.dyp + (size_t)w.s * B * IN;
+        auto arow = [&](int r) -> const GAS float* { return (m0 + r < M) ? dV + (size_t)(m0 + r) * D3 + ks : nullptr; };
+        auto brow = [&](int r) -> const GAS float* { return (n0 + r < IN) ? Wx + (size_t)(n0 + r) * D3 + ks : nullptr; };
+        auto epi = [&](int row, int n, float v, float4) {
+            if (row < M && n < IN) dst[(size_t)row * IN + n] = v;
+        };
+        gemm_tile3<G4R_WIDE_NST, 32, true>(m0, n0, Klen, arow, brow, m.zrow, NoPre(), epi, smem);
+        return;
+    }
     // epilogue ownership: rows m0 + (tid >> 4) + 16 i (i = 0..3), columns n0 + 4 (tid & 15) .. + 3
     const int er = tid >> 4, ec = n0 + 4 * (tid & 15);
     const bool cok = ec < IN;
@@ -300,30 +313,53 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_bw(const DevModel* __restric
 // single GPU, or the gradient -> dense_g for the all-reduce.  Against the 32 x 32 tiles of k_update (dense_grad_tile): half the
 // operand bytes per output, the 32x32x2 MFMA, operands two chunks ahead.  Runs as a launch of its own in front of the sparse row
 // update (at wide layers the two roles of k_update did not overlap anyway: DESIGN.md section 6).
+// Workgroups [ntiles, gridDim) finish the layer-0 input rows when k_gru_bwd_bw left dy as K-slice partial sums (DevModel::bbn[0] > 0):
+// one quad of dy per thread -- slices added in slice order, embedding-dropout mask, per-occurrence Adagrad pieces dSx / dAx (or the
+// accumulator in place for an item that occurs once: see k_gru_bwd_b) -- ahead of the sparse row update that consumes them.
 __global__ __launch_bounds__(256, 2) void k_dense_grad2(const DevModel* __restrict__ mp, StepState* st, const DenseTile* __restrict__ tiles_, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const GAS DenseTile* tiles = (const GAS DenseTile*)tiles_;
     const StepCtx c = load_ctx(st);
+    if ((int)blockIdx.x >= ntiles) {
+        const int IN = m.IN[0], nq = IN >> 2, nsl = m.bbn[0], B = m.B;
+        const int e = ((int)blockIdx.x - ntiles) * 256 + (int)threadIdx.x;
+        const int row = e / nq, c4 = 4 * (e - row * nq);
+        if (row >= c.M) return;
+        const int item = m.occ_idx[row];
+        const GAS float* pp = m.dyp + (size_t)row * IN + c4;
+        const size_t ps = (size_t)B * IN;
+        float4 v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = ld4(pp + (size_t)min(q, nsl - 1) * ps);
+        GAS float* accT = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.accWy : m.accE;
+        const float4 a0 = ld4_at(accT, (size_t)max(item, 0) * IN + c4, item >= 0);
+        const int cnt1 = m.occ_fl[4 * (((m.embed_mode == G4R_EMBED_CONSTRAINED) ? (size_t)0 : (size_t)m.n_items) + max(item, 0)) + 2];
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (q < nsl) { g.x += v[q].x; g.y += v[q].y; g.z += v[q].z; g.w += v[q].w; }
+        if (m.drop_e > 0.f) {
+            const float4 mk = drop_mult4(m.seed, (unsigned)c.g, G4R_STREAM_DROP_EMBED, row, c4 >> 2, 1.0f - m.drop_e);
+            g.x *= mk.x; g.y *= mk.y; g.z *= mk.z; g.w *= mk.w;
+        }
+        const size_t o = (size_t)row * IN + c4;
+        const float lr = m.lr;
+        const bool generic = m.generic != 0;
+        const float4 an = make_float4(a0.x + G4R_MUT_ACC(g.x * g.x), a0.y + G4R_MUT_ACC(g.y * g.y), a0.z + G4R_MUT_ACC(g.z * g.z), a0.w + G4R_MUT_ACC(g.w * g.w));
+        const float4 stp = generic ? g : make_float4(G4R_MUT_STEP(lr * g.x * frsq(an.x + G4R_EPS_ADAGRAD)), G4R_MUT_STEP(lr * g.y * frsq(an.y + G4R_EPS_ADAGRAD)),
+                                                     G4R_MUT_STEP(lr * g.z * frsq(an.z + G4R_EPS_ADAGRAD)), G4R_MUT_STEP(lr * g.w * frsq(an.w + G4R_EPS_ADAGRAD)));
+        st4(m.dSx + o, stp);
+        if (!generic && cnt1 == 1 && item >= 0) st4(accT + (size_t)item * IN + c4, an);
+        else st4(m.dAx + o, an);
+        return;
+    }
     const DenseTile tl = tiles[G4R_XCD_TILE(blockIdx.x, ntiles)];
     const int M = c.M, tid = threadIdx.x;
     const float lr = m.lr, momc = m.mom, lmbd = m.lmbd;
     const int inplace = m.apply_dense_inplace;
     GAS float *dp = m.dense_p, *dacc = m.dense_acc, *dvel = m.dense_vel, *dg = m.dense_g;
     const GAS float* dV = tl.dV;
-    auto apply = [&](size_t off, float g, float a0, float p0, float v0) {
-        if (!inplace) { dg[off] = g; return; }
-        const float acc = a0 + G4R_MUT_DACC(g * g);
-        dacc[off] = acc;
-        const float gs = g * frsq(acc + G4R_EPS_ADAGRAD);
-        if (momc > 0.f) {
-            const float v = momc * v0 - lr * (gs + lmbd * p0);
-            dvel[off] = v;
-            dp[off] = p0 + v;
-        } else {
-            dp[off] = p0 * (1.0f - lr * lmbd) - lr * gs;
-        }
-    };
     if (tl.nrows == 1) {
         // bias row: column sums of dV over the batch for 64 columns; thread (column tid & 63, row group tid >> 6)
         const int cl = tid & 63, grp = tid >> 6, col = tl.c0 + cl;
@@ -341,7 +377,20 @@ __global__ __launch_bounds__(256, 2) void k_dense_grad2(const DevModel* __restri
         }
         smem[grp * 64 + cl] = s;
         __syncthreads();
-        if (tid < 64 && cok) apply(off, (smem[cl] + smem[64 + cl]) + (smem[128 + cl] + smem[192 + cl]), a0, p0, v0);
+        if (tid < 64 && cok) {
+            const float g = (smem[cl] + smem[64 + cl]) + (smem[128 + cl] + smem[192 + cl]);
+            if (!inplace) { dg[off] = g; return; }
+            const float acc = a0 + G4R_MUT_DACC(g * g);            // gru4rec.py:330-334,390-406
+            dacc[off] = acc;
+            const float gs = g * frsq(acc + G4R_EPS_ADAGRAD);
+            if (momc > 0.f) {
+                const float v = momc * v0 - lr * (gs + lmbd * p0);
+                dvel[off] = v;
+                dp[off] = p0 + v;
+            } else {
+                dp[off] = p0 * (1.0f - lr * lmbd) - lr * gs;
+            }
+        }
         return;
     }
     const GAS float* X = tl.gather ? (const GAS float*)m.yin0 : ((c.g & 1) ? tl.X1 : tl.X0);
@@ -358,7 +407,18 @@ __global__ __launch_bounds__(256, 2) void k_dense_grad2(const DevModel* __restri
     };
     auto epi = [&](int row, int col, float g, float4 p) {
         if (row >= tl.nrows || col >= tl.ncols) return;
-        apply((size_t)tl.base + (size_t)row * tl.ldo + col, g, p.x, p.y, p.z);
+        const size_t off = (size_t)tl.base + (size_t)row * tl.ldo + col;
+        if (!inplace) { dg[off] = g; return; }
+        const float acc = p.x + G4R_MUT_DACC(g * g);            // gru4rec.py:330-334,390-406
+        dacc[off] = acc;
+        const float gs = g * frsq(acc + G4R_EPS_ADAGRAD);
+        if (momc > 0.f) {
+            const float v = momc * p.z - lr * (gs + lmbd * p.y);
+            dvel[off] = v;
+            dp[off] = p.y + v;
+        } else {
+            dp[off] = p.y * (1.0f - lr * lmbd) - lr * gs;
+        }
     };
     gemm_tile2k<true, false>(tl.r0, tl.c0, M, aptr, bptr, m.zrow, pre, epi, smem);
 }

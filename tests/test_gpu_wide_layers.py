@@ -73,7 +73,7 @@ def test_wide_kernels_against_the_oracle(name, tail):
     assert not errs, errs
 
 
-@pytest.mark.parametrize('mask', [1, 2, 4, 8, 16, 31])
+@pytest.mark.parametrize('mask', [1, 2, 4, 8, 16, 24, 31])
 def test_each_wide_kernel_against_the_kernel_it_replaces(mask):
     """One new kernel at a time (and all of them) next to the round-1 kernels on the same plan: the losses agree to summation order."""
     I, B, ns, T, kw = SHAPES['d512_b240_xe_logq_drop']
