@@ -105,7 +105,7 @@ def rocprof_means(config):
     if not os.path.exists(path):
         return {}
     out = {'__file__': os.path.relpath(path, ROOT)}
-    alias = {'k_gru_fwd_fused': 'k_gru_fwd', 'k_gru_bwd_fused': 'k_gru_bwd', 'k_score_bwd2': 'k_score_bwd', 'k_gru_p1w': 'k_gru_p1', 'k_gru_p2w': 'k_gru_p2',
+    alias = {'k_gru_fwd_fused': 'k_gru_fwd', 'k_gru_bwd_fused': 'k_gru_bwd', 'k_score_bwd2': 'k_score_bwd', 'k_gru_p1w': 'k_gru_p1', 'k_gru_p1s': 'k_gru_p1', 'k_gru_p2w': 'k_gru_p2',
              'k_gru_bwd_aw': 'k_gru_bwd_a', 'k_gru_bwd_bw': 'k_gru_bwd_b', 'k_dense_grad2': 'k_dense_grad'}
     acc = {}
     for r in csv.DictReader(open(path)):

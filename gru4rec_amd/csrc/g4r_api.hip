@@ -47,10 +47,10 @@ void g4r_set_error(const char* fmt, ...) {
     } while (0)
 
 enum { KN_GRU_P1 = 0, KN_GRU_P2, KN_SCORE_FWD, KN_LOSS, KN_SCORE_BWD, KN_BWD_PRE, KN_BWD_A, KN_BWD_B, KN_DENSE, KN_ALLREDUCE,
-       KN_DENSE_APPLY, KN_SPARSE, KN_UPDATE, KN_BWD_FUSED, KN_FWD_FUSED, KN_COMPACT, KN_COUNT };
+       KN_DENSE_APPLY, KN_SPARSE, KN_UPDATE, KN_BWD_FUSED, KN_FWD_FUSED, KN_COMPACT, KN_GATE, KN_COUNT };
 static const char* KN_NAMES[KN_COUNT] = {"k_gru_p1", "k_gru_p2", "k_score_fwd", "k_loss_rows", "k_score_bwd", "k_gru_bwd_pre",
                                          "k_gru_bwd_a", "k_gru_bwd_b", "k_dense_grad", "rccl_allreduce", "k_dense_apply",
-                                         "k_sparse_update", "k_update", "k_gru_bwd", "k_gru_fwd", "k_compact_sy"};
+                                         "k_sparse_update", "k_update", "k_gru_bwd", "k_gru_fwd", "k_compact_sy", "k_gru_gate"};
 
 struct EvRec { int kn; hipEvent_t a, b; };
 
@@ -91,7 +91,7 @@ struct g4r_model {
     bool loss_long = false;      // k_loss_rows<true>: score rows too long for two LDS copies
     // wide layers (g4r_wide_kernels.cuh): per layer which kernels run (bit 1 k_gru_p1w, 2 k_gru_p2w, 4 k_gru_bwd_aw, 8 k_gru_bwd_bw) and
     // their K-slice geometry; bit 16 of wide_mask: the 64 x 64 dense-gradient tiles (k_dense_grad2) for the whole model
-    struct WideGeo { int use = 0, ny = 1, nh = 1, kys = 0, khs = 0, p2n = 1, p2k = 0, ban = 1, bak = 0, bbn = 1, bbk = 0; };
+    struct WideGeo { int use = 0, ny = 1, nh = 1, kys = 0, khs = 0, p2n = 1, p2k = 0, ban = 1, bak = 0, bbn = 1, bbk = 0, p1slab = 0; };
     WideGeo wg[G4R_MAX_LAYERS];
     bool wide_dense = false;
     float* wk_ws = nullptr;      // split-K partial sums: [tile][slice][4096] floats (shared by the kernels: they run one after the other)
@@ -507,7 +507,15 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     // dozen 64 x 64 tiles; a workgroup's latency hardly depends on its slice length until the chip is full), overridable for A/B runs:
     // G4R_P1_KS / G4R_P2_KS / G4R_BA_KS / G4R_BB_KS.
     {
-        const int mask = env_int("G4R_WIDE2", 0);
+        // default ("auto", -1), from the A/B runs of round 5 (profiles/r05_experiments.md): the kernels that need no in-launch join --
+        // phase 1 as K-slice partial sums + k_gru_gate (1), dy as partial sums added up by its consumer (8) -- plus the 64 x 64
+        // dense-gradient tiles as a launch of their own (16) where the dense gradients outweigh the sparse rows (6 D >= 2 B + n_sample:
+        // BASELINE configs[2] yes, configs[3] no -- there the merged k_update overlaps its two roles and stays)
+        const int mask_env = env_int("G4R_WIDE2", -1);
+        int dmax_ = 0;
+        for (int l = 0; l < L; ++l) dmax_ = std::max(dmax_, d.D[l]);
+        const int mask = mask_env >= 0 ? mask_env : (1 | 8 | (6 * dmax_ >= d.R ? 16 : 0));
+        const bool automask = mask_env < 0;
         const int nrt = cdiv(B, 64);
         int max_slots = 0, max_tiles = 0;
         // slices of a K range: the fewest (longest) that bring tiles * slices to `want` workgroups, of at least `min_len`, multiples of `gran`
@@ -529,12 +537,17 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
             // phase 1: 3 nct column tiles over K = IN (+ D for the r / z columns): one slice length for both parts
             {
                 const int forced = env_int("G4R_P1_KS", 0);
-                int ks = 512;
-                for (; ks > 128; ks >>= 1) {
+                // partial sums (no join): short slices -- a slice is a bare GEMM, four or five of its workgroups share a CU and overlap
+                // each other's barriers; joined (G4R_P1_JOIN=1, tests): the longest slice that still fills 3/4 of the CUs
+                G.p1slab = env_int("G4R_P1_JOIN", 0) ? 0 : 1;
+                int ks = G.p1slab ? 128 : 512;
+                for (; !G.p1slab && ks > 128; ks >>= 1) {
                     const int ny = cdiv(IN, ks), nh = cdiv(D, ks);
                     if (nct * nrt * (3 * ny + 2 * nh) >= (3 * m->n_cu) / 4) break;
                 }
+                if (G.p1slab) while (cdiv(IN, ks) > 8 || cdiv(IN, ks) + cdiv(D, ks) > 16) ks += 64;      // k_gru_gate adds up <= 8 / 16 slices
                 if (forced > 0) ks = std::min(512, std::max(16, forced / 16 * 16));
+                if (G.p1slab && (cdiv(IN, ks) > 8 || cdiv(IN, ks) + cdiv(D, ks) > 16)) G.p1slab = 0;
                 G.ny = cdiv(IN, ks); G.kys = ((cdiv(IN, G.ny) + 15) / 16) * 16; G.ny = cdiv(IN, G.kys);
                 G.nh = cdiv(D, ks); G.khs = ((cdiv(D, G.nh) + 15) / 16) * 16; G.nh = cdiv(D, G.khs);
                 max_slots = std::max(max_slots, 3 * nct * nrt * (G.ny + G.nh));
@@ -552,17 +565,21 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         int dmax0 = 0;
         for (int l = 0; l < L; ++l) dmax0 = std::max(dmax0, d.D[l]);
         const bool wdense = (mask & 16) && wide_layer(dmax0) && !(cfg->embed_mode == G4R_EMBED_ONEHOT);
-        size_t dyp_floats = 0;
-        if (env_int("G4R_BB_SLABS", 1)) {
-            for (int l = 0; l < L; ++l) {
-                if (!(m->wg[l].use & 8) || m->wg[l].bbn > 16) continue;
-                const bool consumer = (l == 0) ? wdense : !fused_bwd(d, l - 1);
-                if (!consumer) continue;
-                d.bbn[l] = m->wg[l].bbn;
-                dyp_floats = std::max(dyp_floats, (size_t)d.bbn[l] * B * d.IN[l]);
+        size_t dyp_floats = 0, vp_floats = 0;
+        for (int l = 0; l < L; ++l) {
+            if (!(m->wg[l].use & 8)) continue;
+            const bool consumer = env_int("G4R_BB_SLABS", 1) && m->wg[l].bbn <= 16 && ((l == 0) ? wdense : !fused_bwd(d, l - 1));
+            if (!consumer) {
+                if (automask) m->wg[l].use &= ~8;      // (default policy: nobody to add the partial sums up -> the round-1 kernel, not the joined one)
+                continue;
             }
+            d.bbn[l] = m->wg[l].bbn;
+            dyp_floats = std::max(dyp_floats, (size_t)d.bbn[l] * B * d.IN[l]);
         }
+        for (int l = 0; l < L; ++l)
+            if ((m->wg[l].use & 1) && m->wg[l].p1slab) vp_floats = std::max(vp_floats, (size_t)(m->wg[l].ny + m->wg[l].nh) * B * 3 * d.D[l]);
         if (dyp_floats) DA(d.dyp, dyp_floats);
+        if (vp_floats) DA(d.vp, vp_floats);
         if (max_slots > 0) {
             DA(m->wk_ws, (size_t)max_slots * 4096);
             DA(m->wk_cnt, (size_t)max_tiles);
@@ -990,7 +1007,12 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         const g4r_model::WideGeo& G = m->wg[l];
         const int nrt64 = cdiv(B, 64), nct64 = d.D[l] / 64;
         begin(KN_GRU_P1);
-        if (G.use & 1) LK(k_gru_p1w, dim3(nct64 * nrt64 * (3 * G.ny + 2 * G.nh)), dim3(256), SMEM_T2K, s, dmp, stp, l, l == 0 ? 1 : 0, m->wk_ws, m->wk_cnt, G.ny, G.nh, G.kys, G.khs);
+        if ((G.use & 1) && G.p1slab) {
+            LK(k_gru_p1s, dim3(nct64 * nrt64 * (3 * G.ny + 2 * G.nh)), dim3(256), SMEM_T2K, s, dmp, stp, l, l == 0 ? 1 : 0, G.ny, G.nh, G.kys, G.khs);
+            end();
+            begin(KN_GATE);
+            LK(k_gru_gate, dim3(cdiv((long long)B * (d.D[l] / 4), 256)), dim3(256), 0, s, dmp, stp, l, G.ny, G.nh);
+        } else if (G.use & 1) LK(k_gru_p1w, dim3(nct64 * nrt64 * (3 * G.ny + 2 * G.nh)), dim3(256), SMEM_T2K, s, dmp, stp, l, l == 0 ? 1 : 0, m->wk_ws, m->wk_cnt, G.ny, G.nh, G.kys, G.khs);
         else if (wide_layer(d.D[l])) LK(k_gru_p1_n64, dim3(cdiv(3 * d.D[l], 64), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1_N64, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
         else LK(k_gru_p1_n32, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
         end();

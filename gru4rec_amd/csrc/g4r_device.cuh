@@ -170,6 +170,7 @@ struct DevModel {
     // dy anyway -- the lower layer's k_gru_bwd_pre, or (layer 0) the row-finishing workgroups of k_dense_grad2
     GP(float) dyp;
     int bbn[G4R_MAX_LAYERS];
+    GP(float) vp;        // K-slice partial sums of GRU phase 1, vp[slice][B][3D] (k_gru_p1s -> k_gru_gate)
 };
 
 // In-kernel phase traces (tools/clk*.py) exist only in builds made with G4R_BUILD_CLK=1 (-DG4R_CLK_TRACE): a test of a

@@ -2792,7 +2792,10 @@ __global__ __launch_bounds__(SP_WAVES * 64, MAXCH == 1 ? 4 : 2) void k_sparse_up
         const OptOut o = opt_rule(adapt, v1, v3, false, ba0, bu0, bc0, bS, bQ, bT1, bgk, fb);
         const float reg = (lmbd > 0.f) ? lmbd * bp0 : 0.f;
         const float dsum = lr * (o.G + fb * reg);
-        m.accBy[item] = (xmean && adagrad) ? o.A + bAadd : o.A;
+        // MEAN form: pre-step value + the ranks' last-occurrence increments.  bAadd holds those of the bias hits of the scan; the owner's
+        // own (o.A - ba0) joins them only when the owner IS a bias occurrence -- otherwise the last bias hit is already in bAadd (round 4
+        // added it twice: found by the oracle-as-replicas test of this form)
+        m.accBy[item] = (xmean && adagrad) ? (bias_own ? o.A + bAadd : ba0 + bAadd) : o.A;
         if (m.acc2By) m.acc2By[item] = o.U;
         if (m.cntBy) m.cntBy[item] = o.C;
         const float inc = mom ? (fb * (momc * bw0) - dsum) : -dsum;

@@ -36,9 +36,11 @@ __device__ __forceinline__ WideItem wide_item(int idx, int nsplit, int nrt) {
 // columns have no hidden part here -- theirs is (H r) Wh, phase 2).  B = rows of Wx / Wrz ([k][n], K-major).
 // Embedding dropout: the Philox masks of a thread's staging slots (one quad per 16-deep chunk: row tid >> 2, k offset 4 (tid & 3))
 // are drawn up front, next to the first operand requests, as 4 bits per chunk.
-__global__ __launch_bounds__(256, 2) void k_gru_p1w(const DevModel* __restrict__ mp, StepState* st, int l, int first, float* ws, unsigned* cnt,
-                                                    int ny, int nh, int kys, int khs) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// SLAB: no join -- every slice stores its partial tile to vp[slice][B][3D] and k_gru_gate (the next launch) adds the slices up and
+// applies the gates; the kernel then is a bare GEMM: no epilogue operands, no join buffers, half the registers (more workgroups per CU).
+template <bool SLAB>
+__device__ __forceinline__ void gru_p1w_body(const DevModel* __restrict__ mp, StepState* st, int l, int first, float* ws, unsigned* cnt,
+                                             int ny, int nh, int kys, int khs, float* smem) {
     const DevModel& m = *mp;
     const int tid = threadIdx.x;
     const StepCtx c = first ? load_ctx_first(st) : load_ctx(st);
@@ -136,8 +138,62 @@ __global__ __launch_bounds__(256, 2) void k_gru_p1w(const DevModel* __restrict__
         }
         zb[(size_t)row * D + (n - 2 * D)] = sigmoidf_(v);
     };
-    const SplitKJoin join = {ws, cnt, w.ct * nrt + w.rt, s, nsplit, ny + nh};
-    gemm_tile2k<false, false>(m0, n0, Klen, aprov, bprov, m.zrow, pre, epi, smem, nullptr, join, afix);
+    if constexpr (SLAB) {
+        GAS float* dst = m.vp + (size_t)s * B * D3;
+        auto epis = [&](int row, int n, float v, float4) {
+            if (row < M) dst[(size_t)row * D3 + n] = v;
+        };
+        gemm_tile2k<false, true>(m0, n0, Klen, aprov, bprov, m.zrow, NoPre(), epis, smem, nullptr, NoJoin(), afix);
+    } else {
+        const SplitKJoin join = {ws, cnt, w.ct * nrt + w.rt, s, nsplit, ny + nh};
+        gemm_tile2k<false, false>(m0, n0, Klen, aprov, bprov, m.zrow, pre, epi, smem, nullptr, join, afix);
+    }
+}
+__global__ __launch_bounds__(256, 2) void k_gru_p1w(const DevModel* __restrict__ mp, StepState* st, int l, int first, float* ws, unsigned* cnt,
+                                                    int ny, int nh, int kys, int khs) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gru_p1w_body<false>(mp, st, l, first, ws, cnt, ny, nh, kys, khs, smem);
+}
+__global__ __launch_bounds__(256, 4) void k_gru_p1s(const DevModel* __restrict__ mp, StepState* st, int l, int first, int ny, int nh, int kys, int khs) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gru_p1w_body<true>(mp, st, l, first, nullptr, nullptr, ny, nh, kys, khs, smem);
+}
+
+// The gates behind k_gru_p1s (gru4rec.py:472-475): one quad of hidden units per thread -- K-slice partial sums of V added in slice order
+// (candidate columns: the ny input slices; r / z columns: ny + nh), bias, r = sigmoid, Hr = H r, z = sigmoid; Vc / r / Hr / z to where
+// k_gru_p2 and the backward kernels expect them.
+__global__ __launch_bounds__(256) void k_gru_gate(const DevModel* __restrict__ mp, StepState* st, int l, int ny, int nh) {
+    const DevModel& m = *mp;
+    const StepCtx c = load_ctx(st);
+    const int D = m.D[l], D3 = 3 * D, nq = D >> 2, B = m.B, ns = ny + nh;
+    const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int row = e / nq, d = 4 * (e - row * nq);
+    if (row >= c.M) return;
+    const GAS float* pp = m.vp + (size_t)row * D3 + d;
+    const size_t ps = (size_t)B * D3;
+    const GAS float* Bh = m.dense_p + m.offBh[l];
+    float4 vc[8], vr[16], vz[16];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) vc[q] = ld4(pp + (size_t)min(q, ny - 1) * ps);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { vr[q] = ld4(pp + (size_t)min(q, ns - 1) * ps + D); vz[q] = ld4(pp + (size_t)min(q, ns - 1) * ps + 2 * D); }
+    const float4 bc = ld4(Bh + d), br = ld4(Bh + D + d), bz = ld4(Bh + 2 * D + d);
+    const size_t o = (size_t)row * D + d;
+    const float4 h = ld4(m.H[l][c.g & 1] + o);
+    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sr = sc, sz = sc;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (q < ny) { sc.x += vc[q].x; sc.y += vc[q].y; sc.z += vc[q].z; sc.w += vc[q].w; }
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        if (q < ns) {
+            sr.x += vr[q].x; sr.y += vr[q].y; sr.z += vr[q].z; sr.w += vr[q].w;
+            sz.x += vz[q].x; sz.y += vz[q].y; sz.z += vz[q].z; sz.w += vz[q].w;
+        }
+    const float4 r = make_float4(sigmoidf_(sr.x + br.x), sigmoidf_(sr.y + br.y), sigmoidf_(sr.z + br.z), sigmoidf_(sr.w + br.w));
+    st4(m.Vc[l] + o, make_float4(sc.x + bc.x, sc.y + bc.y, sc.z + bc.z, sc.w + bc.w));
+    st4(m.r[l] + o, r);
+    st4(m.Hr[l] + o, make_float4(h.x * r.x, h.y * r.y, h.z * r.z, h.w * r.w));
+    st4(m.z[l] + o, make_float4(sigmoidf_(sz.x + bz.x), sigmoidf_(sz.y + bz.y), sigmoidf_(sz.z + bz.z), sigmoidf_(sz.w + bz.w)));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

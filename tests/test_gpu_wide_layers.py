@@ -1,5 +1,6 @@
-"""The split-K kernels of wide GRU layers (gru4rec_amd/csrc/g4r_wide_kernels.cuh: k_gru_p1w / k_gru_p2w / k_gru_bwd_aw / k_gru_bwd_bw /
-k_dense_grad2, joined inside the launch by the tile's last arriver) against the oracle, against the round-1 kernels they replace
+"""The split-K kernels of wide GRU layers (gru4rec_amd/csrc/g4r_wide_kernels.cuh: k_gru_p1s + k_gru_gate / k_gru_p1w / k_gru_p2w /
+k_gru_bwd_aw / k_gru_bwd_bw / k_dense_grad2; K slices joined inside the launch by the tile's last arriver, or left as partial sums that the
+consuming kernel adds up) against the oracle, against the round-1 kernels they replace
 (G4R_WIDE2=0; the switch is read per model), one kernel at a time, and against themselves (graph replay == eager launches, bit for
 bit: the join adds the slices in slice order whatever the arrival order).
 
@@ -73,14 +74,17 @@ def test_wide_kernels_against_the_oracle(name, tail):
     assert not errs, errs
 
 
-@pytest.mark.parametrize('mask', [1, 2, 4, 8, 16, 24, 31])
+@pytest.mark.parametrize('mask', [1, 101, 2, 4, 8, 16, 24, 31, -1])
 def test_each_wide_kernel_against_the_kernel_it_replaces(mask):
-    """One new kernel at a time (and all of them) next to the round-1 kernels on the same plan: the losses agree to summation order."""
+    """One new kernel at a time (and all of them; -1: the default policy; 101: phase 1 in its joined form instead of partial sums +
+    k_gru_gate) next to the round-1 kernels on the same plan: the losses agree to summation order."""
     I, B, ns, T, kw = SHAPES['d512_b240_xe_logq_drop']
     runs = {}
     for mk in (0, mask):
-        with _env(G4R_WIDE2=mk):
+        with _env(G4R_WIDE2=None if mk < 0 else mk % 100, G4R_P1_JOIN=1 if mk > 100 else None):
             o, m = make_pair(I, B, ns, store_rows=T + 2, **kw)
+            if mk != 0:
+                assert m.get_debug('wide_mask', 1)[0] != 0
         plan = _plan(I, B, T, o, tail=True)
         m.set_plan(plan)
         m.train_steps(0, T)
