@@ -672,3 +672,65 @@ __device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, 
     for (int j = 0; j < 16; ++j) epi(m0 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3), n, acc[j], pf[PRE_COL ? 0 : j]);
     if (trc && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[4] = wall_clock64(); }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// gemm_tile2k's tile for SHORT K slices (K <= 16 NCH, NCH <= 8): the whole slice of both operands is requested up front -- 2 NCH quads
+// per thread, plain loads in chunk order, so the compiler's own counted waits release chunk after chunk as they land -- and then only
+// committed chunk by chunk through the double-buffered LDS tile.  What the split-K kernels without an in-launch join want (a slice
+// is a bare GEMM, several of its workgroups share a CU): one memory round trip per workgroup instead of one per two chunks -- the
+// A rows of GRU phase 1 are gathered rows of a multi-GB table, ~2 us away, and gemm_tile2k's two-chunks-ahead pipeline paid that
+// latency every second chunk (k_gru_p1s at D = 512: 19 us).  No asm loads: nothing to audit.
+// A K-contiguous (row pointers, `afix(chunk, quad, ok)` on the way to LDS), B K-major (`bprov(kk, kr, kc)` per chunk), as gemm_tile2k<false>.
+template <int NCH, class AProv, class BProv, class Epi, class AFix = NoFix2k>
+__device__ __forceinline__ void gemm_tile2k_full(int m0, int n0, int K, AProv aprov, BProv bprov, const GAS float* safe, Epi epi, float* smem, AFix afix = AFix()) {
+    static_assert(NCH >= 1 && NCH <= 8, "slice length");
+    constexpr int BK = 16, BUF = 64 * BK;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1, l32 = lane & 31, lh = lane >> 5;
+    const int kr = tid >> 4, kc = 4 * (tid & 15);                 // K-major staging slot: k row kr, columns kc .. kc + 3
+    const int kofs = kr * 64 + (kc ^ (32 * (kr & 1)));
+    const int sr = tid >> 2, sc = 4 * (tid & 3);                  // K-contiguous staging slot of A: row sr, k offset sc
+    const int sw_st = 2 * ((sr >> 2) & 7);
+    const int nchunk = (K + BK - 1) / BK;
+    const GAS float* a = aprov(sr);
+    const bool oka = a != nullptr;
+    const GAS float* pa = oka ? a + sc : safe;
+    float4 ra[NCH], rb[NCH];
+    bool ob[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const bool live = i < nchunk;
+        ra[i] = ld4((oka && live) ? pa + i * BK : safe);
+        const GAS float* b_ = live ? bprov(i * BK, kr, kc) : nullptr;
+        ob[i] = b_ != nullptr;
+        rb[i] = ld4(b_ ? b_ : safe);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    const int sw_fr = 2 * ((l32 >> 2) & 7);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        if (i < nchunk) {                                         // (workgroup-uniform)
+            const int buf = i & 1;
+            float4 va = oka ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            va = afix(i, va, oka);
+            const float4 vb = ob[i] ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float2* da = reinterpret_cast<float2*>(smem + buf * BUF + sr * BK + (sc ^ (sw_st & ~3)));
+            da[(sw_st >> 1) & 1] = make_float2(va.x, va.y); da[((sw_st >> 1) & 1) ^ 1] = make_float2(va.z, va.w);
+            *reinterpret_cast<float4*>(smem + (2 + buf) * BUF + kofs) = vb;
+            __syncthreads();                                      // chunk i is in buffer i & 1 (and nobody reads the other buffer any more: its readers passed the previous barrier)
+            const float* fa = smem + buf * BUF + (wm * 32 + l32) * BK + lh;
+            const float* fb = smem + (2 + buf) * BUF + lh * 64 + ((wn * 32 + l32) ^ (32 * lh));
+            float av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { av[u] = fa[(2 * u) ^ sw_fr]; bv[u] = fb[128 * u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = mfma32(av[u], bv[u], acc);
+        }
+    }
+    const int n = n0 + wn * 32 + l32;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) epi(m0 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3), n, acc[j], z4);
+}

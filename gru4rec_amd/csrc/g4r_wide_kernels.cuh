@@ -143,7 +143,8 @@ __device__ __forceinline__ void gru_p1w_body(const DevModel* __restrict__ mp, St
         auto epis = [&](int row, int n, float v, float4) {
             if (row < M) dst[(size_t)row * D3 + n] = v;
         };
-        gemm_tile2k<false, true>(m0, n0, Klen, aprov, bprov, m.zrow, NoPre(), epis, smem, nullptr, NoJoin(), afix);
+        if (Klen <= 128) gemm_tile2k_full<8>(m0, n0, Klen, aprov, bprov, m.zrow, epis, smem, afix);      // the default geometry: the whole slice in flight at once
+        else gemm_tile2k<false, true>(m0, n0, Klen, aprov, bprov, m.zrow, NoPre(), epis, smem, nullptr, NoJoin(), afix);
     } else {
         const SplitKJoin join = {ws, cnt, w.ct * nrt + w.rt, s, nsplit, ny + nh};
         gemm_tile2k<false, false>(m0, n0, Klen, aprov, bprov, m.zrow, pre, epi, smem, nullptr, join, afix);
