@@ -725,8 +725,12 @@ __device__ __forceinline__ void gemm_tile2k_full(int m0, int n0, int K, AProv ap
             float av[8], bv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { av[u] = fa[(2 * u) ^ sw_fr]; bv[u] = fb[128 * u]; }
+#if defined(G4R_P1S_DBG) && (G4R_P1S_DBG & 8)
+            acc[0] += av[0] * bv[0] + av[7] * bv[7];
+#else
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc = mfma32(av[u], bv[u], acc);
+#endif
         }
     }
     const int n = n0 + wn * 32 + l32;

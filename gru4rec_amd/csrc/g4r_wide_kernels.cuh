@@ -84,6 +84,9 @@ __device__ __forceinline__ void gru_p1w_body(const DevModel* __restrict__ mp, St
         const int row = m0 + r;
         if (row >= M) return nullptr;
         if (!ysl) return Hcur + (size_t)row * D + ks;
+#if defined(G4R_P1S_DBG) && (G4R_P1S_DBG & 2)
+        if (l == 0) return Hcur + (size_t)row * D + ks;
+#endif
         if (l == 0) return table + (size_t)gidx[row] * IN + ks;
         return ysrc + (size_t)row * IN + ks;
     };
@@ -94,7 +97,11 @@ __device__ __forceinline__ void gru_p1w_body(const DevModel* __restrict__ mp, St
     };
     // dropout bits of this thread's staging slots: chunk i < 16 in dm0, else in dm1 (host: a y slice is <= 512 units)
     const int sr = tid >> 2, sc = 4 * (tid & 3);
+#if defined(G4R_P1S_DBG) && (G4R_P1S_DBG & 4)
+    const bool dropping = false;
+#else
     const bool dropping = ysl && l == 0 && m.drop_e > 0.f;
+#endif
     const float retain = 1.0f - m.drop_e, inv_retain = 1.0f / retain;
     unsigned long long dm0 = ~0ull, dm1 = ~0ull;
     if (dropping) {
@@ -141,6 +148,9 @@ __device__ __forceinline__ void gru_p1w_body(const DevModel* __restrict__ mp, St
     if constexpr (SLAB) {
         GAS float* dst = m.vp + (size_t)s * B * D3;
         auto epis = [&](int row, int n, float v, float4) {
+#if defined(G4R_P1S_DBG) && (G4R_P1S_DBG & 1)
+            if (v == 123.456f)
+#endif
             if (row < M) dst[(size_t)row * D3 + n] = v;
         };
         if (Klen <= 128) gemm_tile2k_full<8>(m0, n0, Klen, aprov, bprov, m.zrow, epis, smem, afix);      // the default geometry: the whole slice in flight at once
