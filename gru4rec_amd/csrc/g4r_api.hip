@@ -89,14 +89,11 @@ struct g4r_model {
     unsigned* sk_flags = nullptr;
     size_t smem_sk = 0;
     bool loss_long = false;      // k_loss_rows<true>: score rows too long for two LDS copies
-    // wide layers (g4r_wide_kernels.cuh): per layer which kernels run (bit 1 k_gru_p1w, 2 k_gru_p2w, 4 k_gru_bwd_aw, 8 k_gru_bwd_bw) and
-    // their K-slice geometry; bit 16 of wide_mask: the 64 x 64 dense-gradient tiles (k_dense_grad2) for the whole model
-    struct WideGeo { int use = 0, ny = 1, nh = 1, kys = 0, khs = 0, p2n = 1, p2k = 0, ban = 1, bak = 0, bbn = 1, bbk = 0, p1slab = 0; };
+    // wide layers (g4r_wide_kernels.cuh): per layer which kernels run (bit 1 k_gru_p1s + k_gru_gate, 8 k_gru_bwd_bw) and their K-slice
+    // geometry; wide_dense: the 64 x 64 dense-gradient tiles (k_dense_grad2, mask bit 16) as a launch of their own for the whole model
+    struct WideGeo { int use = 0, ny = 1, nh = 1, kys = 0, khs = 0, bbn = 1, bbk = 0; };
     WideGeo wg[G4R_MAX_LAYERS];
     bool wide_dense = false;
-    float* wk_ws = nullptr;      // split-K partial sums: [tile][slice][4096] floats (shared by the kernels: they run one after the other)
-    unsigned* wk_cnt = nullptr;  // [tile] arrival counters
-    int wk_ntile = 0;
     DenseTile* d_tiles64 = nullptr;
     int ntiles64 = 0;
     float* d_tmpH = nullptr;
@@ -240,7 +237,7 @@ static inline bool score_fwd_dma(const DevModel& d) {
 }
 static const size_t SMEM_SF = tile_smem<SF_BM, GT_BN, GT_BK, false, true>() + GT_BN * sizeof(int);
 static const size_t SMEM_T2K = (size_t)(4 * 64 * 16) * sizeof(float);                               // gemm_tile2k: two 16-deep buffers per operand
-static const size_t SMEM_T3 = (size_t)Tile3Cfg<G4R_WIDE_NST, 32>::SMEM_FLOATS * sizeof(float);                 // gemm_tile3: ring of three 32-deep stages
+static const size_t SMEM_T3 = (size_t)Tile3Cfg<3, 32>::SMEM_FLOATS * sizeof(float);                 // gemm_tile3: ring of three 32-deep stages
 // publish the host descriptor to the device copy (stream-ordered; pageable source is staged before return)
 static int sync_dm(g4r_model* m) {
     HIPCHK(hipMemcpyAsync(m->d_dm, &m->dm, sizeof(DevModel), hipMemcpyHostToDevice, m->stream));
@@ -501,93 +498,58 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         }
         if (hipStreamSynchronize(m->stream) != hipSuccess) { g4r_destroy(m); return fail("sync"); }
     }
-    // wide layers: split-K kernels of g4r_wide_kernels.cuh.  G4R_WIDE2 (read per model: tests and A/B runs toggle it between models)
-    // is a bit mask -- 1 k_gru_p1w, 2 k_gru_p2w, 4 k_gru_bwd_aw, 8 k_gru_bwd_bw, 16 k_dense_grad2 -- default all (31); 0 = the round-1
-    // kernels.  Slice lengths: the longest one that still gives the launch enough workgroups (the product of a wide layer is a few
-    // dozen 64 x 64 tiles; a workgroup's latency hardly depends on its slice length until the chip is full), overridable for A/B runs:
-    // G4R_P1_KS / G4R_P2_KS / G4R_BA_KS / G4R_BB_KS.
+    // wide layers: the K-sliced kernels of g4r_wide_kernels.cuh.  G4R_WIDE2 (read per model: tests and A/B runs toggle it between
+    // models) is a bit mask -- 1 k_gru_p1s + k_gru_gate, 8 k_gru_bwd_bw, 16 k_dense_grad2; 0 = the round-1 kernels -- default: the policy
+    // below, from the A/B runs of round 5 (profiles/r05_experiments.md):
+    //   16  the 64 x 64 dense-gradient tiles as a launch of their own where the dense gradients outweigh the sparse rows
+    //       (6 D >= 2 B + n_sample: BASELINE configs[2] yes -- k_update 24.4 us as one launch, 17.7 + 7.5 as two; configs[3] shape no --
+    //       20.6 merged, 20.3 + 13.4 apart: there the merged launch overlaps its two roles)
+    //    8  dy as K-slice partial sums wherever a consumer adds them up: the lower layer's k_gru_bwd_pre (any layer above an unfused
+    //       one), or for layer 0 the row-finishing workgroups of k_dense_grad2, i.e. with 16 (17.5 -> 7.0 us at configs[2])
+    //    1  phase 1 as partial sums + k_gru_gate from D = 512 on (25.0 -> 18.3 + 4.5 us at configs[2]; D = 256: 13.9 -> 12.9 + 4.3, off)
+    // K-slice lengths for A/B runs: G4R_P1_KS (<= 128), G4R_BB_KS.
     {
-        // default ("auto", -1), from the A/B runs of round 5 (profiles/r05_experiments.md): the kernels that need no in-launch join --
-        // phase 1 as K-slice partial sums + k_gru_gate (1), dy as partial sums added up by its consumer (8) -- plus the 64 x 64
-        // dense-gradient tiles as a launch of their own (16) where the dense gradients outweigh the sparse rows (6 D >= 2 B + n_sample:
-        // BASELINE configs[2] yes, configs[3] no -- there the merged k_update overlaps its two roles and stays)
         const int mask_env = env_int("G4R_WIDE2", -1);
         int dmax_ = 0;
         for (int l = 0; l < L; ++l) dmax_ = std::max(dmax_, d.D[l]);
-        const int mask = mask_env >= 0 ? mask_env : (1 | 8 | (6 * dmax_ >= d.R ? 16 : 0));
         const bool automask = mask_env < 0;
+        const int mask = automask ? (1 | 8 | (6 * dmax_ >= d.R ? 16 : 0)) : mask_env;
         const int nrt = cdiv(B, 64);
-        int max_slots = 0, max_tiles = 0;
-        // slices of a K range: the fewest (longest) that bring tiles * slices to `want` workgroups, of at least `min_len`, multiples of `gran`
-        auto slices = [&](int K, int tiles, int want, int gran, int min_len, int forced, int* len) {
-            int n = std::max(1, cdiv(want, std::max(tiles, 1)));
-            n = std::min(n, std::max(1, K / min_len));
-            int ks = ((cdiv(K, n) + gran - 1) / gran) * gran;
-            if (forced > 0) ks = std::max(gran, (forced / gran) * gran);
-            *len = ks;
-            return cdiv(K, ks);
-        };
+        const bool wdense = (mask & 16) && wide_layer(dmax_) && !(cfg->embed_mode == G4R_EMBED_ONEHOT);
+        size_t dyp_floats = 0, vp_floats = 0;
         for (int l = 0; l < L; ++l) {
             const int D = d.D[l], IN = d.IN[l];
             g4r_model::WideGeo& G = m->wg[l];
             const bool ok = wide_layer(D) && D % 64 == 0 && IN % 16 == 0 && IN >= 64 && !(l == 0 && cfg->embed_mode == G4R_EMBED_ONEHOT);
-            if (!ok || !(mask & 15)) continue;
-            G.use = mask & 15;
-            const int nct = D / 64;
-            // phase 1: 3 nct column tiles over K = IN (+ D for the r / z columns): one slice length for both parts
-            {
-                const int forced = env_int("G4R_P1_KS", 0);
-                // partial sums (no join): short slices -- a slice is a bare GEMM, four or five of its workgroups share a CU and overlap
-                // each other's barriers; joined (G4R_P1_JOIN=1, tests): the longest slice that still fills 3/4 of the CUs
-                G.p1slab = env_int("G4R_P1_JOIN", 0) ? 0 : 1;
-                int ks = G.p1slab ? 128 : 512;
-                for (; !G.p1slab && ks > 128; ks >>= 1) {
-                    const int ny = cdiv(IN, ks), nh = cdiv(D, ks);
-                    if (nct * nrt * (3 * ny + 2 * nh) >= (3 * m->n_cu) / 4) break;
-                }
-                if (G.p1slab) while (cdiv(IN, ks) > 8 || cdiv(IN, ks) + cdiv(D, ks) > 16) ks += 64;      // k_gru_gate adds up <= 8 / 16 slices
-                if (forced > 0) ks = std::min(512, std::max(16, forced / 16 * 16));
-                if (G.p1slab && (cdiv(IN, ks) > 8 || cdiv(IN, ks) + cdiv(D, ks) > 16)) G.p1slab = 0;
+            if (!ok) continue;
+            // phase 1: slices of <= 128 units (the whole slice of a workgroup is in flight at once: gemm_tile2k_full); k_gru_gate adds
+            // up <= 8 input slices / <= 16 slices in all
+            if ((mask & 1) && (!automask || D >= 512)) {
+                int ks = std::min(128, std::max(16, env_int("G4R_P1_KS", 128) / 16 * 16));
                 G.ny = cdiv(IN, ks); G.kys = ((cdiv(IN, G.ny) + 15) / 16) * 16; G.ny = cdiv(IN, G.kys);
                 G.nh = cdiv(D, ks); G.khs = ((cdiv(D, G.nh) + 15) / 16) * 16; G.nh = cdiv(D, G.khs);
-                max_slots = std::max(max_slots, 3 * nct * nrt * (G.ny + G.nh));
-                max_tiles = std::max(max_tiles, 3 * nct * nrt);
+                if (G.ny <= 8 && G.ny + G.nh <= 16) {
+                    G.use |= 1;
+                    vp_floats = std::max(vp_floats, (size_t)(G.ny + G.nh) * B * 3 * D);
+                }
             }
-            G.p2n = slices(D, nct * nrt, m->n_cu / 2, 16, 64, env_int("G4R_P2_KS", 0), &G.p2k);
-            G.ban = slices(D, nct * nrt, m->n_cu / 2, 32, 64, env_int("G4R_BA_KS", 0), &G.bak);
-            const int nctb = cdiv(IN, 64);
-            G.bbn = slices(3 * D, nctb * nrt, m->n_cu, 32, 128, env_int("G4R_BB_KS", 0), &G.bbk);
-            max_slots = std::max(max_slots, std::max(nct * nrt * std::max(G.p2n, G.ban), nctb * nrt * G.bbn));
-            max_tiles = std::max(max_tiles, std::max(nct, nctb) * nrt);
-        }
-        // dy of k_gru_bwd_bw as K-slice partial sums added up by its consumer (no in-launch join) where that consumer exists: the lower
-        // layer's k_gru_bwd_pre (not the fused backward), or -- layer 0 -- the row-finishing workgroups of k_dense_grad2.  G4R_BB_SLABS=0: join.
-        int dmax0 = 0;
-        for (int l = 0; l < L; ++l) dmax0 = std::max(dmax0, d.D[l]);
-        const bool wdense = (mask & 16) && wide_layer(dmax0) && !(cfg->embed_mode == G4R_EMBED_ONEHOT);
-        size_t dyp_floats = 0, vp_floats = 0;
-        for (int l = 0; l < L; ++l) {
-            if (!(m->wg[l].use & 8)) continue;
-            const bool consumer = env_int("G4R_BB_SLABS", 1) && m->wg[l].bbn <= 16 && ((l == 0) ? wdense : !fused_bwd(d, l - 1));
-            if (!consumer) {
-                if (automask) m->wg[l].use &= ~8;      // (default policy: nobody to add the partial sums up -> the round-1 kernel, not the joined one)
-                continue;
+            // dy: enough slices of >= 128 (multiples of 32) to give every CU a workgroup, <= 16 (what the consumers add up in one round trip)
+            const bool consumer = (l == 0) ? wdense : !fused_bwd(d, l - 1);
+            if ((mask & 8) && consumer) {
+                const int K = 3 * D, tiles = cdiv(IN, 64) * nrt, forced = env_int("G4R_BB_KS", 0);
+                int n = std::min(std::max(1, cdiv(m->n_cu, std::max(tiles, 1))), std::max(1, K / 128));
+                int ks = ((cdiv(K, n) + 31) / 32) * 32;
+                if (forced > 0) ks = std::max(32, forced / 32 * 32);
+                if (cdiv(K, ks) <= 16) {
+                    G.use |= 8; G.bbk = ks; G.bbn = cdiv(K, ks);
+                    d.bbn[l] = G.bbn;
+                    dyp_floats = std::max(dyp_floats, (size_t)G.bbn * B * IN);
+                }
             }
-            d.bbn[l] = m->wg[l].bbn;
-            dyp_floats = std::max(dyp_floats, (size_t)d.bbn[l] * B * d.IN[l]);
         }
-        for (int l = 0; l < L; ++l)
-            if ((m->wg[l].use & 1) && m->wg[l].p1slab) vp_floats = std::max(vp_floats, (size_t)(m->wg[l].ny + m->wg[l].nh) * B * 3 * d.D[l]);
         if (dyp_floats) DA(d.dyp, dyp_floats);
         if (vp_floats) DA(d.vp, vp_floats);
-        if (max_slots > 0) {
-            DA(m->wk_ws, (size_t)max_slots * 4096);
-            DA(m->wk_cnt, (size_t)max_tiles);
-            m->wk_ntile = max_tiles;
-        }
-        int dmax = 0;
-        for (int l = 0; l < L; ++l) dmax = std::max(dmax, d.D[l]);
-        m->wide_dense = (mask & 16) && wide_layer(dmax) && !(cfg->embed_mode == G4R_EMBED_ONEHOT);
+        m->wide_dense = wdense;
         if (m->wide_dense) {
             std::vector<DenseTile> tiles;
             for (int l = 0; l < L; ++l) {
@@ -655,8 +617,6 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_update<1, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_aw, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_bw, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_store, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
 #define G4R_LOSS_ATTR(L, S) HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<L, S>, hipFuncAttributeMaxDynamicSharedMemorySize, big))
@@ -1007,18 +967,16 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         const g4r_model::WideGeo& G = m->wg[l];
         const int nrt64 = cdiv(B, 64), nct64 = d.D[l] / 64;
         begin(KN_GRU_P1);
-        if ((G.use & 1) && G.p1slab) {
+        if (G.use & 1) {
             LK(k_gru_p1s, dim3(nct64 * nrt64 * (3 * G.ny + 2 * G.nh)), dim3(256), SMEM_T2K, s, dmp, stp, l, l == 0 ? 1 : 0, G.ny, G.nh, G.kys, G.khs);
             end();
             begin(KN_GATE);
             LK(k_gru_gate, dim3(cdiv((long long)B * (d.D[l] / 4), 256)), dim3(256), 0, s, dmp, stp, l, G.ny, G.nh);
-        } else if (G.use & 1) LK(k_gru_p1w, dim3(nct64 * nrt64 * (3 * G.ny + 2 * G.nh)), dim3(256), SMEM_T2K, s, dmp, stp, l, l == 0 ? 1 : 0, m->wk_ws, m->wk_cnt, G.ny, G.nh, G.kys, G.khs);
-        else if (wide_layer(d.D[l])) LK(k_gru_p1_n64, dim3(cdiv(3 * d.D[l], 64), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1_N64, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
+        } else if (wide_layer(d.D[l])) LK(k_gru_p1_n64, dim3(cdiv(3 * d.D[l], 64), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1_N64, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
         else LK(k_gru_p1_n32, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
         end();
         begin(KN_GRU_P2);
-        if (G.use & 2) LK(k_gru_p2w, dim3(nct64 * nrt64 * G.p2n), dim3(256), SMEM_T2K, s, dmp, stp, l, m->wk_ws, m->wk_cnt, G.p2n, G.p2k);
-        else LK(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH), SMEM_NN, s, dmp, stp, l, 1, nopa);
+        LK(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH), SMEM_NN, s, dmp, stp, l, 1, nopa);
         end();
     }
     if (syc_fork) HIPCHK(hipStreamWaitEvent(s, m->ev_join2, 0));
@@ -1073,12 +1031,11 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         const g4r_model::WideGeo& G = m->wg[l];
         const int nrt64 = cdiv(B, 64);
         begin(KN_BWD_A);
-        if (G.use & 4) LK(k_gru_bwd_aw, dim3((d.D[l] / 64) * nrt64 * G.ban), dim3(256), SMEM_T3, s, dmp, stp, l, m->wk_ws, m->wk_cnt, G.ban, G.bak);
-        else LK(k_gru_bwd_a, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH), SMEM_NT, s, dmp, stp, l);
+        LK(k_gru_bwd_a, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH), SMEM_NT, s, dmp, stp, l);
         end();
         begin(KN_BWD_B);
         if (l == 0 && d.embed_mode == G4R_EMBED_ONEHOT) LK(k_onehot_step, dim3(cdiv((long long)B * d.Ein, 4 * 256)), dim3(256), 0, s, dmp, stp);
-        else if (G.use & 8) LK(k_gru_bwd_bw, dim3(cdiv(d.IN[l], 64) * nrt64 * G.bbn), dim3(256), SMEM_T3, s, dmp, stp, l, m->wk_ws, m->wk_cnt, G.bbn, G.bbk, d.bbn[l] > 0 ? 1 : 0);
+        else if (G.use & 8) LK(k_gru_bwd_bw, dim3(cdiv(d.IN[l], 64) * nrt64 * G.bbn), dim3(256), SMEM_T3, s, dmp, stp, l, G.bbn, G.bbk);
         else LK(k_gru_bwd_b, dim3(cdiv(d.IN[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_BB, s, dmp, stp, l);
         end();
     }
@@ -1295,7 +1252,6 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
     if (t0 < 0 || n_steps < 0 || t0 + n_steps > m->T) return fail("step range outside the plan");
     if (m->dm.ns > 0 && !m->have_pop && !m->store_frozen) return fail("negative sampling needs g4r_set_popularity first");
     HIPCHK(hipSetDevice(m->cfg.device));
-    if (m->wk_cnt) HIPCHK(hipMemsetAsync(m->wk_cnt, 0, (size_t)m->wk_ntile * sizeof(unsigned), m->stream));      // split-K arrival counters (every launch leaves them at zero; a poisoned call must not outlive itself)
     hipLaunchKernelGGL(k_set_state, dim3(1), dim3(512), 0, m->stream, (const DevModel*)m->d_dm, (StepState*)m->dm.st, (long long)t0, (long long)m->gstep);
     bool use_graph = m->cfg.use_graph && !m->profiling && !getenv("G4R_TRACE") && (m->dm.apply_dense_inplace || dist_graph_wanted(m));
     if (use_graph && !m->dm.apply_dense_inplace) {
@@ -1394,8 +1350,7 @@ int g4r_virtual_train_steps(g4r_model* const* ms, int32_t n, int64_t t0, int64_t
     for (int q = 0; q < n; ++q) {
         g4r_model* m = ms[q];
         va.src[q] = m->dm.dense_g; va.dst[q] = m->dm.dense_g;
-        if (m->wk_cnt) HIPCHK(hipMemsetAsync(m->wk_cnt, 0, (size_t)m->wk_ntile * sizeof(unsigned), m->stream));      // split-K arrival counters (every launch leaves them at zero; a poisoned call must not outlive itself)
-    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(512), 0, m->stream, (const DevModel*)m->d_dm, (StepState*)m->dm.st, (long long)t0, (long long)m->gstep);
+        hipLaunchKernelGGL(k_set_state, dim3(1), dim3(512), 0, m->stream, (const DevModel*)m->d_dm, (StepState*)m->dm.st, (long long)t0, (long long)m->gstep);
         ci[q] = std::lower_bound(m->compact_steps.begin(), m->compact_steps.end(), t0) - m->compact_steps.begin();
     }
     for (int64_t t = t0; t < t0 + n_steps; ++t) {

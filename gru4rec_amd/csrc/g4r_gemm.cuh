@@ -314,68 +314,7 @@ __device__ __forceinline__ void gemm_tile2(int m0, int n0, int K, ARow arow, BRo
     if (trc && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[4] = wall_clock64(); }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Split-K inside ONE launch for the 64 x 64 tiles below (gemm_tile2k / gemm_tile3: 256 threads, 16 accumulator registers per lane).
-// The GEMMs of a wide GRU layer (B ~ 240-512 rows, 3D ~ 768-1536 columns, K ~ 512-1536) are only 32-96 tiles of 64 x 64: to put all
-// 256 CUs to work -- and, which is what bounds them, to cut the operand bytes every CU has to pull through its own L1 path -- the K
-// range of a tile is cut into `nsplit` slices, one workgroup each.  A slice publishes its partial accumulators (write-through
-// 16-byte stores, every wave drains them, one lane draws a ticket from the tile's counter: MI355X guide, Guideline 16 form R1 in its
-// counter form); the workgroup that draws the LAST ticket adds all slices up -- its own included, re-read like the others, in slice
-// order, so the sum does not depend on who arrived when: bit-reproducible -- and runs the tile's epilogue; everybody else is done.
-// Nobody waits for anybody (no residency assumption).  The counter is taken back to zero by the last arriver (the next launch that
-// uses it is a kernel boundary away) and zeroed by the host at the start of every g4r_train_steps call.
-// Workspace: slot (tile * maxsplit + slice) of 4096 floats, element ((j4 * 256 + tid) * 4 + e) = accumulator 4 j4 + e of thread tid.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-struct NoJoin { __device__ __forceinline__ bool operator()(f32x16&, float*) const { return true; } };
-struct NoFix2k { __device__ __forceinline__ float4 operator()(int, float4 v, bool) const { return v; } };
-#define G4R_AUX_SC1 16      // cache policy bits of the raw buffer builtins: sc1 = write-through store / L1-bypassing load
-struct SplitKJoin {
-    float* ws;          // kernel-argument pointers (wave-uniform): partial sums, per-tile arrival counters
-    unsigned* cnt;
-    int tile, split, nsplit, maxsplit;
-    __device__ __forceinline__ bool operator()(f32x16& acc, float* smem) const {
-        if (nsplit <= 1) return true;
-        const int tid = threadIdx.x;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ws + (size_t)tile * maxsplit * 4096, 0, maxsplit * 16384, 0x00020000);
-#pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4) {
-            const f32x4 v = {acc[4 * j4], acc[4 * j4 + 1], acc[4 * j4 + 2], acc[4 * j4 + 3]};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, ((split * 4 + j4) * 256 + tid) * 16, 0, G4R_AUX_SC1);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
-        __syncthreads();                                      // ... (and is past its last fragment read of the operand tiles) ...
-        unsigned* sflag = reinterpret_cast<unsigned*>(smem);
-        if (tid == 0) *sflag = __hip_atomic_fetch_add((GAS unsigned*)cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... then ONE lane draws the ticket
-        __syncthreads();
-        const unsigned ticket = *sflag;
-        if (ticket != (unsigned)(nsplit - 1)) return false;
-        if (tid == 0) __hip_atomic_store((GAS unsigned*)cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // last arriver: all slices in slice order, four slices' loads in flight together (slots past nsplit re-read the last slice
-        // and are discarded by a select, not a multiply)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-        for (int s0 = 0; s0 < nsplit; s0 += 4) {
-            u32x4 v[4][4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int s = min(s0 + u, nsplit - 1);
-#pragma unroll
-                for (int j4 = 0; j4 < 4; ++j4) v[u][j4] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((s * 4 + j4) * 256 + tid) * 16, 0, G4R_AUX_SC1);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool live = s0 + u < nsplit;
-#pragma unroll
-                for (int j4 = 0; j4 < 4; ++j4) {
-                    const f32x4 f = __builtin_bit_cast(f32x4, v[u][j4]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[4 * j4 + e] += live ? f[e] : 0.f;
-                }
-            }
-        }
-        return true;
-    }
-};
+struct NoFix2k { __device__ __forceinline__ float4 operator()(int, float4 v, bool) const { return v; } };      // gemm_tile2k_full: no post-processing of staged A quads
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // gemm_tile3: gemm_tile2's tile (64 x 64, 4 waves 2 x 2, one v_mfma_f32_32x32x2_f32 accumulator per wave, both operands
@@ -418,21 +357,13 @@ __device__ __forceinline__ void wait_vm_barrier() {      // my LDS-DMA pieces ex
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N) : "memory");
 }
 
-// `behind` stages of LPS pieces each may stay in flight behind the stage that is waited for (counted wait + barrier)
-template <int LPS, int MAXB>
-__device__ __forceinline__ void wait_vm_behind(int behind) {
-    if constexpr (MAXB > 0) {
-        if (behind >= MAXB) { wait_vm_barrier<MAXB * LPS>(); return; }
-        wait_vm_behind<LPS, MAXB - 1>(behind);
-    } else wait_vm_barrier<0>();
-}
 // BKS = 32: a row of a stage is 8 quads, a DMA piece (1 KiB) 8 rows, 2 pieces per wave and operand, f(row) = (row >> 1) & 7;
 // BKS = 16: 4 quads, 16 rows per piece, 1 piece per wave and operand, f(row) = (row >> 2) & 3 (8 KiB stages: more workgroups per CU).
-template <int NST, int BKS, bool PRE_COL, class ARow, class BRow, class Pre, class Epi, class Join = NoJoin>
+template <int NST, int BKS, bool PRE_COL, class ARow, class BRow, class Pre, class Epi>
 __device__ __forceinline__ void gemm_tile3(int m0, int n0, int K, ARow arow, BRow brow, const GAS float* zrow, Pre pre, Epi epi, float* smem,
-                                           GAS long long* trc = nullptr, Join join = Join()) {
+                                           GAS long long* trc = nullptr) {
     using C = Tile3Cfg<NST, BKS>;
-    static_assert(NST >= 3 && NST <= 9, "ring depth");
+    static_assert(NST >= 3 && NST <= 5, "ring depth");
     static_assert(BKS == 16 || BKS == 32, "stage depth");
     constexpr int QPR = BKS / 4, RPP = 64 / QPR, NP = 64 / RPP / 4;      // quads per row, rows per piece, pieces per wave and operand
     constexpr int FSH = BKS == 32 ? 1 : 2, FMASK = QPR - 1;              // f(row) = (row >> FSH) & FMASK
@@ -484,7 +415,10 @@ __device__ __forceinline__ void gemm_tile3(int m0, int n0, int K, ARow arow, BRo
     for (int i = 0; i < nchunk; ++i) {
         // stages i + 1 .. i + NST - 2 may stay in flight (LPS pieces each); at the tail fewer are behind stage i
         const int behind = min(NST - 2, nchunk - 1 - i);
-        wait_vm_behind<LPS, NST - 2>(behind);
+        if (NST >= 5 && behind == 3) wait_vm_barrier<3 * LPS>();
+        else if (NST >= 4 && behind == 2) wait_vm_barrier<2 * LPS>();
+        else if (behind == 1) wait_vm_barrier<LPS>();
+        else wait_vm_barrier<0>();
         if (trc && tid == 0 && i == 0) trc[2] = wall_clock64();          // first stage landed
         if (i + NST - 1 < nchunk) issue(nbuf);            // into the buffer stage i - 1 was read from (everyone is past the barrier)
         const float* fa = fa0 + buf * C::STAGE;
@@ -508,7 +442,6 @@ __device__ __forceinline__ void gemm_tile3(int m0, int n0, int K, ARow arow, BRo
         nbuf = (nbuf + 1 == NST) ? 0 : nbuf + 1;
     }
     if (trc && tid == 0) trc[3] = wall_clock64();
-    if (!join(acc, smem)) return;      // split-K: every slice but the tile's last arriver is done (its partial sum is published)
 #pragma unroll
     for (int j = 0; j < 16; ++j) epi(m0 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3), n, acc[j], pf[PRE_COL ? 0 : j]);
     if (trc && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[4] = wall_clock64(); }
@@ -527,12 +460,8 @@ __device__ __forceinline__ void gemm_tile3(int m0, int n0, int K, ARow arow, BRo
 // `safe`: >= 16 readable bytes (DevModel::zrow): what a masked slot loads instead of its operand.  (Round 2 re-read the provider's
 // element (0, 0, 0) there, which is itself a null pointer when the FIRST column of a dh slab is an inactive in-batch column -- a slab
 // boundary inside [M, B) at the tail of an epoch: a GPU fault at address 0 once B = 240 took these tiles.)
-// `join(acc, smem)` (optional; SplitKJoin below): called once the tile's K range is accumulated -- false ends the workgroup without an
-// epilogue.  `afix(chunk, quad, ok)` (optional, K-contiguous A only): post-processes the quad a thread stages for K chunk `chunk`
-// (its row and k offset inside a chunk never change: row tid >> 2, k offset 4 (tid & 3)) on its way to LDS -- dropout masks.
-template <bool A_KM, bool PRE_COL, class AProv, class BProv, class Pre, class Epi, class Join = NoJoin, class AFix = NoFix2k>
-__device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, BProv bprov, const GAS float* safe, Pre pre, Epi epi, float* smem, GAS long long* trc = nullptr,
-                                            Join join = Join(), AFix afix = AFix()) {
+template <bool A_KM, bool PRE_COL, class AProv, class BProv, class Pre, class Epi>
+__device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, BProv bprov, const GAS float* safe, Pre pre, Epi epi, float* smem, GAS long long* trc = nullptr) {
     constexpr int BK = 16;
     constexpr int BUF = 64 * BK;                        // floats per operand buffer, either layout
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -581,9 +510,8 @@ __device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, 
         ob = b_ != nullptr;
         rb = ldasm(b_ ? b_ : safe);
     };
-    auto commit = [&](int buf, int ci, const f32x4& ra, const f32x4& rb, bool oa, bool ob) {
-        float4 va = make_float4(oa ? ra[0] : 0.f, oa ? ra[1] : 0.f, oa ? ra[2] : 0.f, oa ? ra[3] : 0.f);
-        if constexpr (!A_KM) va = afix(ci, va, oa);
+    auto commit = [&](int buf, const f32x4& ra, const f32x4& rb, bool oa, bool ob) {
+        const float4 va = make_float4(oa ? ra[0] : 0.f, oa ? ra[1] : 0.f, oa ? ra[2] : 0.f, oa ? ra[3] : 0.f);
         const float4 vb = make_float4(ob ? rb[0] : 0.f, ob ? rb[1] : 0.f, ob ? rb[2] : 0.f, ob ? rb[3] : 0.f);
         if constexpr (A_KM) {
             *reinterpret_cast<float4*>(smem + buf * BUF + kofs) = va;
@@ -616,7 +544,7 @@ __device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, 
     float4 pf[NPF];
 #pragma unroll
     for (int j = 0; j < NPF; ++j) pf[j] = pre(m0 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3), n);
-    commit(0, 0, ra0, rb0, oa0, ob0);
+    commit(0, ra0, rb0, oa0, ob0);
     if (trc && tid == 0) trc[2] = wall_clock64();
     // one K chunk out of LDS buffer `buf`: fragments, the loads of the chunk after next, the MFMAs, then the wait for the NEXT chunk
     // (the newest two loads stay in flight; loads return in order, and the epilogue operands requested above are older than both)
@@ -654,20 +582,19 @@ __device__ __forceinline__ void gemm_tile2k(int m0, int n0, int K, AProv aprov, 
         if (i + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" : "+v"(ra1), "+v"(rb1) :: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra1), "+v"(rb1) :: "memory");
 #endif
-        commit(1, i + 1, ra1, rb1, oa1, ob1);
+        commit(1, ra1, rb1, oa1, ob1);
         chunk(1, i + 1, ra1, rb1, oa1, ob1);
         if (i + 2 >= nchunk) break;
 #if defined(G4R_MUTATE) && G4R_MUTATE == 4
         if (i + 3 < nchunk) asm volatile("s_waitcnt vmcnt(2)" : "+v"(ra0), "+v"(rb0) :: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(rb0) :: "memory");
 #endif
-        commit(0, i + 2, ra0, rb0, oa0, ob0);
+        commit(0, ra0, rb0, oa0, ob0);
     }
     // the dummy loads of the tail are still in flight and their registers are free as far as the compiler knows: drain before anything reuses them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if (trc && tid == 0) trc[3] = wall_clock64();
-    if (!join(acc, smem)) return;      // split-K: every slice but the tile's last arriver is done (its partial sum is published)
 #pragma unroll
     for (int j = 0; j < 16; ++j) epi(m0 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3), n, acc[j], pf[PRE_COL ? 0 : j]);
     if (trc && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[4] = wall_clock64(); }
@@ -725,12 +652,8 @@ __device__ __forceinline__ void gemm_tile2k_full(int m0, int n0, int K, AProv ap
             float av[8], bv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { av[u] = fa[(2 * u) ^ sw_fr]; bv[u] = fb[128 * u]; }
-#if defined(G4R_P1S_DBG) && (G4R_P1S_DBG & 8)
-            acc[0] += av[0] * bv[0] + av[7] * bv[7];
-#else
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc = mfma32(av[u], bv[u], acc);
-#endif
         }
     }
     const int n = n0 + wn * 32 + l32;

@@ -1,8 +1,7 @@
-"""The split-K kernels of wide GRU layers (gru4rec_amd/csrc/g4r_wide_kernels.cuh: k_gru_p1s + k_gru_gate / k_gru_p1w / k_gru_p2w /
-k_gru_bwd_aw / k_gru_bwd_bw / k_dense_grad2; K slices joined inside the launch by the tile's last arriver, or left as partial sums that the
-consuming kernel adds up) against the oracle, against the round-1 kernels they replace
-(G4R_WIDE2=0; the switch is read per model), one kernel at a time, and against themselves (graph replay == eager launches, bit for
-bit: the join adds the slices in slice order whatever the arrival order).
+"""The K-sliced kernels of wide GRU layers (gru4rec_amd/csrc/g4r_wide_kernels.cuh: k_gru_p1s + k_gru_gate, k_gru_bwd_bw, k_dense_grad2 with
+its row-finishing workgroups; the K slices of a tile are left as partial sums that the consuming kernel adds up in slice order)
+against the oracle, against the round-1 kernels they replace (G4R_WIDE2=0; the switch is read per model), one kernel at a time, under
+the default policy, and against themselves (graph replay == eager launches, bit for bit).
 
 Tolerances: test_gpu_parity.py (fp32 both sides, different summation orders).  The old and the new kernels differ ONLY in summation
 order (k-ordered 16x16x4 chains over the whole K against 32x32x2 chains over slices), so their losses are compared at rtol 2e-5."""
@@ -15,8 +14,9 @@ from test_gpu_parity import close, compare_params, make_pair, random_plan, repor
 
 pytestmark = pytest.mark.gpu
 
+ALL = 1 | 8 | 16
 SHAPES = {
-    # name: (I, B, ns, T, kwargs)      B = 96: a full and a half row tile; B = 240: cfg3's 3.75 row tiles
+    # name: (I, B, ns, T, kwargs)      B = 96: a full and a half row tile; B = 240: BASELINE configs[2]'s 3.75 row tiles
     'd256_b96_bprmax': (3000, 96, 512, 8, dict(loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(256,),
                                                learning_rate=0.1, bpreg=1.0, momentum=0.1)),
     'd512_b240_xe_logq_drop': (5000, 240, 1024, 6, dict(loss='cross-entropy', final_act='softmax', constrained_embedding=True, layers=(512,),
@@ -25,6 +25,8 @@ SHAPES = {
                                                    learning_rate=0.1, dropout_p_embed=0.2, dropout_p_hidden=0.1)),
     'separate_embedding_128_to_384': (2000, 64, 256, 6, dict(loss='bpr-max', final_act='elu-0.5', constrained_embedding=False, embedding=128,
                                                              layers=(384,), learning_rate=0.1, bpreg=0.5)),
+    'rmsprop_generic_path': (2000, 96, 256, 6, dict(loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(256,),
+                                                    learning_rate=0.05, bpreg=1.0, adapt='rmsprop', dropout_p_embed=0.1)),
 }
 
 
@@ -59,9 +61,9 @@ def _plan(I, B, T, o, tail):
 @pytest.mark.parametrize('tail', [False, True])
 def test_wide_kernels_against_the_oracle(name, tail):
     I, B, ns, T, kw = SHAPES[name]
-    with _env(G4R_WIDE2=31):
+    with _env(G4R_WIDE2=ALL):
         o, m = make_pair(I, B, ns, store_rows=T + 2, **kw)
-    assert m.get_debug('wide_mask', 1)[0] != 0, 'the wide-layer kernels did not engage at this shape'
+    assert int(m.get_debug('wide_mask', 1)[0]) == ALL, 'the wide-layer kernels did not engage at this shape'
     plan = _plan(I, B, T, o, tail)
     m.set_plan(plan)
     want = [o.train_step(plan['in_idx'][t], plan['out_idx'][t], int(plan['M'][t]), plan['reset'][t]) for t in range(T)]
@@ -74,17 +76,17 @@ def test_wide_kernels_against_the_oracle(name, tail):
     assert not errs, errs
 
 
-@pytest.mark.parametrize('mask', [1, 101, 2, 4, 8, 16, 24, 31, -1])
+@pytest.mark.parametrize('mask', [1, 16, 24, ALL, -1])
 def test_each_wide_kernel_against_the_kernel_it_replaces(mask):
-    """One new kernel at a time (and all of them; -1: the default policy; 101: phase 1 in its joined form instead of partial sums +
-    k_gru_gate) next to the round-1 kernels on the same plan: the losses agree to summation order."""
+    """One new kernel at a time (8 needs 16: the launch that adds dy's slices up for layer 0), all of them, and -1: the default policy,
+    next to the round-1 kernels on the same plan: the losses agree to summation order."""
     I, B, ns, T, kw = SHAPES['d512_b240_xe_logq_drop']
     runs = {}
     for mk in (0, mask):
-        with _env(G4R_WIDE2=None if mk < 0 else mk % 100, G4R_P1_JOIN=1 if mk > 100 else None):
+        with _env(G4R_WIDE2=None if mk < 0 else mk):
             o, m = make_pair(I, B, ns, store_rows=T + 2, **kw)
             if mk != 0:
-                assert m.get_debug('wide_mask', 1)[0] != 0
+                assert int(m.get_debug('wide_mask', 1)[0]) == (ALL if mk < 0 else mk)      # (the default policy takes all three at this shape)
         plan = _plan(I, B, T, o, tail=True)
         m.set_plan(plan)
         m.train_steps(0, T)
@@ -98,31 +100,42 @@ def test_each_wide_kernel_against_the_kernel_it_replaces(mask):
         assert np.abs(a - b).max() <= 2e-4 * scale, (nm, float(np.abs(a - b).max()), float(scale))
 
 
-@pytest.mark.parametrize('ks', [64, 128, 512])
+def test_default_policy_by_shape():
+    """BASELINE configs[3]'s shape (D = 256, 2 B + n_sample = 9216 rows): the merged k_update stays, nothing of layer 0 is sliced;
+    a wide layer above an unfused one has its dy sliced whatever the update launch."""
+    o, m = make_pair(3000, 512, 8192, store_rows=2, loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(256,), learning_rate=0.1)
+    assert int(m.get_debug('wide_mask', 1)[0]) == 0
+    m.close()
+    o, m = make_pair(3000, 512, 8192, store_rows=2, loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(256, 256), learning_rate=0.1)
+    assert int(m.get_debug('wide_mask', 1)[0]) == 8
+    m.close()
+
+
+@pytest.mark.parametrize('ks', [(64, 128), (96, 256), (128, 768)])
 def test_slice_lengths(ks):
-    """Other K-slice geometries than the default (1 .. 8 slices per tile): same results."""
+    """Other K-slice geometries than the default: same results."""
     I, B, ns, T, kw = SHAPES['d512_b240_xe_logq_drop']
-    with _env(G4R_WIDE2=31, G4R_P1_KS=ks, G4R_P2_KS=ks, G4R_BA_KS=ks, G4R_BB_KS=ks if ks >= 128 else 128):
+    with _env(G4R_WIDE2=ALL, G4R_P1_KS=ks[0], G4R_BB_KS=ks[1]):
         o, m = make_pair(I, B, ns, store_rows=T + 2, **kw)
     plan = _plan(I, B, T, o, tail=False)
     m.set_plan(plan)
     want = [o.train_step(plan['in_idx'][t], plan['out_idx'][t], B, plan['reset'][t]) for t in range(T)]
     m.train_steps(0, T)
     errs = []
-    report('--- wide slices of %d' % ks)
+    report('--- wide slices of %d / %d' % ks)
     close('loss curve', m.get_losses(0, T), np.array(want), atol=5e-6, rtol=5e-4, errs=errs)
-    compare_params(o, m, errs, 'wide-ks%d' % ks)
+    compare_params(o, m, errs, 'wide-ks%d' % ks[0])
     m.close()
     assert not errs, errs
 
 
 def test_wide_graph_replay_is_bit_identical_to_eager():
-    """32 steps as two graph replays against 32 eager steps: identical bits in every loss and parameter (the in-launch join is
-    order-independent), and a second identical run reproduces the first."""
+    """32 steps as two graph replays against 32 eager steps: identical bits in every loss and parameter (slices are added in slice
+    order), and a second identical run reproduces the first."""
     I, B, ns, T, kw = 4000, 240, 1024, 32, SHAPES['d512_b240_xe_logq_drop'][4]
     out = []
     for use_graph in (0, 1, 1):
-        with _env(G4R_WIDE2=31):
+        with _env(G4R_WIDE2=ALL):
             o, m = make_pair(I, B, ns, store_rows=T + 2, use_graph=use_graph, **kw)
         plan = _plan(I, B, T, o, tail=False)
         m.set_plan(plan)
