@@ -356,12 +356,16 @@ def main():
     if sync_in_timed:
         m.set_sync_every(0)      # the per-kernel passes below time the bare step
     kt = {}
+    defer_rows = None
     if n_profile > 0:
         # per-kernel durations: HIP events on the library's own stream, eager launches over the next plan steps
+        d0 = m.get_debug('defer_stats', 4)
         m.profile(True)
         m.train_steps(args.warmup + args.steps + n_long, n_profile)
         m.profile(False)
         kt = m.kernel_times()
+        d1 = m.get_debug('defer_stats', 4)
+        defer_rows = (float(d1[0] - d0[0]), float(d1[1] - d0[1])) if d1[2] else None
     staged = (world > 1 or bool(os.environ.get('G4R_FORCE_STAGED'))) and not args.sparse_exact
     kt_split = {}
     if n_profile > 0 and world == 1 and not staged:
@@ -616,10 +620,29 @@ def main():
                                  'run as k_dense_grad next to it), HIP events on the dispatches; achieved / frac price it with SURVEY 8d\'s '
                                  'sparse bytes like the merged launch; rows_moved_bytes is what it reads and writes if every row is a '
                                  'single occurrence (3 row transfers: the accumulator is updated in place by the gradient producer)'}
+            # Deferred row updates (k_sparse_flush): the row transfers of every update that could wait for the end of its window of
+            # steps, in ONE launch per window.  Priced on the bytes the launch MOVES (step row read + parameter row read + write per
+            # applied row, bias entry, and its scan of the window's pending list), with SURVEY 8d's five-transfer figure beside it.
+            flush = None
+            if 'k_sparse_flush' in kt and defer_rows:
+                ms_f, n_f = kt['k_sparse_flush']
+                us_f = 1000.0 * ms_f / max(n_f, 1)
+                rows_per, bias_per = defer_rows[0] / max(n_f, 1), defer_rows[1] / max(n_f, 1)
+                W_ = cfg['layers'][-1]
+                moved_f = rows_per * 3 * W_ * 4 + bias_per * 12 + (n_profile / max(n_f, 1)) * (2 * cfg['batch_size'] + cfg['n_sample']) * 8
+                flush = {'kernel': 'k_sparse_flush', 'avg_us': us_f, 'launches': n_f, 'rows_per_launch': rows_per,
+                         'share_of_the_steps_rows': defer_rows[0] / max(1.0, n_profile * (2 * cfg['batch_size'] + cfg['n_sample'])),
+                         'moved_bytes_per_launch': moved_f, 'achieved': moved_f / (us_f * 1e-6) / 1e9, 'unit': 'GB/s',
+                         'frac': moved_f / (us_f * 1e-6) / 1e9 / 8000.0, 'survey_8d_bytes_per_launch': rows_per * 5 * W_ * 4,
+                         'frac_on_survey_8d_bytes': rows_per * 5 * W_ * 4 / (us_f * 1e-6) / 1e9 / 8000.0,
+                         'rocprofv3_avg_us': rp.get('k_sparse_flush'),
+                         'note': 'one launch per window of <= 16 steps (a replay of the step graph): rows whose item is not gathered again inside '
+                                 'the window (k_defer_scan, from the plan and the sample store) are applied here instead of in their step\'s '
+                                 'k_update -- bit-identical results (tests/test_gpu_defer.py); avg_us: HIP events around the launch'}
             out['roofline_gather_scatter'] = {
                 'kernel': rk, 'bound': 'hbm', 'achieved': gbps, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbps / 8000.0,
                 'traffic': traffic_of(rk), 'sparse_bytes': sparse_bytes, 'avg_us': k['avg_us'],
-                'rocprofv3_avg_us': k.get('rocprofv3_avg_us'), 'sparse_role_alone': alone,
+                'rocprofv3_avg_us': k.get('rocprofv3_avg_us'), 'sparse_role_alone': alone, 'deferred_flush': flush,
                 'dense_param_bytes_same_launch': (alg['k_update']['bytes'] - sparse_bytes) if rk == 'k_update' else 0,
                 'note': 'sparse bytes per launch = (5 R D + 5 N + R) * 4, R = 2B + n_sample gathered rows, N = B + n_sample score columns '
                         '(SURVEY 8d); on one GPU the same launch also holds the dense-gradient tiles (their parameter / accumulator bytes '

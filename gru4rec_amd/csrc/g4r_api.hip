@@ -47,10 +47,10 @@ void g4r_set_error(const char* fmt, ...) {
     } while (0)
 
 enum { KN_GRU_P1 = 0, KN_GRU_P2, KN_SCORE_FWD, KN_LOSS, KN_SCORE_BWD, KN_BWD_PRE, KN_BWD_A, KN_BWD_B, KN_DENSE, KN_ALLREDUCE,
-       KN_DENSE_APPLY, KN_SPARSE, KN_UPDATE, KN_BWD_FUSED, KN_FWD_FUSED, KN_COMPACT, KN_GATE, KN_COUNT };
+       KN_DENSE_APPLY, KN_SPARSE, KN_UPDATE, KN_BWD_FUSED, KN_FWD_FUSED, KN_COMPACT, KN_GATE, KN_FLUSH, KN_SCAN, KN_COUNT };
 static const char* KN_NAMES[KN_COUNT] = {"k_gru_p1", "k_gru_p2", "k_score_fwd", "k_loss_rows", "k_score_bwd", "k_gru_bwd_pre",
                                          "k_gru_bwd_a", "k_gru_bwd_b", "k_dense_grad", "rccl_allreduce", "k_dense_apply",
-                                         "k_sparse_update", "k_update", "k_gru_bwd", "k_gru_fwd", "k_compact_sy", "k_gru_gate"};
+                                         "k_sparse_update", "k_update", "k_gru_bwd", "k_gru_fwd", "k_compact_sy", "k_gru_gate", "k_sparse_flush", "k_defer_scan"};
 
 struct EvRec { int kn; hipEvent_t a, b; };
 
@@ -94,6 +94,8 @@ struct g4r_model {
     struct WideGeo { int use = 0, ny = 1, nh = 1, kys = 0, khs = 0, bbn = 1, bbk = 0; };
     WideGeo wg[G4R_MAX_LAYERS];
     bool wide_dense = false;
+    bool defer_on = false;       // deferred row updates (k_defer_scan / k_sparse_flush around every replay of the step graph)
+    hipEvent_t ev_df[4] = {nullptr, nullptr, nullptr, nullptr};      // profiling: scan / flush launches of a window
     DenseTile* d_tiles64 = nullptr;
     int ntiles64 = 0;
     float* d_tmpH = nullptr;
@@ -230,6 +232,7 @@ static inline bool wide_scores(const DevModel& d) {
 // for a wide top layer (D >= 256) whenever the batch fills 64-row tiles -- there the launch is a few hundred tiles, fewer than
 // the chip holds at once, and only the ring's depth hides a stage's memory round trip (B = 240, N = 2288, D = 512: 18.7 -> 15.0 us)
 #define ZROW_FLOATS 8192      // DevModel::zrow: an LDS-DMA tile walks K floats along it
+#define G4R_DEFER_SLOTS 16    // ring slots of the step planes = steps of a deferral window (= G4R_GRAPH_STEPS; a power of two)
 static inline bool score_fwd_dma(const DevModel& d) {
     static const int on = env_int("G4R_TILE3", 1);
     if (!on || !score_tile2() || d.Dtop % 32 != 0) return false;
@@ -391,6 +394,24 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         if (exact) d.dense_g = own + d.xoffDg;      // (the buffer allocated above stays unused)
     }
     DA(d.dAx, (size_t)B * d.Ein); DA(d.dAy, (size_t)d.ldSc * d.Dtop); DA(d.dABy, d.ldSc);
+    // Deferred row updates (g4r_step_kernels.cuh: k_defer_scan / k_sparse_flush): the single-GPU Adagrad step without momentum / L2 term, replayed
+    // from the step graph.  The step planes become rings of G4R_GRAPH_STEPS slots (one window = one graph replay).  G4R_DEFER=0: off.
+    m->defer_on = d.apply_dense_inplace && !d.generic && cfg->momentum <= 0.f && cfg->lmbd == 0.f && cfg->use_graph && env_int("G4R_DEFER", 1) != 0;
+    if (m->defer_on) {
+        const size_t W = G4R_DEFER_SLOTS;
+        d.defer_mask = (int)W - 1;
+        d.dRcap = cdiv(d.R, SP_WAVES) * SP_WAVES;
+        d.dSx_stride = (long long)(((size_t)B * d.Ein + 63) & ~(size_t)63);
+        d.dSy_stride = (long long)(((size_t)d.ldSc * d.Dtop + 63) & ~(size_t)63);
+        d.dSBy_stride = (long long)(((size_t)d.ldSc + 63) & ~(size_t)63);
+        float *rx = nullptr, *ry = nullptr, *rb = nullptr;
+        DA(rx, W * (size_t)d.dSx_stride); DA(ry, W * (size_t)d.dSy_stride); DA(rb, W * (size_t)d.dSBy_stride);
+        d.dSx = rx; d.dSy = ry; d.dSBy = rb;
+        DA(d.last_use, (size_t)(cfg->embed_mode != G4R_EMBED_CONSTRAINED ? 2 : 1) * I);
+        DA(d.dcand, W * (size_t)d.dRcap); DA(d.dlist, W * (size_t)d.dRcap); DA(d.dstat, 4);
+        if (hipMemsetAsync(d.dlist, 0xFF, W * (size_t)d.dRcap * sizeof(int), m->stream) != hipSuccess) { g4r_destroy(m); return fail("dlist init"); }
+        for (auto& e : m->ev_df) if (hipEventCreate(&e) != hipSuccess) { g4r_destroy(m); return fail("event create"); }
+    }
     DA(d.lossrow, B);
     DA(d.col_item, d.ldSc); DA(d.cur_in, B); DA(d.cur_col, d.ldSc);
     DA(d.occ_fl, (size_t)(cfg->embed_mode != G4R_EMBED_CONSTRAINED ? 2 : 1) * I * 4);
@@ -654,6 +675,7 @@ void g4r_destroy(g4r_model* m) {
     for (void* q : m->p2p_peer) if (q) (void)hipIpcCloseMemHandle(q);
     if (m->p2p_region) (void)hipFree(m->p2p_region);
     for (auto e : m->evs) (void)hipEventDestroy(e);
+    for (auto e : m->ev_df) if (e) (void)hipEventDestroy(e);
     for (g4r_model::Scratch* sc : {&m->sc_ids, &m->sc_blk, &m->sc_cnt, &m->sc_all, &m->sc_send, &m->sc_pack, &m->sc_recv, &m->sc_hall}) {
         if (sc->p) { if (sc->host) (void)hipHostFree(sc->p); else (void)hipFree(sc->p); }
         sc->p = nullptr; sc->cap = 0;
@@ -1283,13 +1305,48 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
         if (m->dm.ns > 0 && !m->store_frozen) run = std::min<int64_t>(run, m->gl - (m->gstep % m->gl));
         if (run <= 0) return fail("internal: empty run");
         int64_t done = 0;
+        // a deferral window around `nw` steps starting `done` steps into this run: which rows may wait (scan), ... steps ..., their flush
+        auto window_open = [&](int64_t nw) {
+            if (!m->defer_on) return;
+            const dim3 gs(cdiv(nw * m->dm.R, 256));
+            if (m->profiling) (void)hipEventRecord(m->ev_df[0], m->stream);
+            hipLaunchKernelGGL(k_defer_scan, gs, dim3(256), 0, m->stream, (const DevModel*)m->d_dm, (long long)(t + done), (long long)(m->gstep + done), (int)nw, 0);
+            hipLaunchKernelGGL(k_defer_scan, gs, dim3(256), 0, m->stream, (const DevModel*)m->d_dm, (long long)(t + done), (long long)(m->gstep + done), (int)nw, 1);
+            if (m->profiling) (void)hipEventRecord(m->ev_df[1], m->stream);
+        };
+        auto window_close = [&](int64_t nw, int64_t first) -> int {
+            if (!m->defer_on) return 0;
+            if (m->profiling) (void)hipEventRecord(m->ev_df[2], m->stream);
+            hipLaunchKernelGGL(k_sparse_flush, dim3(cdiv(nw * m->dm.dRcap, SP_WAVES)), dim3(SP_WAVES * 64), 0, m->stream, (const DevModel*)m->d_dm, (long long)(m->gstep + first), (int)nw);
+            if (m->profiling) {
+                (void)hipEventRecord(m->ev_df[3], m->stream);
+                HIPCHK(hipStreamSynchronize(m->stream));
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, m->ev_df[0], m->ev_df[1]) == hipSuccess) { m->kn_ms[KN_SCAN] += ms; m->kn_n[KN_SCAN]++; }
+                if (hipEventElapsedTime(&ms, m->ev_df[2], m->ev_df[3]) == hipSuccess) { m->kn_ms[KN_FLUSH] += ms; m->kn_n[KN_FLUSH]++; }
+            }
+            return 0;
+        };
         if (use_graph && run >= G4R_GRAPH_STEPS_SMALL) {
             if (ensure_graph(m)) return -1;
-            for (; done + m->graph_steps <= run; done += m->graph_steps) HIPCHK(hipGraphLaunch(m->gexec, m->stream));
+            for (; done + m->graph_steps <= run; done += m->graph_steps) {
+                window_open(m->graph_steps);
+                HIPCHK(hipGraphLaunch(m->gexec, m->stream));
+                if (window_close(m->graph_steps, done)) return -1;
+            }
             if (m->gexec_small)
-                for (; done + G4R_GRAPH_STEPS_SMALL <= run; done += G4R_GRAPH_STEPS_SMALL) HIPCHK(hipGraphLaunch(m->gexec_small, m->stream));
+                for (; done + G4R_GRAPH_STEPS_SMALL <= run; done += G4R_GRAPH_STEPS_SMALL) {
+                    window_open(G4R_GRAPH_STEPS_SMALL);
+                    HIPCHK(hipGraphLaunch(m->gexec_small, m->stream));
+                    if (window_close(G4R_GRAPH_STEPS_SMALL, done)) return -1;
+                }
         }
+        int64_t win_first = -1, win_n = 0;      // profiling: eager steps in windows of up to G4R_DEFER_SLOTS (the timed run's windows, with events)
         for (; done < run; ++done) {
+            if (m->profiling && m->defer_on && win_n == 0) {
+                win_n = std::min<int64_t>(G4R_DEFER_SLOTS, run - done); win_first = done;
+                window_open(win_n);
+            }
             if (m->profiling) {
                 // per-kernel durations: start/stop events attached to every dispatch (hipExtLaunchKernelGGL), i.e. the
                 // kernel's own begin/end timestamps -- the quantity rocprofv3 --kernel-trace reports; eager launches
@@ -1307,6 +1364,10 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
                 HIPCHK(hipGraphLaunch(m->gexec_head, m->stream));
                 if (launch_step(m, nullptr, 2)) return -1;
             } else if (launch_step(m, nullptr)) return -1;
+            if (win_n > 0 && done + 1 == win_first + win_n) {
+                if (window_close(win_n, win_first)) return -1;
+                win_n = 0;
+            }
         }
         t += run;
         m->gstep += run;
@@ -1411,6 +1472,8 @@ int g4r_set_step_counters(g4r_model* m, int64_t global_step, int64_t refills) {
     if (global_step < 0 || refills < 0) return fail("negative counter");
     HIPCHK(hipSetDevice(m->cfg.device));
     m->gstep = global_step;
+    if (m->defer_on)      // (the scan's "newest step that gathers the item" table is keyed by the global step)
+        HIPCHK(hipMemsetAsync(m->dm.last_use, 0, (size_t)(m->cfg.embed_mode != G4R_EMBED_CONSTRAINED ? 2 : 1) * m->dm.n_items * sizeof(int), m->stream));
     if (m->dm.ns > 0 && !m->store_frozen) {
         if (!m->have_pop) return fail("g4r_set_popularity first");
         if (refills < 1) return fail("a model with negative sampling has filled its store at least once");
@@ -2252,9 +2315,17 @@ int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
     if (l >= d.n_layers) return fail("layer out of range");
     const int64_t bd = (int64_t)d.B * d.D[l];
     if (s == "scores") { p = d.Sc; n = (int64_t)d.B * d.ldSc; }
-    else if (s == "dSx") { p = d.dSx; n = (int64_t)d.B * d.Ein; }
-    else if (s == "dSy") { p = d.dSy; n = (int64_t)d.ldSc * d.Dtop; }
-    else if (s == "dSBy") { p = d.dSBy; n = d.ldSc; }
+    // (step planes: the ring slot of the last step run)
+    else if (s == "dSx") { p = d.dSx + (size_t)((m->gstep - 1) & d.defer_mask) * (size_t)d.dSx_stride; n = (int64_t)d.B * d.Ein; }
+    else if (s == "dSy") { p = d.dSy + (size_t)((m->gstep - 1) & d.defer_mask) * (size_t)d.dSy_stride; n = (int64_t)d.ldSc * d.Dtop; }
+    else if (s == "dSBy") { p = d.dSBy + (size_t)((m->gstep - 1) & d.defer_mask) * (size_t)d.dSBy_stride; n = d.ldSc; }
+    else if (s == "defer_stats") {      // (rows applied by flush launches, bias entries, 1 if deferral is on, slots)
+        if (count < 4) return fail("count");
+        unsigned st4[4] = {0, 0, 0, 0};
+        if (m->defer_on) { HIPCHK(hipStreamSynchronize(m->stream)); HIPCHK(hipMemcpy(st4, d.dstat, sizeof(st4), hipMemcpyDeviceToHost)); }
+        host[0] = (float)st4[0]; host[1] = (float)st4[1]; host[2] = m->defer_on ? 1.f : 0.f; host[3] = (float)(d.defer_mask + 1);
+        return 0;
+    }
     else if (s == "dhpart") { p = d.dhpart; n = (int64_t)d.ksplit * d.B * d.Dtop; }
     else if (s == "lossrow") { p = d.lossrow; n = d.B; }
     else if (s == "hd") { p = d.hd[l]; n = bd; }

@@ -171,7 +171,22 @@ struct DevModel {
     GP(float) dyp;
     int bbn[G4R_MAX_LAYERS];
     GP(float) vp;        // K-slice partial sums of GRU phase 1, vp[slice][B][3D] (k_gru_p1s -> k_gru_gate)
+    // Deferred row updates (single GPU, Adagrad without momentum; g4r_step_kernels.cuh: k_defer_scan / k_sparse_flush).  The step
+    // planes dSx / dSy / dSBy are rings of defer_mask + 1 slots (slot = global step & defer_mask; 0: one plane, nothing is deferred):
+    // a row whose item is not gathered again before the end of the current window of steps keeps its step row in the ring and
+    // is applied by ONE flush launch per window -- the same arithmetic on the same operands, in a launch long enough for the HBM.
+    int defer_mask, dRcap;
+    long long dSx_stride, dSy_stride, dSBy_stride;      // floats between two slots
+    GP(int) last_use;    // [tables][n_items] newest scanned global step (low 32 bits) in which the item's row is gathered
+    GP(int) dcand;       // [slots][dRcap] 1: occurrence k of that step is its item's last use inside the window (k_defer_scan)
+    GP(int) dlist;       // [slots][dRcap] item of an occurrence whose row update is pending (written by its owner wave), else -1
+    GP(unsigned) dstat;  // [4] rows / bias entries applied by flush launches, flush launches, occurrences seen (statistics)
 };
+// step plane of global step g
+#define G4R_SLOT(m, g) ((size_t)((g) & (long long)(m).defer_mask))
+#define G4R_DSX(m, g) ((m).dSx + G4R_SLOT(m, g) * (size_t)(m).dSx_stride)
+#define G4R_DSY(m, g) ((m).dSy + G4R_SLOT(m, g) * (size_t)(m).dSy_stride)
+#define G4R_DSBY(m, g) ((m).dSBy + G4R_SLOT(m, g) * (size_t)(m).dSBy_stride)
 
 // In-kernel phase traces (tools/clk*.py) exist only in builds made with G4R_BUILD_CLK=1 (-DG4R_CLK_TRACE): a test of a
 // descriptor field at the top of a kernel makes its first instructions wait for the descriptor's scalar loads, which the vector

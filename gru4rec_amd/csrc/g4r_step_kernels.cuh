@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
         // this launch gathers the same Wy rows.
         GAS float *accWy = m.accWy, *accBy = m.accBy;
         const GAS int* occ_fl = m.occ_fl;
-        GAS float *dSy = m.dSy, *dAy = m.dAy, *dSBy = m.dSBy, *dABy = m.dABy;
+        GAS float *dSy = G4R_DSY(m, c.g), *dAy = m.dAy, *dSBy = G4R_DSBY(m, c.g), *dABy = m.dABy;
         const float lr = m.lr;
         const bool generic = m.generic != 0;
         auto pre = [&](int n, int d) -> float4 {
@@ -1248,7 +1248,7 @@ __global__ __launch_bounds__(256, G4R_BWD2_WPE) void k_score_bwd2(const DevModel
         };
         GAS float* accWy = m.accWy;
         const GAS int* occ_fl = m.occ_fl;
-        GAS float *dSy = m.dSy, *dAy = m.dAy;
+        GAS float *dSy = G4R_DSY(m, c.g), *dAy = m.dAy;
         auto pre = [&](int n, int d) -> float4 {      // (accumulator in place for single-occurrence items: see k_score_bwd)
             const int item = sIt[n - n0];
             const bool ok = item >= 0;
@@ -1317,7 +1317,7 @@ __global__ __launch_bounds__(256, G4R_BWD2_WPE) void k_score_bwd2(const DevModel
             const float an = ldf_at(m.accBy, max(item, 0), ok) + G4R_MUT_ACC(g * g);
             float step = ok ? G4R_MUT_STEP(lr * g * frsq(an + G4R_EPS_ADAGRAD)) : 0.f;
             if (generic) step = ok ? g : 0.f;
-            m.dSBy[n] = step;
+            G4R_DSBY(m, c.g)[n] = step;
             if (!generic && ok && cnt == 1) m.accBy[item] = an; else m.dABy[n] = an;
         }
     }
@@ -1427,7 +1427,7 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_bwd_b(const DevModel* __rest
     const float lr = m.lr, drop_e = m.drop_e;
     const bool generic = m.generic != 0;
     const unsigned long long seed = m.seed;
-    GAS float *dSx = m.dSx, *dAx = m.dAx, *dylo = (l > 0) ? m.dyl[l - 1] : nullptr;
+    GAS float *dSx = G4R_DSX(m, c.g), *dAx = m.dAx, *dylo = (l > 0) ? m.dyl[l - 1] : nullptr;
     auto pre = [&](int row, int n) -> float4 {      // pre-step accumulator of the input item's row (layer 0) and its occurrence count
         const int item = (row - m0 < GT_BM) ? sRow[row - m0] : -1;
         const int cnt = occ_fl[4 * (size_t)max(item, 0) + 2];
@@ -1672,7 +1672,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd_fused(const DevModel* __restric
     }
     const float lr = m.lr, drop_e = m.drop_e;
     const bool generic = m.generic != 0;
-    GAS float *dSx = m.dSx, *dAx = m.dAx, *dylo = (l > 0) ? m.dyl[l - 1] : nullptr;
+    GAS float *dSx = G4R_DSX(m, c.g), *dAx = m.dAx, *dylo = (l > 0) ? m.dyl[l - 1] : nullptr;
     const int n = n0 + ns2 * 16 + li;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
@@ -1719,8 +1719,8 @@ __global__ __launch_bounds__(256) void k_onehot_step(const DevModel* __restrict_
     const float4 an = make_float4(a.x + g.x * g.x, a.y + g.y * g.y, a.z + g.z * g.z, a.w + g.w * g.w);
     if (!m.generic && cnt == 1) st4(m.accE + (size_t)item * W + 4 * c4, an);      // single occurrence: in place (see k_score_bwd)
     else st4(m.dAx + (size_t)row * W + 4 * c4, an);
-    if (m.generic) { st4(m.dSx + (size_t)row * W + 4 * c4, g); return; }
-    st4(m.dSx + (size_t)row * W + 4 * c4, make_float4(lr * g.x * frsq(an.x + G4R_EPS_ADAGRAD), lr * g.y * frsq(an.y + G4R_EPS_ADAGRAD),
+    if (m.generic) { st4(G4R_DSX(m, c.g) + (size_t)row * W + 4 * c4, g); return; }
+    st4(G4R_DSX(m, c.g) + (size_t)row * W + 4 * c4, make_float4(lr * g.x * frsq(an.x + G4R_EPS_ADAGRAD), lr * g.y * frsq(an.y + G4R_EPS_ADAGRAD),
                                                          lr * g.z * frsq(an.z + G4R_EPS_ADAGRAD), lr * g.w * frsq(an.w + G4R_EPS_ADAGRAD)));
 }
 
@@ -2059,7 +2059,12 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     GAS float *tE = m.E, *tWy = m.Wy, *tvE = m.velE, *tvWy = m.velWy, *taE = m.accE, *taWy = m.accWy;
     const int wE = m.Ein, wY = m.Dtop;
     const GAS int* g_occ = m.occ_idx;
-    const GAS float *g_dSx = m.dSx, *g_dSy = m.dSy, *g_dSBy = m.dSBy;      // (the dA planes are only read by owners of repeated items: not snapshotted)
+    // step planes of this step (a ring of slots when row updates may be deferred: DevModel::defer_mask; the step's global index is
+    // read next to the wave's first loads -- *_b is not written by this launch)
+    constexpr bool CAN_DEFER = !MOM;
+    const int dmask = CAN_DEFER ? m.defer_mask : 0;
+    const long long gq = dmask ? ((const GAS StepState*)st)->g_b : 0;
+    const GAS float *g_dSx = G4R_DSX(m, gq), *g_dSy = G4R_DSY(m, gq), *g_dSBy = G4R_DSBY(m, gq);      // (the dA planes are only read by owners of repeated items: not snapshotted)
     if (blk == nblk_occ) {
         // ---- bookkeeping block: cost = sum_i L_i / batch_size (gru4rec.py:577), NaN flag (:626), advance state
         // (the only block of this role that needs the step context: the row update works from occ_idx / occ_fl alone)
@@ -2109,6 +2114,11 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
 #pragma unroll
     for (int q = 0; q < EARLY; ++q) ev[q] = g_occ4[early ? min(q * SP_WAVES * 64 + tid, n4 - 1) : 0];
     int item = g_occ[min(k, R - 1)];
+    // deferral candidate: this occurrence is its item's last use inside the current window of steps (k_defer_scan, from the plan and
+    // the sample store: known ahead).  If it also is the item's ONLY occurrence of this step, nothing will gather the row before the
+    // window's flush launch: the wave then moves no row at all -- the step row stays in its ring slot, the item goes to dlist.
+    const size_t dslot = (size_t)(gq & dmask) * (size_t)m.dRcap + (size_t)min(k, m.dRcap - 1);
+    const bool cand = dmask != 0 && k < R && m.dcand[dslot] != 0;      // wave-uniform
     if (k >= R) item = -1;
     // occurrence range sharing a table with k: constrained -> all of X|Y|samples ; separate -> X alone, Y|samples alone
     const int lo = (constrained || k < B) ? 0 : B;
@@ -2129,12 +2139,17 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     const GAS float* srow_k = (k_c < B) ? g_dSx + (size_t)k_c * W : g_dSy + (size_t)(k_c - B) * W;
     float4 pz[MAXCH], vz[MAXCH], sk[MAXCH];
 #pragma unroll
-    for (int q = 0; q < MAXCH; ++q) {
-        const int cc = 4 * min(lane + 64 * q, nc4 - 1);
-        pz[q] = ld4(P + (size_t)item_c * W + cc);
-        sk[q] = ld4(srow_k + cc);
-        vz[q] = mom ? ld4(V + (size_t)item_c * W + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int q = 0; q < MAXCH; ++q) { pz[q] = make_float4(0.f, 0.f, 0.f, 0.f); sk[q] = pz[q]; vz[q] = pz[q]; }
+    auto load_rows = [&]() {
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) {
+            const int cc = 4 * min(lane + 64 * q, nc4 - 1);
+            pz[q] = ld4(P + (size_t)item_c * W + cc);
+            sk[q] = ld4(srow_k + cc);
+            vz[q] = mom ? ld4(V + (size_t)item_c * W + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (!cand) load_rows();      // (a candidate waits for its entry: most candidates are deferred and never touch their rows)
     float bpz = 0.f, bvz = 0.f, bsk = 0.f;
     if (bias) {
         bpz = m.By[item_c]; bsk = g_dSBy[k_c - B];
@@ -2148,6 +2163,9 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     // same item row, same bias, no column of them is anybody's positive -- so k_loss_rows / k_score_bwd produced bit-identical
     // step rows for them and the sum over the earlier occurrences is (count - 1) x this wave's own row, added one at a time in
     // the order the list walk would have used: no occurrence list, no second round trip for the step rows.
+    const bool deferred = cand && owner && fl.z == 1;      // wave-uniform
+    if (dmask != 0 && lane == 0 && k < m.dRcap) m.dlist[dslot] = deferred ? item : -1;
+    if (cand && !deferred) load_rows();      // a candidate that repeats inside its own step (or is not an owner): the usual path, one round trip later
     const bool allsmp = owner && fl.z > 1 && first_j >= 2 * B;
     const bool dup = owner && fl.z > 1 && !allsmp;
     const bool hot = owner && fl.z - 1 > HOT && !allsmp;
@@ -2195,7 +2213,7 @@ __device__ __forceinline__ void sparse_update_block(const DevModel* __restrict__
     // ---- the common case: the item's only occurrence.  Its accumulator is already in place (written by the producer of the step
     // row); parameter (and velocity) rows are final right here, ahead of the workgroup's barrier
     const bool single = owner && fl.z == 1;
-    if (single) finish(S, 0.f, 1, bias ? 1 : 0);
+    if (single && !deferred) finish(S, 0.f, 1, bias ? 1 : 0);
     // owners of items with several occurrences: the last occurrence's accumulator row (dA plane), requested now that the count
     // is known -- it lands during the barrier / the list walk below
     float4 ak[MAXCH];
@@ -2414,6 +2432,93 @@ __global__ __launch_bounds__(SP_WAVES * 64, MAXCH > 2 ? 2 : 4) void k_sparse_upd
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // workgroup 0 does the step bookkeeping (it depends on nothing the other workgroups produce; dispatched first, it is off the tail)
     sparse_update_block<MAXCH, MOM>(mp, st, nblk_occ, blockIdx.x == 0 ? nblk_occ : (int)blockIdx.x - 1, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deferred row updates: one flush launch per window of steps (a window = one replay of the step graph, <= 16 steps).
+// A launch that moves one step's rows is too short for the HBM: the bare scatter pattern reaches 41-47 % of 8 TB/s at one step's rows and
+// 72-77 % at 4-16 steps' rows (profiles/r02_micro_rows.json).  The plan (in_idx / out_idx of every step) and the sample store are known
+// ahead, so for a window of steps it is known which occurrence is the LAST use of its item inside the window; if that occurrence also
+// is the item's only one in its step, nothing gathers the row again before the window ends, and its update
+//     P[item] -= step row (+ lr lmbd P[item]),   By[item] -= bias step            (gru4rec.py:420-431, one occurrence)
+// can wait for the end of the window: same operands, same arithmetic, same bits as applying it at once (asserted: tests/
+// test_gpu_defer.py).  The accumulators never wait (the gradient producers write them in place for single occurrences).
+//   k_defer_scan pass 0: last_use[item] = max(global step) over the window's occurrences (X | Y | samples of every step)
+//                pass 1: dcand[slot][k] = (last_use[item of occurrence k of step s] == that step)
+//   k_update / k_sparse_update: a candidate that owns a single-occurrence item moves nothing and leaves dlist[slot][k] = item
+//   k_sparse_flush: one wave per (step, occurrence) of the window: pending rows applied -- three row transfers each, in ONE launch over
+//                up to 16 steps' rows; takes dcand / dlist back to 0 / -1.
+// Windows never span a g4r_train_steps call, a sample-store refill or a compaction (the host loop launches scan, graph replay, flush).
+__device__ __forceinline__ int defer_item(const DevModel& m, long long t, long long g, int k, int& table) {
+    const int B = m.B, M = m.Mplan[t];
+    table = 0;
+    int item = -1;
+    if (k < B) { if (k < M) item = m.in_idx[t * B + k]; table = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? 0 : 1; }
+    else if (k < 2 * B) { if (k - B < M) item = m.out_idx[t * B + (k - B)]; }
+    else if (M > 0) item = m.ST[(size_t)(m.gl > 0 ? g % m.gl : 0) * m.ns + (k - 2 * B)];
+    return item;
+}
+__global__ __launch_bounds__(256) void k_defer_scan(const DevModel* __restrict__ mp, long long t0, long long g0, int n, int pass) {
+    const DevModel& m = *mp;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int R = m.R, s = (int)(idx / R), k = (int)(idx - (long long)s * R);
+    if (s >= n) return;
+    int table;
+    const int item = defer_item(m, t0 + s, g0 + s, k, table);
+    const size_t slot = G4R_SLOT(m, g0 + s) * (size_t)m.dRcap + k;
+    if (item < 0) { if (pass) m.dcand[slot] = 0; return; }
+    GAS int* lu = m.last_use + (size_t)table * m.n_items + item;
+    if (pass == 0) atomicMax((int*)lu, (int)(g0 + s));
+    else m.dcand[slot] = (*lu == (int)(g0 + s)) ? 1 : 0;
+}
+__global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_flush(const DevModel* __restrict__ mp, long long g0, int n) {
+    const DevModel& m = *mp;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * SP_WAVES + wid;
+    const int Rc = m.dRcap, s = (int)(idx / Rc), k = (int)(idx - (long long)s * Rc);
+    if (s >= n) return;
+    const size_t slot = G4R_SLOT(m, g0 + s) * (size_t)Rc + k;
+    const int item = m.dlist[slot];
+    if (lane == 0) { m.dcand[slot] = 0; if (item >= 0) m.dlist[slot] = -1; }
+    if (item < 0) return;
+    const int B = m.B;
+    const bool tableE = (k < B && m.embed_mode != G4R_EMBED_CONSTRAINED);
+    GAS float* P = tableE ? m.E : m.Wy;
+    const int W = tableE ? m.Ein : m.Dtop, nc4 = W >> 2;
+    const GAS float* srow = (k < B) ? G4R_DSX(m, g0 + s) + (size_t)k * W : G4R_DSY(m, g0 + s) + (size_t)(k - B) * W;
+    const float lr = m.lr, lmbd = m.lmbd;
+    float bp = 0.f, bs = 0.f;
+    if (k >= B && lane == 0) { bp = m.By[item]; bs = G4R_DSBY(m, g0 + s)[k - B]; }
+    for (int c4 = lane; c4 < nc4; c4 += 256) {      // (rows of <= 1024 floats: up to four quads per lane, all requested together)
+        float4 p[4], g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cc = 4 * min(c4 + 64 * q, nc4 - 1);
+            p[q] = ld4(P + (size_t)item * W + cc);
+            g[q] = ld4(srow + cc);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (c4 + 64 * q >= nc4) continue;
+            const float p0[4] = {p[q].x, p[q].y, p[q].z, p[q].w}, sl[4] = {g[q].x, g[q].y, g[q].z, g[q].w};
+            float pn[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {      // exactly sparse_update_block::finish for one occurrence: ss = 0 + s_k, fn = 1
+                const float ss = 0.f + sl[e];
+                const float reg = (lmbd > 0.f) ? lr * lmbd * p0[e] : 0.f;
+                const float tot = (lmbd > 0.f) ? ss + 1.0f * reg : ss;
+                pn[e] = p0[e] - tot;
+            }
+            st4(P + (size_t)item * W + 4 * (c4 + 64 * q), make_float4(pn[0], pn[1], pn[2], pn[3]));
+        }
+    }
+    if (k >= B && lane == 0) {
+        const float reg = (lmbd > 0.f) ? lr * lmbd * bp : 0.f;
+        const float sb = 0.f + bs;
+        const float tot = (lmbd > 0.f) ? sb + 1.0f * reg : sb;
+        m.By[item] = bp - tot;
+    }
+    if (lane == 0) { atomicAdd((unsigned*)m.dstat, 1u); if (k >= B) atomicAdd((unsigned*)m.dstat + 1, 1u); }
 }
 
 // Single GPU: the dense-gradient tiles (+ fused dense Adagrad) and the sparse row update are independent of each other

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_grad2(const DevModel* __restri
         const float4 an = make_float4(a0.x + G4R_MUT_ACC(g.x * g.x), a0.y + G4R_MUT_ACC(g.y * g.y), a0.z + G4R_MUT_ACC(g.z * g.z), a0.w + G4R_MUT_ACC(g.w * g.w));
         const float4 stp = generic ? g : make_float4(G4R_MUT_STEP(lr * g.x * frsq(an.x + G4R_EPS_ADAGRAD)), G4R_MUT_STEP(lr * g.y * frsq(an.y + G4R_EPS_ADAGRAD)),
                                                      G4R_MUT_STEP(lr * g.z * frsq(an.z + G4R_EPS_ADAGRAD)), G4R_MUT_STEP(lr * g.w * frsq(an.w + G4R_EPS_ADAGRAD)));
-        st4(m.dSx + o, stp);
+        st4(G4R_DSX(m, c.g) + o, stp);
         if (!generic && cnt1 == 1 && item >= 0) st4(accT + (size_t)item * IN + c4, an);
         else st4(m.dAx + o, an);
         return;

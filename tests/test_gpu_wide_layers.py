@@ -26,7 +26,7 @@ SHAPES = {
     'separate_embedding_128_to_384': (2000, 64, 256, 6, dict(loss='bpr-max', final_act='elu-0.5', constrained_embedding=False, embedding=128,
                                                              layers=(384,), learning_rate=0.1, bpreg=0.5)),
     'rmsprop_generic_path': (2000, 96, 256, 6, dict(loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(256,),
-                                                    learning_rate=0.05, bpreg=1.0, adapt='rmsprop', dropout_p_embed=0.1)),
+                                                    learning_rate=0.05, bpreg=1.0, adapt='rmsprop', adapt_params=[0.9], dropout_p_embed=0.1)),
 }
 
 
