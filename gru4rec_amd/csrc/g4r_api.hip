@@ -408,7 +408,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         DA(rx, W * (size_t)d.dSx_stride); DA(ry, W * (size_t)d.dSy_stride); DA(rb, W * (size_t)d.dSBy_stride);
         d.dSx = rx; d.dSy = ry; d.dSBy = rb;
         DA(d.last_use, (size_t)(cfg->embed_mode != G4R_EMBED_CONSTRAINED ? 2 : 1) * I);
-        DA(d.dcand, W * (size_t)d.dRcap); DA(d.dlist, W * (size_t)d.dRcap); DA(d.dstat, 4);
+        DA(d.dcand, W * (size_t)d.dRcap); DA(d.dlist, W * (size_t)d.dRcap); DA(d.dstat, 2048);
         if (hipMemsetAsync(d.dlist, 0xFF, W * (size_t)d.dRcap * sizeof(int), m->stream) != hipSuccess) { g4r_destroy(m); return fail("dlist init"); }
         for (auto& e : m->ev_df) if (hipEventCreate(&e) != hipSuccess) { g4r_destroy(m); return fail("event create"); }
     }
@@ -2321,9 +2321,14 @@ int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
     else if (s == "dSBy") { p = d.dSBy + (size_t)((m->gstep - 1) & d.defer_mask) * (size_t)d.dSBy_stride; n = d.ldSc; }
     else if (s == "defer_stats") {      // (rows applied by flush launches, bias entries, 1 if deferral is on, slots)
         if (count < 4) return fail("count");
-        unsigned st4[4] = {0, 0, 0, 0};
-        if (m->defer_on) { HIPCHK(hipStreamSynchronize(m->stream)); HIPCHK(hipMemcpy(st4, d.dstat, sizeof(st4), hipMemcpyDeviceToHost)); }
-        host[0] = (float)st4[0]; host[1] = (float)st4[1]; host[2] = m->defer_on ? 1.f : 0.f; host[3] = (float)(d.defer_mask + 1);
+        double rows = 0, bias = 0;
+        if (m->defer_on) {
+            std::vector<unsigned> st(2048);
+            HIPCHK(hipStreamSynchronize(m->stream));
+            HIPCHK(hipMemcpy(st.data(), d.dstat, st.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < st.size(); i += 2) { rows += st[i]; bias += st[i + 1]; }
+        }
+        host[0] = (float)rows; host[1] = (float)bias; host[2] = m->defer_on ? 1.f : 0.f; host[3] = (float)(d.defer_mask + 1);
         return 0;
     }
     else if (s == "dhpart") { p = d.dhpart; n = (int64_t)d.ksplit * d.B * d.Dtop; }

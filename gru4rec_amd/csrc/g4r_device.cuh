@@ -180,7 +180,7 @@ struct DevModel {
     GP(int) last_use;    // [tables][n_items] newest scanned global step (low 32 bits) in which the item's row is gathered
     GP(int) dcand;       // [slots][dRcap] 1: occurrence k of that step is its item's last use inside the window (k_defer_scan)
     GP(int) dlist;       // [slots][dRcap] item of an occurrence whose row update is pending (written by its owner wave), else -1
-    GP(unsigned) dstat;  // [4] rows / bias entries applied by flush launches, flush launches, occurrences seen (statistics)
+    GP(unsigned) dstat;  // [1024][2] rows / bias entries applied by flush launches, per workgroup id mod 1024 (statistics)
 };
 // step plane of global step g
 #define G4R_SLOT(m, g) ((size_t)((g) & (long long)(m).defer_mask))
