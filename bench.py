@@ -165,7 +165,7 @@ def make_plan(cfg, n_steps, rank, nranks, seed=42, session_items=0):
     return plan, support
 
 
-def create_model(cfg, support, rank, nranks, device, unique_id, use_graph=True, seed=12345, sample_store=10000000, sparse_exact=False):
+def create_model(cfg, support, rank, nranks, device, unique_id, use_graph=True, seed=12345, sample_store=10000000, sparse_exact=False, defer=False):
     from gru4rec_amd import _native
     from gru4rec_amd.gru4rec import _parse_act
     fa = _parse_act(cfg['final_act'], True)
@@ -176,7 +176,7 @@ def create_model(cfg, support, rank, nranks, device, unique_id, use_graph=True, 
         learning_rate=cfg['learning_rate'], momentum=cfg['momentum'], lmbd=0.0, bpreg=cfg['bpreg'], logq=cfg['logq'],
         sample_alpha=cfg['sample_alpha'], dropout_p_hidden=cfg['dropout_p_hidden'],
         dropout_p_embed=cfg['dropout_p_embed'], sample_store=sample_store, seed=seed + (0 if sparse_exact else 7919 * rank), device=device,
-        rank=rank, nranks=nranks, use_graph=1 if use_graph else 0, sparse_exact=3 if sparse_exact else 0)
+        rank=rank, nranks=nranks, use_graph=1 if use_graph else 0, sparse_exact=3 if sparse_exact else 0, defer_updates=1 if defer else 0)
     if nranks > 1:
         m.comm_init(unique_id, nranks, rank)
     elif os.environ.get('G4R_FORCE_STAGED'):      # diagnostic: the N > 1 data path with a one-rank communicator
@@ -248,6 +248,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-micro', action='store_true', help='skip the row gather / scatter micro-benchmark object')
+    ap.add_argument('--defer', action='store_true', help='deferred row updates (g4r_config::defer_updates): one flush launch per window of 16 steps; bit-identical '
+                    'results, the flush launch is priced in roofline_gather_scatter.deferred_flush')
     ap.add_argument('--sparse-exact', action='store_true', help='N > 1 (or G4R_FORCE_STAGED=1): the exact-replica mode (REDUCE form) instead of GPU-local '
                     'item rows + reconciliation: per-occurrence gradient rows all-gathered every step, nothing to reconcile')
     ap.add_argument('--session-items', type=int, default=0, help='distinct items the synthetic sessions are drawn from (0 = the whole catalogue of the '
@@ -276,7 +278,7 @@ def main():
     plan, support = make_plan(cfg, total_steps, rank, world, session_items=args.session_items)
     assert plan['T'] >= total_steps, 'synthetic plan too short: %d < %d' % (plan['T'], total_steps)
     assert (plan['M'][:total_steps] == cfg['batch_size']).all()
-    m = create_model(cfg, support, rank, world, local_rank if world > 1 else 0, unique_id, use_graph=not args.no_graph, sparse_exact=args.sparse_exact)
+    m = create_model(cfg, support, rank, world, local_rank if world > 1 else 0, unique_id, use_graph=not args.no_graph, sparse_exact=args.sparse_exact, defer=args.defer)
     n_ranks = m.comm_nranks()      # what RCCL reports for the communicator (1 without one): n_gpus in the output is THIS number
     if n_ranks != world:
         raise SystemExit('RCCL communicator has %d rank(s), expected %d' % (n_ranks, world))
@@ -351,6 +353,7 @@ def main():
         'events_per_s': events / dt, 'loss_first': float(losses[0]), 'loss_last': float(losses[-1]),
         'loss_finite': bool(np.isfinite(losses).all()),
     }
+    out['config']['defer_updates'] = bool(args.defer)
     if long_run:
         out['long_run'] = long_run
     if sync_in_timed:

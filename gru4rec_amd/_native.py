@@ -32,7 +32,7 @@ class G4RConfig(C.Structure):
         ('sample_store', C.c_int64), ('seed', C.c_uint64),
         ('device', C.c_int32), ('rank', C.c_int32), ('nranks', C.c_int32), ('use_graph', C.c_int32),
         ('smoothing', C.c_float), ('adapt', C.c_int32), ('adapt_p0', C.c_float), ('adapt_p1', C.c_float),
-        ('grad_cap', C.c_float), ('sparse_exact', C.c_int32), ('reserved', C.c_int32),
+        ('grad_cap', C.c_float), ('sparse_exact', C.c_int32), ('defer_updates', C.c_int32),
     ]
 
 

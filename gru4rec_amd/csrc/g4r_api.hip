@@ -395,8 +395,12 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     }
     DA(d.dAx, (size_t)B * d.Ein); DA(d.dAy, (size_t)d.ldSc * d.Dtop); DA(d.dABy, d.ldSc);
     // Deferred row updates (g4r_step_kernels.cuh: k_defer_scan / k_sparse_flush): the single-GPU Adagrad step without momentum / L2 term, replayed
-    // from the step graph.  The step planes become rings of G4R_GRAPH_STEPS slots (one window = one graph replay).  G4R_DEFER=0: off.
-    m->defer_on = d.apply_dense_inplace && !d.generic && cfg->momentum <= 0.f && cfg->lmbd == 0.f && cfg->use_graph && env_int("G4R_DEFER", 1) != 0;
+    // from the step graph.  The step planes become rings of G4R_GRAPH_STEPS slots (one window = one graph replay).  OPT-IN (G4R_DEFER=1;
+    // GRU4Rec.defer_updates, bench.py --defer): bit-identical results and a flush launch at 59 % of the HBM peak on the bytes it
+    // moves at BASELINE configs[2] -- but the step gets 2-5 % SLOWER, because the update launch it relieves is at its latency floor
+    // (cfg3: k_sparse_update 7.5 -> 6.2 us with 90 % of the rows gone) or bound by its dense-gradient tiles (cfg4), and the flush
+    // (2.9 / 7.4 us per step) and scan (0.7 / 1.1) come on top (profiles/r05_experiments.md #7).
+    m->defer_on = d.apply_dense_inplace && !d.generic && cfg->momentum <= 0.f && cfg->lmbd == 0.f && cfg->use_graph && env_int("G4R_DEFER", cfg->defer_updates) != 0;
     if (m->defer_on) {
         const size_t W = G4R_DEFER_SLOTS;
         d.defer_mask = (int)W - 1;
@@ -1317,7 +1321,7 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
         auto window_close = [&](int64_t nw, int64_t first) -> int {
             if (!m->defer_on) return 0;
             if (m->profiling) (void)hipEventRecord(m->ev_df[2], m->stream);
-            hipLaunchKernelGGL(k_sparse_flush, dim3(cdiv(nw * m->dm.dRcap, SP_WAVES)), dim3(SP_WAVES * 64), 0, m->stream, (const DevModel*)m->d_dm, (long long)(m->gstep + first), (int)nw);
+            hipLaunchKernelGGL(k_sparse_flush, dim3(cdiv(nw * m->dm.dRcap, SP_WAVES * FL_NR)), dim3(SP_WAVES * 64), 0, m->stream, (const DevModel*)m->d_dm, (long long)(m->gstep + first), (int)nw);
             if (m->profiling) {
                 (void)hipEventRecord(m->ev_df[3], m->stream);
                 HIPCHK(hipStreamSynchronize(m->stream));

@@ -2471,56 +2471,77 @@ __global__ __launch_bounds__(256) void k_defer_scan(const DevModel* __restrict__
     if (pass == 0) atomicMax((int*)lu, (int)(g0 + s));
     else m.dcand[slot] = (*lu == (int)(g0 + s)) ? 1 : 0;
 }
+#define FL_NR 4      // pending entries per wave: their row requests are in flight together (rows of <= 256 floats)
 __global__ __launch_bounds__(SP_WAVES * 64) void k_sparse_flush(const DevModel* __restrict__ mp, long long g0, int n) {
     const DevModel& m = *mp;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const long long idx = (long long)blockIdx.x * SP_WAVES + wid;
-    const int Rc = m.dRcap, s = (int)(idx / Rc), k = (int)(idx - (long long)s * Rc);
+    const long long e0 = ((long long)blockIdx.x * SP_WAVES + wid) * FL_NR;      // first entry of this wave (dRcap is a multiple of 8: a group stays inside one step)
+    const int Rc = m.dRcap, s = (int)(e0 / Rc), k0 = (int)(e0 - (long long)s * Rc);
     if (s >= n) return;
-    const size_t slot = G4R_SLOT(m, g0 + s) * (size_t)Rc + k;
-    const int item = m.dlist[slot];
-    if (lane == 0) { m.dcand[slot] = 0; if (item >= 0) m.dlist[slot] = -1; }
-    if (item < 0) return;
+    const size_t slot = G4R_SLOT(m, g0 + s) * (size_t)Rc + k0;
+    int it[FL_NR];
+#pragma unroll
+    for (int u = 0; u < FL_NR; ++u) it[u] = m.dlist[slot + u];
+    if (lane < FL_NR) { m.dcand[slot + lane] = 0; m.dlist[slot + lane] = -1; }
     const int B = m.B;
-    const bool tableE = (k < B && m.embed_mode != G4R_EMBED_CONSTRAINED);
-    GAS float* P = tableE ? m.E : m.Wy;
-    const int W = tableE ? m.Ein : m.Dtop, nc4 = W >> 2;
-    const GAS float* srow = (k < B) ? G4R_DSX(m, g0 + s) + (size_t)k * W : G4R_DSY(m, g0 + s) + (size_t)(k - B) * W;
+    const bool sep = m.embed_mode != G4R_EMBED_CONSTRAINED;
+    const GAS float *sx = G4R_DSX(m, g0 + s), *sy = G4R_DSY(m, g0 + s), *sb = G4R_DSBY(m, g0 + s);
     const float lr = m.lr, lmbd = m.lmbd;
-    float bp = 0.f, bs = 0.f;
-    if (k >= B && lane == 0) { bp = m.By[item]; bs = G4R_DSBY(m, g0 + s)[k - B]; }
-    for (int c4 = lane; c4 < nc4; c4 += 256) {      // (rows of <= 1024 floats: up to four quads per lane, all requested together)
-        float4 p[4], g[4];
+    // exactly sparse_update_block::finish for ONE occurrence (ss = 0 + s_k, fn = 1)
+    auto upd = [&](float p0, float sl) { const float ss = 0.f + sl; const float reg = (lmbd > 0.f) ? lr * lmbd * p0 : 0.f; return p0 - ((lmbd > 0.f) ? ss + 1.0f * reg : ss); };
+    int napp = 0, nbias = 0;
+    const int wmax = max(m.Ein, m.Dtop);
+    if (wmax <= 256) {
+        float4 p[FL_NR], g[FL_NR];
+        float bp = 0.f, bs = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int cc = 4 * min(c4 + 64 * q, nc4 - 1);
-            p[q] = ld4(P + (size_t)item * W + cc);
-            g[q] = ld4(srow + cc);
+        for (int u = 0; u < FL_NR; ++u) {
+            const int k = k0 + u, item = max(it[u], 0);
+            const bool tE = k < B && sep;
+            const int W = tE ? m.Ein : m.Dtop, cc = 4 * min(lane, (W >> 2) - 1);
+            const GAS float* P = tE ? m.E : m.Wy;
+            const GAS float* srow = (k < B) ? sx + (size_t)min(k, B - 1) * W : sy + (size_t)(k - B) * W;
+            p[u] = ld4(P + (size_t)item * W + cc);
+            g[u] = ld4(it[u] >= 0 ? srow + cc : P + (size_t)item * W + cc);
+            if (lane == u && it[u] >= 0 && k >= B) { bp = m.By[item]; bs = sb[k - B]; }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (c4 + 64 * q >= nc4) continue;
-            const float p0[4] = {p[q].x, p[q].y, p[q].z, p[q].w}, sl[4] = {g[q].x, g[q].y, g[q].z, g[q].w};
-            float pn[4];
+        for (int u = 0; u < FL_NR; ++u) {
+            if (it[u] < 0) continue;      // wave-uniform
+            const int k = k0 + u;
+            const bool tE = k < B && sep;
+            const int W = tE ? m.Ein : m.Dtop;
+            GAS float* P = tE ? m.E : m.Wy;
+            if (lane < (W >> 2)) st4(P + (size_t)it[u] * W + 4 * lane, make_float4(upd(p[u].x, g[u].x), upd(p[u].y, g[u].y), upd(p[u].z, g[u].z), upd(p[u].w, g[u].w)));
+            if (lane == u && k >= B) m.By[it[u]] = upd(bp, bs);
+            ++napp; nbias += (k >= B) ? 1 : 0;
+        }
+    } else {
+        for (int u = 0; u < FL_NR; ++u) {
+            if (it[u] < 0) continue;
+            const int k = k0 + u, item = it[u];
+            const bool tE = k < B && sep;
+            const int W = tE ? m.Ein : m.Dtop, nc4 = W >> 2;
+            GAS float* P = tE ? m.E : m.Wy;
+            const GAS float* srow = (k < B) ? sx + (size_t)k * W : sy + (size_t)(k - B) * W;
+            float4 p[4], g[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {      // exactly sparse_update_block::finish for one occurrence: ss = 0 + s_k, fn = 1
-                const float ss = 0.f + sl[e];
-                const float reg = (lmbd > 0.f) ? lr * lmbd * p0[e] : 0.f;
-                const float tot = (lmbd > 0.f) ? ss + 1.0f * reg : ss;
-                pn[e] = p0[e] - tot;
+            for (int q = 0; q < 4; ++q) {      // rows of <= 1024 floats: up to four quads per lane, all requested together
+                const int cc = 4 * min(lane + 64 * q, nc4 - 1);
+                p[q] = ld4(P + (size_t)item * W + cc);
+                g[q] = ld4(srow + cc);
             }
-            st4(P + (size_t)item * W + 4 * (c4 + 64 * q), make_float4(pn[0], pn[1], pn[2], pn[3]));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (lane + 64 * q < nc4)
+                    st4(P + (size_t)item * W + 4 * (lane + 64 * q), make_float4(upd(p[q].x, g[q].x), upd(p[q].y, g[q].y), upd(p[q].z, g[q].z), upd(p[q].w, g[q].w)));
+            if (k >= B && lane == 0) m.By[item] = upd(m.By[item], sb[k - B]);
+            ++napp; nbias += (k >= B) ? 1 : 0;
         }
-    }
-    if (k >= B && lane == 0) {
-        const float reg = (lmbd > 0.f) ? lr * lmbd * bp : 0.f;
-        const float sb = 0.f + bs;
-        const float tot = (lmbd > 0.f) ? sb + 1.0f * reg : sb;
-        m.By[item] = bp - tot;
     }
     // statistics (bench.py, tests): 1024 counter pairs, one per workgroup id mod 1024 -- a single counter serialised 10^5 atomics per launch
     // (11-13 ns each: the launch took milliseconds)
-    if (lane == 0) { GAS unsigned* ds = m.dstat + 2 * (blockIdx.x & 1023u); atomicAdd((unsigned*)ds, 1u); if (k >= B) atomicAdd((unsigned*)ds + 1, 1u); }
+    if (lane == 0 && napp) { GAS unsigned* ds = m.dstat + 2 * (blockIdx.x & 1023u); atomicAdd((unsigned*)ds, (unsigned)napp); if (nbias) atomicAdd((unsigned*)ds + 1, (unsigned)nbias); }
 }
 
 // Single GPU: the dense-gradient tiles (+ fused dense Adagrad) and the sparse row update are independent of each other

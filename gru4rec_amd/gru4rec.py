@@ -140,6 +140,10 @@ class GRU4Rec:
         # ranks), not against all nranks x batch_size targets.  Kept for the A/B of DESIGN.md section 7: 'mean' (every rank's occurrences listed, an item's increment = the mean
         # over the ranks touching it) and 'sum' (every occurrence of every rank applied like a duplicate: diverges from four ranks on)
         self.sparse_exact = False
+        # single GPU, Adagrad without momentum / lmbd: row updates whose item is not gathered again inside the current window of 16 steps
+        # wait for ONE flush launch per window (g4r_config::defer_updates).  Results are bit-identical; the flush launch runs at ~60 % of
+        # the HBM peak at BASELINE configs[2] -- and the step gets 2-5 % slower: off unless asked for
+        self.defer_updates = False
         self._model = None
         self._dist = None
         self._cpu_store = False
@@ -339,7 +343,8 @@ class GRU4Rec:
             # (gru4rec.py:436-437), and every sampled item is touched by all ranks, whose increments are averaged
             sample_store=int(sample_store), seed=int(self.seed) + (0 if self.sparse_exact else 7919 * rank), device=int(self.device),
             rank=rank, nranks=nranks, use_graph=1 if self.use_graph else 0,
-            sparse_exact=({'sum': 1, 'mean': 2, 'reduce': 3}.get(self.sparse_exact, 3) if (self.sparse_exact and nranks > 1) else 0))
+            sparse_exact=({'sum': 1, 'mean': 2, 'reduce': 3}.get(self.sparse_exact, 3) if (self.sparse_exact and nranks > 1) else 0),
+            defer_updates=1 if getattr(self, 'defer_updates', False) else 0)
         if self._dist and self._dist['unique_id'] is not None:
             m.comm_init(self._dist['unique_id'], nranks, rank)
             if nranks > 1:
@@ -738,7 +743,7 @@ class GRU4Rec:
                                   'exposes the same computation through gru4rec_amd.evaluation.evaluate_gpu')
 
     # ------------------------------------------------------------------ (de)serialisation (gru4rec.py:742-781)
-    _EXTRAS = dict(seed=12345, device=0, use_graph=True, steps_per_call=16384, sync_every='auto', sparse_exact=False)     # attributes the reference does not have
+    _EXTRAS = dict(seed=12345, device=0, use_graph=True, steps_per_call=16384, sync_every='auto', sparse_exact=False, defer_updates=False)     # attributes the reference does not have
 
     def __getstate__(self):
         st = dict(self.__dict__)

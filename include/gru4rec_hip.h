@@ -88,7 +88,11 @@ typedef struct g4r_config {
                                     Mode 3 checks every step that the ranks' negatives are the same ids (a rank in the padded tail of
                                     its plan holds none: the ids then come from the first rank that has them); a mismatch turns the
                                     step's cost into NaN on every rank -- the run stops at the caller's NaN check */
-    int32_t reserved;
+    int32_t defer_updates;       /* 1 (or G4R_DEFER=1 in the environment): single GPU, Adagrad without momentum / lmbd, graph replay -- the update of a
+                                    gathered row (gru4rec.py:420-431) whose item is not gathered again inside the current window of 16 steps (known
+                                    ahead from the plan and the sample store) is applied by ONE flush launch at the end of the window instead of by
+                                    its step's update launch: the same operands and arithmetic, bit-identical results, a launch long enough for the
+                                    HBM (~60 % of 8 TB/s at BASELINE configs[2]); costs 2-5 % of the step rate */
 } g4r_config;
 
 typedef struct g4r_model g4r_model;

@@ -80,8 +80,33 @@ def test_deferred_updates_leave_identical_bits(case):
 
 def test_deferral_is_off_where_it_does_not_apply():
     """Momentum (velocity rows), an L2 term and the generic optimizers keep the immediate update."""
-    for kw in (dict(momentum=0.1), dict(lmbd=1e-4), dict(adapt='rmsprop', adapt_params=[0.9])):
-        o, m = make_pair(500, 16, 32, store_rows=8, use_graph=1, loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(16,),
-                         learning_rate=0.1, **kw)
-        assert m.get_debug('defer_stats', 4)[2] == 0, kw
-        m.close()
+    old = os.environ.get('G4R_DEFER')
+    os.environ['G4R_DEFER'] = '1'
+    try:
+        for kw, want in ((dict(momentum=0.1), 0), (dict(lmbd=1e-4), 0), (dict(adapt='rmsprop', adapt_params=[0.9]), 0), (dict(), 1)):
+            o, m = make_pair(500, 16, 32, store_rows=8, use_graph=1, loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(16,),
+                             learning_rate=0.1, **kw)
+            assert m.get_debug('defer_stats', 4)[2] == want, kw
+            m.close()
+    finally:
+        if old is None:
+            os.environ.pop('G4R_DEFER', None)
+        else:
+            os.environ['G4R_DEFER'] = old
+
+
+def test_defer_updates_through_the_public_class():
+    """GRU4Rec.defer_updates = True: one epoch ends with the same weights, bit for bit, as the default."""
+    from gru4rec_amd import synth
+    from gru4rec_amd.gru4rec import GRU4Rec
+    data = synth.make_sessions(3000, n_items=800, seed=3)
+    out = []
+    for flag in (False, True):
+        g = GRU4Rec(loss='bpr-max', final_act='elu-0.5', layers=[32], batch_size=32, n_sample=64, constrained_embedding=True, learning_rate=0.1,
+                    bpreg=1.0, n_epochs=1)
+        g.defer_updates = flag
+        g.fit(data.copy(), sample_store=64 * 100)
+        out.append((g.Wy.copy(), g.By.copy(), g.Wx[0].copy()))
+        g.close()
+    for a, b in zip(*out):
+        np.testing.assert_array_equal(a, b)

@@ -1,6 +1,6 @@
 #!/bin/bash
 ROOT=$(cd "$(dirname "$0")/.." && pwd); OUT=$ROOT/gpurun_out/r5; mkdir -p $OUT; cd $ROOT
-timeout 600 python -m pytest tests/test_gpu_defer.py tests/test_gpu_parity.py::test_graph_replay_is_bit_identical_to_eager -x -q -s 2>&1 | tail -15
+timeout 600 python -m pytest tests/test_gpu_defer.py tests/test_gpu_wide_layers.py -x -q 2>&1 | tail -15
 run() {  # name cfg steps env...
   name=$1; c=$2; steps=$3; shift 3
   env "$@" timeout 300 python bench.py --config $c --steps $steps --warmup 100 --no-cpu-baseline --no-micro --long-steps 0 > $OUT/df_${name}_${c}.json 2> $OUT/df_${name}_${c}.err
