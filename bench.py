@@ -223,19 +223,27 @@ def cpu_baseline(cfg, plan, support, budget_s=15.0):
     o.make_sample_store(cfg['n_sample'] * 64)       # a short store: the refill cost is not what is being timed
     for t in range(3):
         o.train_step(plan['in_idx'][t], plan['out_idx'][t], int(plan['M'][t]), plan['reset'][t])
-    t0 = time.time()
-    n = ev = 0
+    # three consecutive windows of budget_s / 3 each, the BEST one reported: the host is a shared 256-CPU box and a single 15 s
+    # sample swung 28 - 38 mini-batches/s between rounds on the same code (context, not a comparator: the roofline fraction is)
     t = 3
-    while time.time() - t0 < budget_s and t < plan['T']:
-        M = int(plan['M'][t])
-        o.train_step(plan['in_idx'][t], plan['out_idx'][t], M, plan['reset'][t])
-        n += 1
-        ev += M
-        t += 1
-    dt = time.time() - t0
-    return dict(value=n / dt, unit='mini-batches/s', cores=int(threads), kind='port',
-                sample='%d steps (%d events) of the same plan, NumPy/BLAS fp32 oracle, %.1f s' % (n, ev, dt),
-                events_per_s=ev / dt, host_cpus=os.cpu_count())
+    wins = []
+    for w in range(3):
+        t0 = time.time()
+        n = ev = 0
+        while time.time() - t0 < budget_s / 3.0 and t < plan['T']:
+            M = int(plan['M'][t])
+            o.train_step(plan['in_idx'][t], plan['out_idx'][t], M, plan['reset'][t])
+            n += 1
+            ev += M
+            t += 1
+        dt = time.time() - t0
+        if n:
+            wins.append((n / dt, n, ev, dt))
+    best = max(wins)
+    return dict(value=best[0], unit='mini-batches/s', cores=int(threads), kind='port',
+                sample='best of %d windows of %.0f s: %d steps (%d events) of the same plan, NumPy/BLAS fp32 oracle, %.1f s; all windows: %s' % (
+                    len(wins), budget_s / 3.0, best[1], best[2], best[3], ', '.join('%.1f' % w[0] for w in wins)),
+                events_per_s=best[2] / best[3], host_cpus=os.cpu_count())
 
 
 def main():
@@ -362,13 +370,14 @@ def main():
     defer_rows = None
     if n_profile > 0:
         # per-kernel durations: HIP events on the library's own stream, eager launches over the next plan steps
-        d0 = m.get_debug('defer_stats', 4)
+        d0 = m.get_debug('defer_stats', 4) if args.defer else None
         m.profile(True)
         m.train_steps(args.warmup + args.steps + n_long, n_profile)
         m.profile(False)
         kt = m.kernel_times()
-        d1 = m.get_debug('defer_stats', 4)
-        defer_rows = (float(d1[0] - d0[0]), float(d1[1] - d0[1])) if d1[2] else None
+        if args.defer:
+            d1 = m.get_debug('defer_stats', 4)
+            defer_rows = (float(d1[0] - d0[0]), float(d1[1] - d0[1])) if d1[2] else None
     staged = (world > 1 or bool(os.environ.get('G4R_FORCE_STAGED'))) and not args.sparse_exact
     kt_split = {}
     if n_profile > 0 and world == 1 and not staged:
@@ -586,8 +595,10 @@ def main():
         if 'bound' in dv:
             a = alg[dk]
             out['roofline'] = {'kernel': dk, 'bound': dv['bound'], 'achieved': dv['achieved'], 'peak': PEAK[dv['bound']][0],
-                               'unit': dv['unit'], 'frac': dv['frac'], 'traffic': traffic_of(dk),
-                               'algorithmic': a.get('flops', a.get('bytes')), 'avg_us': dv['avg_us'],
+                               'unit': dv['unit'], 'frac': dv['frac'], 'traffic': traffic_of(dk), 'traffic_unit': 'bytes per launch',
+                               'algorithmic_flops': a.get('flops'), 'algorithmic_bytes': a.get('bytes'),
+                               'traffic_over_algorithmic_bytes': (traffic_of(dk) / a['bytes']) if (traffic_of(dk) and a.get('bytes')) else None,
+                               'avg_us': dv['avg_us'],
                                'traffic_source': ('%s (STATIC file: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this '
                                                   'command, tools/pmc_traffic.sh; not measured by the run that prints this line)' %
                                                   os.path.relpath(pmc_path, ROOT)) if pmc else None,
@@ -615,9 +626,12 @@ def main():
                 # of the step row) cost a step-row read and a parameter read + write = 3 row transfers, not 8d's 5
                 moved = (3 + mom_planes(cfg)) * (2 * cfg['batch_size'] + cfg['n_sample']) * cfg['layers'][-1] * 4
                 alone = {'kernel': 'k_sparse_update', 'avg_us': us_a, 'launches': n_a,
-                         'achieved': sparse_bytes / (us_a * 1e-6) / 1e9, 'frac': sparse_bytes / (us_a * 1e-6) / 1e9 / 8000.0, 'unit': 'GB/s',
-                         'traffic': traffic_split('k_sparse_update'),
+                         # first the bytes the kernel MOVES (three row transfers per occurrence since round 4), then SURVEY 8d's five
                          'rows_moved_bytes': moved, 'achieved_on_rows_moved': moved / (us_a * 1e-6) / 1e9,
+                         'frac_on_rows_moved': moved / (us_a * 1e-6) / 1e9 / 8000.0,
+                         'survey_8d_bytes': sparse_bytes, 'achieved': sparse_bytes / (us_a * 1e-6) / 1e9,
+                         'frac': sparse_bytes / (us_a * 1e-6) / 1e9 / 8000.0, 'unit': 'GB/s',
+                         'traffic': traffic_split('k_sparse_update'),
                          'k_dense_grad_alone_us': (1000.0 * ms_d / n_d) if n_d else None,
                          'note': 'g4r_profile(m, 2): the sparse row update as a launch of its own (k_sparse_update; the dense-gradient tiles '
                                  'run as k_dense_grad next to it), HIP events on the dispatches; achieved / frac price it with SURVEY 8d\'s '

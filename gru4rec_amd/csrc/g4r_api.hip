@@ -47,10 +47,10 @@ void g4r_set_error(const char* fmt, ...) {
     } while (0)
 
 enum { KN_GRU_P1 = 0, KN_GRU_P2, KN_SCORE_FWD, KN_LOSS, KN_SCORE_BWD, KN_BWD_PRE, KN_BWD_A, KN_BWD_B, KN_DENSE, KN_ALLREDUCE,
-       KN_DENSE_APPLY, KN_SPARSE, KN_UPDATE, KN_BWD_FUSED, KN_FWD_FUSED, KN_COMPACT, KN_GATE, KN_FLUSH, KN_SCAN, KN_COUNT };
+       KN_DENSE_APPLY, KN_SPARSE, KN_UPDATE, KN_BWD_FUSED, KN_FWD_FUSED, KN_GATE, KN_FLUSH, KN_SCAN, KN_COUNT };
 static const char* KN_NAMES[KN_COUNT] = {"k_gru_p1", "k_gru_p2", "k_score_fwd", "k_loss_rows", "k_score_bwd", "k_gru_bwd_pre",
                                          "k_gru_bwd_a", "k_gru_bwd_b", "k_dense_grad", "rccl_allreduce", "k_dense_apply",
-                                         "k_sparse_update", "k_update", "k_gru_bwd", "k_gru_fwd", "k_compact_sy", "k_gru_gate", "k_sparse_flush", "k_defer_scan"};
+                                         "k_sparse_update", "k_update", "k_gru_bwd", "k_gru_fwd", "k_gru_gate", "k_sparse_flush", "k_defer_scan"};
 
 struct EvRec { int kn; hipEvent_t a, b; };
 
@@ -62,8 +62,6 @@ struct g4r_model {
     hipStream_t stream = nullptr;
     hipStream_t comm_stream = nullptr;           // all-reduce + dense Adagrad next to the sparse update (nranks > 1)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;      // G4R_SYC=2: k_compact_sy on a branch next to the GRU forward
-    bool syc_forked = false;
     std::vector<void*> allocs;
     // plan
     int *d_in = nullptr, *d_out = nullptr, *d_M = nullptr, *d_cmaps = nullptr;
@@ -80,14 +78,8 @@ struct g4r_model {
     int64_t gstep = 0;
     // launch geometry
     DenseTile* d_tiles = nullptr;
-    int dt = 32;                                 // edge of the dense-gradient tiles (64 for wide layers)
     int ntiles = 0, nblkA = 0, nblkB = 0, ndtA = 0, ndtB = 0, nrtB = 0, nblk_occ = 0, nblk_occ_g = 0;
     size_t smem_score = 0, smem_loss = 0, smem_sparse = 0;
-    // persistent stream-K scoring forward (k_score_fwd_sk): workers, tile grid, column tiles a worker may touch, scratch
-    int sk_W = 0, sk_nrt = 0, sk_nct = 0, sk_maxct = 0, sk_nst = 3;
-    float* sk_ws = nullptr;
-    unsigned* sk_flags = nullptr;
-    size_t smem_sk = 0;
     bool loss_long = false;      // k_loss_rows<true>: score rows too long for two LDS copies
     // wide layers (g4r_wide_kernels.cuh): per layer which kernels run (bit 1 k_gru_p1s + k_gru_gate, 8 k_gru_bwd_bw) and their K-slice
     // geometry; wide_dense: the 64 x 64 dense-gradient tiles (k_dense_grad2, mask bit 16) as a launch of their own for the whole model
@@ -180,7 +172,6 @@ static constexpr size_t tile_smem() { return (size_t)TileCfg<BM, BN, BK, AKM, BN
 static const size_t SMEM_NN = tile_smem<GT_BM, GT_BN, GT_BK, false, false>() + GT_BM * sizeof(int);   // A [m][k], B [k][n] (+ row items)
 static const size_t SMEM_NT = tile_smem<GT_BM, GT_BN, GT_BK, false, true>() + GT_BM * sizeof(int);    // A [m][k], B [n][k] (+ row items)
 static const size_t SMEM_TN = tile_smem<GT_BM, GT_BN, GT_BK, true, false>();    // A [k][m], B [k][n]
-static const size_t SMEM_DIRECT = (size_t)(GT_NTH_FEW / 64) * 4 * 64 * sizeof(f32x4);      // dense_grad_direct: partial accumulators of the waves
 // wide layers: 64-column tiles halve the number of GRU phase-1 workgroups (all resident at once) and read the weights in
 // 256-byte runs; the 32-column tiles spread the tiny GEMMs of D ~ 100 over more CUs
 static constexpr auto k_gru_p1_n32 = k_gru_p1<GT_BN, P1_BK>;
@@ -198,7 +189,7 @@ static inline bool fused_fwd(const DevModel& d, int l) {
            !(l == 0 && d.embed_mode == G4R_EMBED_ONEHOT) && (size_t)fwd_fused_lds(d.IN[l], d.D[l]).total * sizeof(float) <= 156 * 1024;
 }
 static inline size_t smem_fused_bwd(int D) { return (size_t)((((BF_ROWS + 32) * (3 * D + 2) + D * (D + 2) + 32 + 3) & ~3) + 4 * 6 * 64) * sizeof(float); }
-static inline bool wide_layer(int D) { static const bool off = getenv("G4R_NARROW_TILES") != nullptr; return D >= 256 && !off; }
+static inline bool wide_layer(int D) { return D >= 256; }
 static const size_t SMEM_P1 = tile_smem<GT_BM, GT_BN, P1_BK, false, false>() + GT_BM * sizeof(int);
 static const size_t SMEM_BB = tile_smem<GT_BM, GT_BN, BB_BK, false, true>() + GT_BM * sizeof(int);
 static constexpr auto k_score_fwd_k128 = k_score_fwd<GT_BN, GT_BK>;
@@ -211,7 +202,7 @@ static constexpr auto k_score_fwd_t2 = k_score_fwd<64, 32, T2_BK>;      // gemm_
 static const size_t SMEM_SF2 = (size_t)Tile2Cfg<T2_BK>::SMEM_FLOATS * sizeof(float);
 static constexpr auto k_score_fwd_t3 = k_score_fwd<64, 32, 3>;          // gemm_tile3: the same tile fed by LDS-DMA through a ring of stages
 static const size_t SMEM_SF3 = (size_t)Tile3Cfg<T3_NST, T3_BKS>::SMEM_FLOATS * sizeof(float);
-static inline bool score_tile2() { static const bool off = getenv("G4R_NO_TILE2") != nullptr; return !off; }
+static inline bool score_tile2() { return true; }
 static inline bool wide_scores(const DevModel& d);
 // gemm_tile2k scoring backward (k_score_bwd2): long score rows / big batches and D a multiple of 64
 static inline bool score_bwd2(const DevModel& d) { return wide_scores(d) && score_tile2() && d.Dtop % 64 == 0; }
@@ -221,11 +212,11 @@ static constexpr auto k_score_bwd_w = k_score_bwd<64, 64>;
 static const size_t SMEM_SBW = std::max(tile_smem<64, 64, 64, true, false>(), tile_smem<64, 64, 64, false, false>());
 static inline int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static inline bool wide_scores(const DevModel& d) {
-    static const bool off = getenv("G4R_NARROW_TILES") != nullptr;
-    static const int minB = env_int("G4R_WIDE_B", 256), minN = env_int("G4R_WIDE_N", 4096);
+    const bool off = false;
+    const int minB = 256, minN = 4096;
     // (a top layer that is a multiple of 64 takes the 64 x 64 tiles of k_score_bwd2 from B = 192, 2048 columns on: B = 240, N = 2288,
     // D = 512 measured 22.2 vs 25.1 us against the 32 x 32 tiles)
-    static const int d64 = env_int("G4R_WIDE_D64", 1);
+    const int d64 = 1;
     return !off && ((d.B >= minB && d.ldSc >= minN) || (d64 && d.Dtop % 64 == 0 && d.B >= std::min(minB, 192) && d.ldSc >= std::min(minN, 2048)));
 }
 // LDS-DMA tiles (gemm_tile3, k_score_fwd_t3), D a multiple of 32: where gemm_tile2 served (long score rows / big batches), and
@@ -234,8 +225,7 @@ static inline bool wide_scores(const DevModel& d) {
 #define ZROW_FLOATS 8192      // DevModel::zrow: an LDS-DMA tile walks K floats along it
 #define G4R_DEFER_SLOTS 16    // ring slots of the step planes = steps of a deferral window (= G4R_GRAPH_STEPS; a power of two)
 static inline bool score_fwd_dma(const DevModel& d) {
-    static const int on = env_int("G4R_TILE3", 1);
-    if (!on || !score_tile2() || d.Dtop % 32 != 0) return false;
+    if (d.Dtop % 32 != 0) return false;
     return wide_scores(d) || (d.Dtop >= 256 && d.B >= 64 && d.ldSc >= 1024);
 }
 static const size_t SMEM_SF = tile_smem<SF_BM, GT_BN, GT_BK, false, true>() + GT_BN * sizeof(int);
@@ -295,9 +285,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return fail("stream create"); }
     if (hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_fork2, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_join2, hipEventDisableTiming) != hipSuccess) { g4r_destroy(m); return fail("stream create"); }
+        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) { g4r_destroy(m); return fail("stream create"); }
     DevModel& d = m->dm;
     memset(&d, 0, sizeof(d));
     const int L = cfg->n_layers, B = cfg->batch_size;
@@ -400,7 +388,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     // moves at BASELINE configs[2] -- but the step gets 2-5 % SLOWER, because the update launch it relieves is at its latency floor
     // (cfg3: k_sparse_update 7.5 -> 6.2 us with 90 % of the rows gone) or bound by its dense-gradient tiles (cfg4), and the flush
     // (2.9 / 7.4 us per step) and scan (0.7 / 1.1) come on top (profiles/r05_experiments.md #7).
-    m->defer_on = d.apply_dense_inplace && !d.generic && cfg->momentum <= 0.f && cfg->lmbd == 0.f && cfg->use_graph && env_int("G4R_DEFER", cfg->defer_updates) != 0;
+    m->defer_on = d.apply_dense_inplace && !d.generic && cfg->momentum <= 0.f && cfg->lmbd == 0.f && env_int("G4R_DEFER", cfg->defer_updates) != 0;
     if (m->defer_on) {
         const size_t W = G4R_DEFER_SLOTS;
         d.defer_mask = (int)W - 1;
@@ -442,11 +430,6 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         }
         d.ksplit = cdiv(d.ldSc, d.kch);
         DA(d.dhpart, (size_t)d.ksplit * B * d.Dtop);
-        // compact copy of the step's Sy rows for the k_score_bwd2 shapes (k_compact_sy), opt-in: G4R_SYC=1 (first kernel of the step)
-        // or 2 (on a branch next to the GRU forward).  Measured at B = 512 / 8192 negatives / 10 M x 256: the scoring forward gains
-        // 1.4 us, the dh slabs nothing (57.1 vs 57.4 -- their rate is not set by the gathers), the copy costs 6.9 us: 5.42 vs 5.58 K
-        // mini-batches/s; forked 5.01 K (profiles/r03_experiments.md #12)
-        if (score_bwd2(d) && env_int("G4R_SYC", 0) != 0) { DA(d.Syc, (size_t)d.ldSc * d.Dtop); m->syc_forked = env_int("G4R_SYC", 0) == 2; }
         const int TB = wide_scores(d) ? 64 : 32;      // tile edge of k_score_bwd
         m->ndtA = cdiv(d.Dtop + 1, TB);
         m->nblkA = cdiv(d.ldSc, TB) * m->ndtA;
@@ -460,44 +443,9 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     }
     if (ns > 0) DA(m->d_ST, (size_t)gl * ns);
     d.ST = m->d_ST;
-    // Persistent stream-K scoring forward: OPT-IN (G4R_STREAMK=1; 2 = whatever the tile count).  Built in round 3 as the round-2 review
-    // asked, parity green, and measured no faster than the tile launch at B = 512, N = 8704, D = 256 (31.2 vs 31.5 us; rocprofv3
-    // 34.4 vs 33.7) while moving 54 MB instead of 33 MB (partial sums, re-read rows): DESIGN.md section 5 has the traces.
-    if (score_fwd_dma(d) && env_int("G4R_STREAMK", 0)) {
-        // stream-K scoring forward: two workers per CU (or one per tile when there are fewer tiles), every run >= one tile's K stages
-        const int nrt = cdiv(B, 64), nct = cdiv(d.ldSc, 64), KS = d.Dtop / 32, ntiles = nrt * nct;
-        // ring depth 3 (48 KiB): three workers per CU -- three waves per SIMD cover each other's DMA issue, fragment reads and
-        // barrier waits (measured at B = 512, N = 8704, D = 256: two workers per CU with a 4-deep ring left the MFMA pipe 45 % busy)
-        m->sk_nst = env_int("G4R_SK_NST", 3) >= 4 ? 4 : 3;
-        const int per_cu = m->sk_nst == 3 ? 3 : 2;
-        const int W = std::min(env_int("G4R_SK_W", per_cu * m->n_cu), ntiles);
-        const long long U = (long long)ntiles * KS;
-        int maxct = 1;
-        for (int w = 0; w < W; ++w) {
-            const long long u0 = U * w / W, u1 = U * (w + 1) / W;
-            maxct = std::max(maxct, (int)(((u1 - 1) / KS) / nrt - (u0 / KS) / nrt + 1));
-        }
-        m->smem_sk = (size_t)m->sk_nst * Tile3Cfg<3, 32>::STAGE * sizeof(float) + (size_t)maxct * 64 * (sizeof(int) + sizeof(float));
-        // (fewer tiles than worker slots -- B = 240, N = 2288: 144 tiles -- leave CUs idle either way and the tile launch measured
-        // 1 us better there; G4R_STREAMK=2 takes the persistent launch regardless, for tests)
-        const bool enough = ntiles >= per_cu * m->n_cu || env_int("G4R_STREAMK", 0) == 2;
-        if (W >= 1 && U / W >= KS && enough && m->smem_sk <= (size_t)(78 * 1024)) {
-            m->sk_W = W; m->sk_nrt = nrt; m->sk_nct = nct; m->sk_maxct = maxct;
-            DA(m->sk_ws, (size_t)(W + 1) * 4 * 256 * 4);
-            DA(m->sk_flags, (size_t)W + 1);
-        }
-    }
     // dense-gradient tile table
     {
         std::vector<DenseTile> tiles;
-        {
-            static const bool narrow = getenv("G4R_NARROW_TILES") != nullptr;
-            int dmax = 0;
-            for (int l = 0; l < L; ++l) dmax = std::max(dmax, d.D[l]);
-            // dense-gradient tiles: 32 x 32, LDS-staged (default) or register-fed with K split over the waves (G4R_DT=0, experiment)
-            m->dt = (getenv("G4R_DT") && atoi(getenv("G4R_DT")) == 0) ? 0 : 32;
-            (void)dmax; (void)narrow;
-        }
         const int DTE = 32;
         for (int l = 0; l < L; ++l) {
             const int D = d.D[l], IN = d.IN[l];
@@ -614,8 +562,6 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_k64, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_t2, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_t3, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_sk<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_sk<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd_n, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_fwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -623,11 +569,6 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd2, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_a, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_b, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_dense_grad<0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_update<1, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_update<1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_dense_grad<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -687,8 +628,6 @@ void g4r_destroy(g4r_model* m) {
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
-    if (m->ev_fork2) (void)hipEventDestroy(m->ev_fork2);
-    if (m->ev_join2) (void)hipEventDestroy(m->ev_join2);
     if (m->comm_stream) (void)hipStreamDestroy(m->comm_stream);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -970,19 +909,6 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     StepState* stp = (StepState*)d.st;
     bool merged = false;      // the sparse update already ran inside k_update
     if (part != 2) {
-    // the compact copy of the step's Sy rows: first kernel of the step, or (G4R_SYC=2, graph / plain launches only) on a branch of its
-    // own that joins in front of the scoring forward -- it depends on nothing the GRU forward computes
-    const bool syc_fork = d.Syc && m->syc_forked && !recs && !trace;
-    if (d.Syc && !syc_fork) {
-        begin(KN_COMPACT);
-        LK(k_compact_sy, dim3(cdiv((long long)d.ldSc * (d.Dtop / 4), 256)), dim3(256), 0, s, dmp);
-        end();
-    } else if (syc_fork) {
-        HIPCHK(hipEventRecord(m->ev_fork2, s));
-        HIPCHK(hipStreamWaitEvent(m->comm_stream, m->ev_fork2, 0));
-        hipLaunchKernelGGL(k_compact_sy, dim3(cdiv((long long)d.ldSc * (d.Dtop / 4), 256)), dim3(256), 0, m->comm_stream, dmp);
-        HIPCHK(hipEventRecord(m->ev_join2, m->comm_stream));
-    }
     for (int l = 0; l < L; ++l) {
         if (fused_fwd(d, l)) {
             begin(KN_FWD_FUSED);
@@ -1005,11 +931,8 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         LK(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH), SMEM_NN, s, dmp, stp, l, 1, nopa);
         end();
     }
-    if (syc_fork) HIPCHK(hipStreamWaitEvent(s, m->ev_join2, 0));
     begin(KN_SCORE_FWD);
-    if (m->sk_W > 0 && m->sk_nst == 3) LK(k_score_fwd_sk<3>, dim3(m->sk_W), dim3(GT_NTH), m->smem_sk, s, dmp, stp, m->sk_ws, m->sk_flags, m->sk_W, m->sk_nrt, m->sk_nct, m->sk_maxct);
-    else if (m->sk_W > 0) LK(k_score_fwd_sk<4>, dim3(m->sk_W), dim3(GT_NTH), m->smem_sk, s, dmp, stp, m->sk_ws, m->sk_flags, m->sk_W, m->sk_nrt, m->sk_nct, m->sk_maxct);
-    else if (score_fwd_dma(d)) LK(k_score_fwd_t3, dim3(cdiv(d.ldSc, 64), cdiv(B, 64)), dim3(GT_NTH), SMEM_SF3, s, dmp, stp);
+    if (score_fwd_dma(d)) LK(k_score_fwd_t3, dim3(cdiv(d.ldSc, 64), cdiv(B, 64)), dim3(GT_NTH), SMEM_SF3, s, dmp, stp);
     else if (wide_scores(d) && score_tile2() && d.Dtop % T2_BK == 0) LK(k_score_fwd_t2, dim3(cdiv(d.ldSc, 64), cdiv(B, 64)), dim3(GT_NTH), SMEM_SF2, s, dmp, stp);
     else if (wide_scores(d)) LK(k_score_fwd_k64, dim3(cdiv(d.ldSc, SFW_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF64, s, dmp, stp);
     else LK(k_score_fwd_k128, dim3(cdiv(d.ldSc, GT_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF, s, dmp, stp);
@@ -1017,9 +940,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     begin(KN_LOSS);
     {
         // the (final activation, loss) pairs of BASELINE's configurations run compile-time specialised builds of the kernel
-        static const bool nospec = getenv("G4R_LOSS_GENERIC") != nullptr;
-        const int spec = nospec ? 0
-                       : (d.final_act == G4R_ACT_ELU && d.loss == G4R_LOSS_BPR_MAX) ? 1
+        const int spec = (d.final_act == G4R_ACT_ELU && d.loss == G4R_LOSS_BPR_MAX) ? 1
                        : (d.final_act == G4R_ACT_SOFTMAX && d.loss == G4R_LOSS_XE) ? 2
                        : (d.final_act == G4R_ACT_ELU && d.loss == G4R_LOSS_TOP1_MAX) ? 3 : 0;
 #define G4R_LK_LOSS(L)                                                                              \
@@ -1037,9 +958,6 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     if (score_bwd2(d)) {
         const int ndt = d.Dtop / 64, nrt = cdiv(B, 64);
         int nA = cdiv(d.ldSc, 64) * ndt, nB = d.ksplit * nrt * ndt, nC = cdiv(d.ldSc, 64);
-        // measurement only (results are WRONG): one role of the launch alone -- 1: the dS tiles, 2: the dh slabs (tools/bwd2_roles.sh)
-        static const int only = env_int("G4R_DEBUG_BWD2_ROLE", 0);
-        if (only == 1) { nB = 0; nC = 0; } else if (only == 2) { nA = 0; nC = 0; }
         LK(k_score_bwd2, dim3(nA + nB + nC), dim3(GT_NTH), (size_t)(4 * 64 * 16) * sizeof(float) + (size_t)std::max(d.kch, 64) * sizeof(int), s, dmp, stp, nA, nB, ndt, nrt);
     } else if (wide_scores(d)) LK(k_score_bwd_w, dim3(m->nblkA + m->nblkB), dim3(GT_NTH), SMEM_SBW + (size_t)d.kch * sizeof(int), s, dmp, stp, m->nblkA, m->ndtA, m->ndtB, m->nrtB);
     else LK(k_score_bwd_n, dim3(m->nblkA + m->nblkB), dim3(GT_NTH), std::max(SMEM_TN, SMEM_NN) + (size_t)d.kch * sizeof(int), s, dmp, stp, m->nblkA, m->ndtA, m->ndtB, m->nrtB);
@@ -1069,7 +987,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     if (merged) {
         // dense-gradient tiles (+ fused dense Adagrad on a single GPU; gradients to the RCCL buffer otherwise) and the sparse row
         // update in ONE launch (k_update): the two are independent, the all-reduce / dense apply of N > 1 follow behind
-        const size_t smem = std::max(m->dt == 32 ? SMEM_TN : SMEM_DIRECT, m->smem_sparse);
+        const size_t smem = std::max(SMEM_TN, m->smem_sparse);
         const dim3 grid(m->ntiles + m->nblk_occ + 1), blk(SP_WAVES * 64);
         const bool one = row_chunks(d) == 1;
         begin(KN_UPDATE);
@@ -1079,18 +997,13 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
             if (mo) LK((k_update<CH, DT_, true>), grid, blk, smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);  \
             else LK((k_update<CH, DT_, false>), grid, blk, smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);    \
         } while (0)
-        if (m->dt == 0) {
-            if (one) G4R_LK_UPDATE(1, 0); else G4R_LK_UPDATE(2, 0);
-        } else {
-            if (one) G4R_LK_UPDATE(1, 32); else G4R_LK_UPDATE(2, 32);
-        }
+        if (one) G4R_LK_UPDATE(1, 32); else G4R_LK_UPDATE(2, 32);
 #undef G4R_LK_UPDATE
         end();
         if (d.apply_dense_inplace || part == 1) { HIPCHK(hipGetLastError()); return 0; }
     } else {
     begin(KN_DENSE);
     if (m->wide_dense) LK(k_dense_grad2, dim3(m->ntiles64 + (d.bbn[0] > 0 ? cdiv((long long)B * (d.IN[0] / 4), 256) : 0)), dim3(256), SMEM_T2K, s, dmp, stp, (const DenseTile*)m->d_tiles64, m->ntiles64);
-    else if (m->dt == 0) LK(k_dense_grad<0>, dim3(m->ntiles), dim3(GT_NTH_FEW), SMEM_DIRECT, s, dmp, stp, (const DenseTile*)m->d_tiles);
     else LK(k_dense_grad<32>, dim3(m->ntiles), dim3(GT_NTH_FEW), SMEM_TN, s, dmp, stp, (const DenseTile*)m->d_tiles);
     end();
     }
@@ -1197,8 +1110,7 @@ static int apply_compaction(g4r_model* m, int64_t ci) {
 // collective in the step, so the whole step is captured like the fused single-GPU step (it used to replay a head graph and launch
 // its tail eagerly; G4R_NO_LOCAL_GRAPH=1 keeps that)
 static inline bool local_staged(const g4r_model* m) {
-    static const bool off = getenv("G4R_NO_LOCAL_GRAPH") != nullptr;
-    return !off && !m->dm.apply_dense_inplace && m->cfg.nranks <= 1 && !m->comm_ready && !m->p2p_ready && !m->virtual_ranks;
+    return !m->dm.apply_dense_inplace && m->cfg.nranks <= 1 && !m->comm_ready && !m->p2p_ready && !m->virtual_ranks;
 }
 static inline bool dist_graph_wanted(const g4r_model* m) {
     static const bool eager = getenv("G4R_RCCL_EAGER") != nullptr;
@@ -1345,9 +1257,9 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
                     if (window_close(G4R_GRAPH_STEPS_SMALL, done)) return -1;
                 }
         }
-        int64_t win_first = -1, win_n = 0;      // profiling: eager steps in windows of up to G4R_DEFER_SLOTS (the timed run's windows, with events)
+        int64_t win_first = -1, win_n = 0;      // eager steps (no graph; per-kernel profiling): windows of up to G4R_DEFER_SLOTS steps
         for (; done < run; ++done) {
-            if (m->profiling && m->defer_on && win_n == 0) {
+            if (m->defer_on && win_n == 0) {
                 win_n = std::min<int64_t>(G4R_DEFER_SLOTS, run - done); win_first = done;
                 window_open(win_n);
             }
@@ -2360,9 +2272,7 @@ int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
         host[0] = (float)mk; return 0;
     }
     else if (s == "ksplit") { if (count < 1) return fail("count"); host[0] = (float)d.ksplit; return 0; }
-    else if (s == "streamk_workers") { if (count < 1) return fail("count"); host[0] = (float)m->sk_W; return 0; }
     else if (s == "dev_syncs") { if (count < 1) return fail("count"); host[0] = (float)m->n_dev_syncs; return 0; }
-    else if (s == "compact_sy") { if (count < 1) return fail("count"); host[0] = d.Syc ? 1.f : 0.f; return 0; }
     else if (s == "dense_count") { if (count < 1) return fail("count"); host[0] = (float)d.dense_count; return 0; }
     else if (s == "occ_score_tile") {      // resident workgroups per CU the runtime reports for the gemm_tile2 scoring kernel
         if (count < 1) return fail("count");

@@ -155,7 +155,6 @@ struct DevModel {
     GP(StepState) st;
     GP(long long) dbgclk;   // optional [kernel][16] phase timestamps (100 MHz wall clock), block 0 only
     GP(const float) zrow;   // 8192 zero floats: what the LDS-DMA tiles read for rows outside the matrix / inactive gathered rows
-    GP(float) Syc;          // [ldSc][Dtop] the Wy rows of this step's score columns, compact (k_compact_sy); nullptr = not staged
     GP(long long) dbgtile;  // optional [dense tile][8] phase timestamps of the dense-gradient tiles (G4R_CLK)
     // Per-occurrence exchange blocks.  occ_idx | dSx | dSy | dSBy of this rank are carved out of ONE block of xstride floats; in the
     // exact-replica mode of N > 1 (g4r_config::sparse_exact) xbase holds xn = nranks such blocks, this rank's own at index `rank`

@@ -258,18 +258,11 @@ template __global__ void k_update<1, 32, false>(const DevModel*, StepState*, con
 template __global__ void k_update<1, 32, true>(const DevModel*, StepState*, const DenseTile*, int, int);
 template __global__ void k_update<2, 32, false>(const DevModel*, StepState*, const DenseTile*, int, int);
 template __global__ void k_update<2, 32, true>(const DevModel*, StepState*, const DenseTile*, int, int);
-template __global__ void k_update<1, 0, false>(const DevModel*, StepState*, const DenseTile*, int, int);
-template __global__ void k_update<1, 0, true>(const DevModel*, StepState*, const DenseTile*, int, int);
-template __global__ void k_update<2, 0, false>(const DevModel*, StepState*, const DenseTile*, int, int);
-template __global__ void k_update<2, 0, true>(const DevModel*, StepState*, const DenseTile*, int, int);
-template __global__ void k_dense_grad<0>(const DevModel*, StepState*, const DenseTile*);
 template __global__ void k_dense_grad<32>(const DevModel*, StepState*, const DenseTile*);
 template __global__ void k_score_fwd<GT_BN, GT_BK>(const DevModel*, StepState*);
 template __global__ void k_score_fwd<32, 64>(const DevModel*, StepState*);
 template __global__ void k_score_fwd<64, 32, T2_BK>(const DevModel*, StepState*);
 template __global__ void k_score_fwd<64, 32, 3>(const DevModel*, StepState*);
-template __global__ void k_score_fwd_sk<3>(const DevModel*, StepState*, float*, unsigned*, int, int, int, int);
-template __global__ void k_score_fwd_sk<4>(const DevModel*, StepState*, float*, unsigned*, int, int, int, int);
 template __global__ void k_score_bwd<32, GT_BK>(const DevModel*, StepState*, int, int, int, int);
 template __global__ void k_score_bwd<64, 64>(const DevModel*, StepState*, int, int, int, int);
 template __global__ void k_gru_p1<GT_BN, P1_BK>(const DevModel*, StepState*, int, int, int, GruFwdPredict);

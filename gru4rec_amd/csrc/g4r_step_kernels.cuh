@@ -533,23 +533,6 @@ __global__ __launch_bounds__(512) void k_gru_fwd_fused(const DevModel* __restric
                      // 4 x 16: 32.3 / 16.1, 5 x 16: 32.7 / 16.4 -- gemm_tile2: 34.1 / 17.5)
 #endif
 
-// The Wy rows of this step's score columns (targets | samples: cur_col, staged with the step's inputs) copied once into a compact
-// [ldSc][Dtop] buffer at the start of the step (long score rows on a big catalogue: the k_score_bwd2 shapes).  Why: the dh slabs of
-// k_score_bwd2 contract over the COLUMNS -- a 64 x 64 tile walks ~600 gathered rows, 256 bytes of each, and every row is a fresh page
-// of a multi-GB table, re-gathered by the 8 row tiles x 4 d tiles of its slab (32 piece loads per row and step, each a likely
-// translation miss); from the compact copy the same operand is 8.9 MB of consecutive memory that stays in the L2s / Infinity Cache.
-// The rows are those of the END of the previous step (the sparse update is the last kernel of a step), which is what the scoring
-// forward and backward of this step read anyway.  Inactive columns (item < 0) hold zeros.
-__global__ __launch_bounds__(256) void k_compact_sy(const DevModel* __restrict__ mp) {
-    const DevModel& m = *mp;
-    const int D = m.Dtop, q = D >> 2;
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long long)m.ldSc * q) return;
-    const int n = (int)(e / q), c = 4 * (int)(e - (long long)n * q);
-    const int item = m.cur_col[n];
-    const float4 v = ld4_if(m.Wy, (size_t)max(item, 0) * D + c, item >= 0);
-    *reinterpret_cast<GAS float4*>(m.Syc + (size_t)n * D + c) = v;
-}
 // T2 > 3: the gemm_tile2 variant (64 x 64 tiles, mfma 32x32x2) with K chunks of T2 floats; T2 == 3: gemm_tile3 (LDS-DMA ring);
 // TBN / TBK then only name the instance
 template <int TBN, int TBK, int T2 = 0>
@@ -630,10 +613,9 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
         const GAS int* ccol = m.cur_col;
         const int ldc = m.ldSc;
         auto arow = [&](int r) -> const GAS float* { return (m0 + r < M) ? hsrc + (size_t)(m0 + r) * D : nullptr; };
-        const GAS float* syc = m.Syc;      // compact copy of the columns' rows (k_compact_sy) when staged
         auto brow = [&](int r) -> const GAS float* {
             const int item = (n0 + r < ldc) ? ccol[n0 + r] : -1;
-            return item >= 0 ? (syc ? syc + (size_t)(n0 + r) * D : Wy + (size_t)item * D) : nullptr;
+            return item >= 0 ? Wy + (size_t)item * D : nullptr;
         };
         auto pre2 = [&](int row, int n) -> float4 {
             const int item = (n < N) ? ccol[min(n, ldc - 1)] : -1;
@@ -646,207 +628,6 @@ __global__ __launch_bounds__(GT_NTH) void k_score_fwd(const DevModel* __restrict
         if constexpr (T2 == 3) gemm_tile3<T3_NST, T3_BKS, true>(m0, n0, D, arow, brow, m.zrow, pre2, epi, smem, trc);
         else gemm_tile2<(T2 > 3) ? T2 : 16, true>(m0, n0, D, arow, brow, m.zrow, pre2, epi, smem, trc);
     } else gemm_tile<SF_BM, TBN, TBK, false, true, GT_NTH>(m0, n0, D, aload, bload, pre, epi, smem);
-}
-
-// ---------------------------------------------------------------------------------------------
-// The scoring GEMM as a PERSISTENT stream-K launch (long score rows: B = 512, N = 8704, D = 256 is 1088 tiles of 64 x 64 x 256).
-// One workgroup per CU slot -- exactly two per CU: 64 KiB of LDS each, grid = 2 x #CU, so every CU holds two and all of them are
-// resident from start to end -- and the work, cut into units of (tile, one 32-deep K stage), is dealt out in equal contiguous
-// runs: worker w owns units [U w / W, U (w + 1) / W) in column-tile-major order.  Every CU therefore gets the same number of
-// MFMAs (the plain tile launch gave 4 or 5 tiles of a 4.25 average to a CU and ran its last round at a third of the chip's
-// occupancy: 31 us against 14.5 us of MFMA time), the LDS-DMA ring runs THROUGH tile boundaries (the first stages of the next
-// tile are in flight while this one finishes and stores: no per-tile start-up bubble), and the gathered rows of a column tile are
-// shared by the consecutive row tiles of one worker / one XCD.
-// A run starts and ends inside a tile.  The tile's HEAD (its first K stages) is computed by the worker that reaches it LAST in
-// its own run, its TAIL by the next worker FIRST in its run -- so the tail's partial sum is in memory ~15 us before the head's
-// owner needs it: the owner adds it (fixed order: head + tail, bit-reproducible) and stores the tile.  Partials travel as
-// write-through 16-byte stores and L1-bypassing loads (`sc1` on both sides) behind a drained, step-stamped flag
-// (MI355X_MICROARCH.md, inter-workgroup visibility: form R1); the owner's poll is bounded and reports through nan_flag instead
-// of hanging should the co-residency assumption ever fail.
-__device__ __forceinline__ void st4_sc1(GAS float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }      // s_nop: the data registers may be rewritten right behind an asm store
-template <int NST>
-__global__ __launch_bounds__(256, NST <= 3 ? 3 : 2) void k_score_fwd_sk(const DevModel* __restrict__ mp, StepState* st, float* ws_, unsigned* flags_, int W,
-                                                         int nrt, int nct, int maxct) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const DevModel& m = *mp;
-    constexpr int BKS = 32, STAGE = 2 * 64 * BKS, QPR = BKS / 4, RPP = 64 / QPR, NP = 64 / RPP / 4, FSH = 1, FMASK = QPR - 1, LPS = 2 * NP;
-    constexpr unsigned BOFF = 64 * BKS * 4;
-    GAS float* ws = (GAS float*)ws_;
-    GAS unsigned* flags = (GAS unsigned*)flags_;
-    int* sItem = reinterpret_cast<int*>(smem + NST * STAGE);      // [maxct][64] items of the column tiles this worker touches
-    float* sBias = reinterpret_cast<float*>(sItem + maxct * 64);  // [maxct][64] bias - logQ correction of those columns
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 1, wn = wid & 1, l32 = lane & 31, lh = lane >> 5;
-    GAS long long* trc = (G4R_DBGTILE(m) && blockIdx.x < 2048) ? G4R_DBGTILE(m) + 8 * (size_t)(4096 + blockIdx.x) : nullptr;      // tools/clk_score.py
-    if (trc && tid == 0) trc[0] = wall_clock64();
-    const StepCtx c = load_ctx(st);
-    const int M = c.M, B = m.B, D = m.Dtop, N = m.N, ld = m.ldSc;
-    const int KS = D / BKS;
-    const long long U = (long long)nrt * nct * KS;
-    const int w = G4R_XCD_TILE(blockIdx.x, W);
-    const int u0 = (int)(U * w / W), u1 = (int)(U * (w + 1) / W), S = u1 - u0;
-    if (S <= 0) return;
-    const int t0 = u0 / KS, ks0 = u0 - t0 * KS, tl = (u1 - 1) / KS;
-    const int ct0 = t0 / nrt, ctl = tl / nrt;
-    const unsigned stamp = (unsigned)(c.g + 1);
-    {   // items / biases of the worker's column tiles; the worker whose run holds unit (column tile, row tile 0, stage 0) publishes
-        // the column -> item map and the occurrence entries of that column tile (as the tile launch's row-tile-0 workgroups do)
-        const GAS float *By = m.By, *lq_tgt = m.lq_tgt, *lq_smp = m.lq_smp;
-        const float logq = m.logq;
-        for (int i = tid; i < (ctl - ct0 + 1) * 64; i += 256) {
-            const int ct = ct0 + (i >> 6), n = ct * 64 + (i & 63);
-            const int item = (n < ld) ? m.cur_col[min(n, ld - 1)] : -1;
-            const bool ok = item >= 0 && n < N;
-            float x = ldf_at(By, max(item, 0), ok);
-            const bool lq = ok && logq != 0.f;
-            x -= logq * ldf_at(lq ? (n < B ? lq_tgt : lq_smp) : By, max(item, 0), lq);
-            sItem[i] = item;
-            sBias[i] = ok ? x : 0.f;
-            const long long uf = (long long)ct * nrt * KS;
-            if (uf >= u0 && uf < u1 && n < ld) {
-                m.col_item[n] = item;
-                if (n < N) {
-                    m.occ_idx[B + n] = item;
-                    if (item >= 0 && m.xmode == 0) {
-                        int* fl = (int*)m.occ_fl + 4 * (size_t)item;
-                        atomicMax(fl, B + n + 1);
-                        atomicMax(fl + 1, m.R - (B + n));
-                        atomicAdd(fl + 2, 1);
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (trc && tid == 0) { trc[1] = wall_clock64(); trc[5] = c.t; trc[6] = (long long)__builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4) | ((long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) << 16); trc[7] = S; }      // HW_ID: wave / simd / cu / sh / se
-    const GAS float* hsrc = m.hd[m.n_layers - 1];
-    const GAS float* Wy = m.Wy;
-    const GAS float* zrow = m.zrow;
-    GAS float* Sc = m.Sc;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
-    // ---- issue side: stage `issued` of the run goes to ring buffer issued % NST
-    int cti = ct0, rti = t0 - ct0 * nrt, ksi = ks0, issued = 0, ibuf = 0;
-    const GAS float* pa[NP];
-    const GAS float* pb[NP];
-    auto setptr = [&]() {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int row = RPP * (NP * wid + j) + lane / QPR;
-            const int quad = (lane & FMASK) ^ ((row >> FSH) & FMASK);
-            const int item = sItem[(cti - ct0) * 64 + row];
-            const GAS float* a = (rti * 64 + row < M) ? hsrc + (size_t)(rti * 64 + row) * D : zrow;
-            const GAS float* b = (item >= 0) ? Wy + (size_t)item * D : zrow;
-            pa[j] = a + 4 * quad + ksi * BKS;
-            pb[j] = b + 4 * quad + ksi * BKS;
-        }
-    };
-    setptr();
-    const unsigned piece = lds0 + 1024u * (NP * wid);
-    auto issue = [&]() {
-        const unsigned base = piece + (unsigned)ibuf * (STAGE * 4);
-#pragma unroll
-        for (int j = 0; j < NP; ++j) glds16(pa[j], base + 1024u * j);
-#pragma unroll
-        for (int j = 0; j < NP; ++j) glds16(pb[j], base + BOFF + 1024u * j);
-#pragma unroll
-        for (int j = 0; j < NP; ++j) { pa[j] += BKS; pb[j] += BKS; }
-        ++issued;
-        ibuf = (ibuf + 1 == NST) ? 0 : ibuf + 1;
-        if (++ksi == KS && issued < S) {      // the run goes on in the next tile (row tiles of a column tile first)
-            ksi = 0;
-            if (++rti == nrt) { rti = 0; ++cti; }
-            setptr();
-        }
-    };
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s) if (s < S) issue();
-    // ---- consume side
-    f32x16 acc;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    const int fsw = (l32 >> FSH) & FMASK;
-    const float* fa0 = smem + (wm * 32 + l32) * BKS;
-    const float* fb0 = smem + 64 * BKS + (wn * 32 + l32) * BKS;
-    int ctc = ct0, rtc = t0 - ct0 * nrt, ksc = ks0, kbeg = ks0, cbuf = 0;
-    for (int i = 0; i < S; ++i) {
-        // the pieces of stages i + 1 .. i + NST - 2 may stay in flight (LPS each).  Epilogue stores in between only make the
-        // counted wait conservative: loads return in order, so "at most `behind` x LPS operations outstanding" implies stage i landed
-        const int behind = min(NST - 2, S - 1 - i);
-        if (NST >= 5 && behind == 3) wait_vm_barrier<3 * LPS>();
-        else if (NST >= 4 && behind == 2) wait_vm_barrier<2 * LPS>();
-        else if (behind == 1) wait_vm_barrier<LPS>();
-        else wait_vm_barrier<0>();
-        if (trc && tid == 0 && i == 0) trc[2] = wall_clock64();
-        if (i + NST - 1 < S) issue();
-        const float* fa = fa0 + cbuf * STAGE;
-        const float* fb = fb0 + cbuf * STAGE;
-        constexpr int NG = BKS / 8;
-        float4 qa[NG], qb[NG];
-#pragma unroll
-        for (int j = 0; j < NG; ++j) {
-            qa[j] = *reinterpret_cast<const float4*>(fa + 4 * ((2 * j + lh) ^ fsw));
-            qb[j] = *reinterpret_cast<const float4*>(fb + 4 * ((2 * j + lh) ^ fsw));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < NG; ++j) {
-            acc = mfma32(qa[j].x, qb[j].x, acc);
-            acc = mfma32(qa[j].y, qb[j].y, acc);
-            acc = mfma32(qa[j].z, qb[j].z, acc);
-            acc = mfma32(qa[j].w, qb[j].w, acc);
-        }
-        cbuf = (cbuf + 1 == NST) ? 0 : cbuf + 1;
-        ++ksc;
-        if (trc && tid == 0 && i == S - 1) trc[3] = wall_clock64();
-        if (ksc != KS && i != S - 1) continue;
-        // ---- a segment [kbeg, ksc) of tile (ctc, rtc) is complete
-        if (kbeg > 0) {
-            // TAIL of a tile whose head belongs to worker w - 1: publish the partial sum (slot w), write-through, then the flag
-#pragma unroll
-            for (int j4 = 0; j4 < 4; ++j4)
-                st4_sc1(ws + ((size_t)(w * 4 + j4) * 256 + tid) * 4, (f32x4){acc[4 * j4], acc[4 * j4 + 1], acc[4 * j4 + 2], acc[4 * j4 + 3]});
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(flags + w, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (ksc != KS) {
-                // HEAD of a tile that worker w + 1 finished at the start of its run: add its partial (head + tail, fixed order)
-                if (tid == 0) {
-                    int spin = 0;
-                    while (__hip_atomic_load(flags + w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != stamp) {
-                        __builtin_amdgcn_s_sleep(8);
-                        if (++spin > (1 << 16)) { ((GAS StepState*)st)->nan_flag = 1; break; }      // ~0.1 s; never observed; no hang
-                    }
-                }
-                __syncthreads();
-                // loads and their wait in ONE asm statement, early-clobber outputs (guide section 5.7 item 1, form (i)): the compiler
-                // sees the registers written when the statement ends, which is then true
-                f32x4 o[4];
-                const GAS float* wp = ws + ((size_t)((w + 1) * 4) * 256 + tid) * 4;
-                asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
-                             "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
-                             : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
-                             : "v"(wp), "v"(wp + 1024), "v"(wp + 2048), "v"(wp + 3072) : "memory");
-#pragma unroll
-                for (int j = 0; j < 16; ++j) acc[j] += o[j >> 2][j & 3];
-            }
-            const int n = ctc * 64 + wn * 32 + l32;
-            const float bias = sBias[(ctc - ct0) * 64 + wn * 32 + l32];
-            if (n < N) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int row = rtc * 64 + wm * 32 + 8 * (j >> 2) + 4 * lh + (j & 3);
-                    if (row < M) Sc[(size_t)row * ld + n] = acc[j] + bias;
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-        kbeg = 0; ksc = 0;
-        if (++rtc == nrt) { rtc = 0; ++ctc; }
-    }
-    if (trc && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[4] = wall_clock64(); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1282,17 +1063,11 @@ __global__ __launch_bounds__(256, G4R_BWD2_WPE) void k_score_bwd2(const DevModel
             const int item = sIt[min(kk + kr, kch - 1)];
             return (item >= 0 && kk + kr < kch) ? Wy + (size_t)item * D + d0 + cc : nullptr;
         };
-        // the same rows out of the compact copy (k_compact_sy): consecutive memory, no item look-up (inactive columns hold zeros there)
-        const GAS float* syc = m.Syc;
-        auto bptr_c = [&](int kk, int kr, int cc) -> const GAS float* {
-            return (kk + kr < kch && kbeg + kk + kr < ld) ? syc + (size_t)(kbeg + kk + kr) * D + d0 + cc : nullptr;
-        };
         auto epi = [&](int b, int d, float v, float4) {
             if (b < M) dhpart[((size_t)kc * B + b) * D + d] = v;
         };
         if (trc && tid == 0) trc[1] = wall_clock64();
-        if (syc) gemm_tile2k<false, true>(m0, d0, min(kch, ld - kbeg), arow, bptr_c, m.zrow, NoPre(), epi, smem, trc);
-        else gemm_tile2k<false, true>(m0, d0, min(kch, ld - kbeg), arow, bptr, m.zrow, NoPre(), epi, smem, trc);
+        gemm_tile2k<false, true>(m0, d0, min(kch, ld - kbeg), arow, bptr, m.zrow, NoPre(), epi, smem, trc);
         return;
     }
     // ---- role C: 64 columns, thread (column tid & 63, row group tid >> 6)
@@ -1795,128 +1570,10 @@ __device__ __forceinline__ void dense_grad_tile(const DevModel& m, StepState* st
     static_assert(DT == 32, "tile edge");
     gemm_tile<GT_BM, GT_BN, GT_BK, true, false, GT_NTH_FEW>(tl.r0, tl.c0, M, aload, bload, pre, epi, smem);
 }
-// The same 32 x 32 tile WITHOUT operand staging: the contraction runs over the batch (K = M <= a few hundred), so a tile's
-// operands are K x 32 floats each and every k-step of an MFMA chain can be fed straight from L2: lane (li, lg) loads the two
-// floats X[k0 + lg][r0 + 2 li .. + 1] and dV[k0 + lg][c0 + 2 li .. + 1] (16 lanes x 8 B = one 128-byte run per k) and uses them as
-// the A / B operands of the 2 x 2 sub-tiles whose row i / column j stand for output row r0 + 2 i + s / column c0 + 2 j + s'.  The
-// NW waves of the workgroup split K and add their accumulators through LDS (fixed order); no LDS staging, no barrier inside the
-// K loop, all loads of a wave in flight at once.  EXPERIMENT (G4R_DT=0), not the default: measured against the staged tile it is
-// no faster (cfg3: 20.8 vs 19.1 us alone), because both are bound by L2 -> CU bandwidth, not by staging.
-__device__ __forceinline__ float2 ld2_if(const GAS float* base, size_t off, bool ok) {
-    const float2 v = *(const GAS float2*)(base + (ok ? off : (size_t)0));
-    return make_float2(ok ? v.x : 0.f, ok ? v.y : 0.f);
-}
-template <int NW>
-__device__ __forceinline__ void dense_grad_direct(const DevModel& m, StepState* st, const DenseTile* tiles_, int tile, float* smem) {
-    const GAS DenseTile* tiles = (const GAS DenseTile*)tiles_;
-    GAS long long* trc = G4R_DBGTILE(m) ? G4R_DBGTILE(m) + 8 * (size_t)tile : nullptr;
-    const long long tr0 = trc ? wall_clock64() : 0;
-    const StepCtx c = load_ctx(st);
-    const DenseTile tl = tiles[tile];
-    const GAS float* X = tl.gather ? (const GAS float*)m.yin0 : ((c.g & 1) ? tl.X1 : tl.X0);
-    const GAS float* dV = tl.dV;
-    const int M = c.M;
-    const bool ones = (X == nullptr);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lg = lane >> 4;
-    const float lr = m.lr, momc = m.mom, lmbd = m.lmbd;
-    const int inplace = m.apply_dense_inplace;
-    long long tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0;
-    if (trc) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tr1 = wall_clock64(); }      // context + descriptor here
-    GAS float *dp = m.dense_p, *dacc = m.dense_acc, *dvel = m.dense_vel, *dg = m.dense_g;
-    // optimizer state of the elements this lane finishes (issued first: they fly during the K loop).  Finishing wave w takes
-    // output rows of parity sa = w & 1 and NRG = 8 / NW accumulator registers rg of every lane, both columns (sb = 0, 1) of each:
-    // 16 lanes x 8 bytes = 128-byte runs.
-    constexpr int NRG = 8 / NW;                        // 1 (8 waves) or 2 (4 waves)
-    const int sa = wid & 1, rg0 = (wid >> 1) * NRG;
-    float2 pa[NRG], pp[NRG], pv[NRG];
-    size_t eoff[NRG];
-    bool eok[NRG];
-#pragma unroll
-    for (int q = 0; q < NRG; ++q) {
-        const int row = tl.r0 + 2 * (4 * lg + rg0 + q) + sa, col = tl.c0 + 2 * li;
-        eok[q] = row < tl.nrows && col < tl.ncols;      // column counts are even
-        eoff[q] = (size_t)tl.base + (size_t)row * tl.ldo + col;
-        const bool ok = eok[q] && inplace;
-        const size_t o = ok ? eoff[q] : (size_t)0;
-        pa[q] = *(const GAS float2*)(dacc + o);
-        pp[q] = *(const GAS float2*)(dp + o);
-        pv[q] = make_float2(0.f, 0.f);
-        if (momc > 0.f) pv[q] = *(const GAS float2*)(dvel + o);
-    }
-    const int nsteps = (M + 3) >> 2, per = (nsteps + NW - 1) / NW;
-    const int s0 = wid * per, s1 = min(nsteps, s0 + per);
-    const int mcol = tl.r0 + 2 * li, ncol = tl.c0 + 2 * li;
-    const bool mok = mcol < tl.nrows, nok = ncol < tl.ncols;      // row / column counts are even (1 for the bias row: `ones`)
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 8;
-    for (int s = s0; s < s1; s += U) {
-        float2 av[U], bv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = 4 * (s + u) + lg;
-            const bool ok = (s + u < s1) && k < M;
-            if (ones) av[u] = make_float2((ok && mcol == 0) ? 1.f : 0.f, 0.f);
-            else av[u] = ld2_if(X, (size_t)k * tl.ldx + mcol, ok && mok);
-            bv[u] = ld2_if(dV, (size_t)k * tl.ldv + tl.coff + ncol, ok && nok);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            acc[0][0] = mfma16(av[u].x, bv[u].x, acc[0][0]);
-            acc[0][1] = mfma16(av[u].x, bv[u].y, acc[0][1]);
-            acc[1][0] = mfma16(av[u].y, bv[u].x, acc[1][0]);
-            acc[1][1] = mfma16(av[u].y, bv[u].y, acc[1][1]);
-        }
-    }
-    if (trc) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tr2 = wall_clock64(); }      // K loop done (and pre loads landed)
-    // partial accumulators of the NW waves -> LDS, summed in wave order by the finishing waves
-    f32x4* sR = reinterpret_cast<f32x4*>(smem);      // [NW][4 sub-tiles][64 lanes]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) sR[(wid * 4 + 2 * a + b) * 64 + lane] = acc[a][b];
-    __syncthreads();
-    if (trc) tr3 = wall_clock64();
-    float gx[NRG], gy[NRG];
-#pragma unroll
-    for (int q = 0; q < NRG; ++q) { gx[q] = 0.f; gy[q] = 0.f; }
-    for (int w = 0; w < NW; ++w) {
-        const f32x4 o0 = sR[(w * 4 + 2 * sa + 0) * 64 + lane], o1 = sR[(w * 4 + 2 * sa + 1) * 64 + lane];
-#pragma unroll
-        for (int q = 0; q < NRG; ++q) { gx[q] += o0[rg0 + q]; gy[q] += o1[rg0 + q]; }
-    }
-#pragma unroll
-    for (int q = 0; q < NRG; ++q) {
-        if (!eok[q]) continue;
-        const float g[2] = {gx[q], gy[q]};
-        if (!inplace) { *(GAS float2*)(dg + eoff[q]) = make_float2(g[0], g[1]); continue; }
-        const float a0[2] = {pa[q].x, pa[q].y}, p0[2] = {pp[q].x, pp[q].y}, v0[2] = {pv[q].x, pv[q].y};
-        float an[2], pn[2], vn[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            an[e] = a0[e] + g[e] * g[e];            // gru4rec.py:330-334,390-406
-            const float gs = g[e] * frsq(an[e] + G4R_EPS_ADAGRAD);
-            if (momc > 0.f) { vn[e] = momc * v0[e] - lr * (gs + lmbd * p0[e]); pn[e] = p0[e] + vn[e]; }
-            else { vn[e] = 0.f; pn[e] = p0[e] * (1.0f - lr * lmbd) - lr * gs; }
-        }
-        *(GAS float2*)(dacc + eoff[q]) = make_float2(an[0], an[1]);
-        *(GAS float2*)(dp + eoff[q]) = make_float2(pn[0], pn[1]);
-        if (momc > 0.f) *(GAS float2*)(dvel + eoff[q]) = make_float2(vn[0], vn[1]);
-    }
-    if (trc) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tr4 = wall_clock64();
-        if (tid == 0) { trc[0] = tr0; trc[1] = tr1; trc[2] = tr2; trc[3] = tr3; trc[4] = tr4; trc[5] = c.t; trc[6] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) ; }
-    }
-}
 template <int DT>
 __global__ __launch_bounds__(GT_NTH_FEW) void k_dense_grad(const DevModel* __restrict__ mp, StepState* st, const DenseTile* __restrict__ tiles_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if constexpr (DT == 0) dense_grad_direct<GT_NTH_FEW / 64>(*mp, st, tiles_, blockIdx.x, smem);
-    else dense_grad_tile<DT>(*mp, st, tiles_, blockIdx.x, smem);
+    dense_grad_tile<DT>(*mp, st, tiles_, blockIdx.x, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2558,8 +2215,7 @@ __global__ __launch_bounds__(SP_WAVES * 64, 4) void k_update(const DevModel* __r
     if (b < 0) sparse_update_block<MAXCH, MOM>(mp, st, nblk_occ, nblk_occ, smem);
     else if (b < ntiles) {
         const int t = G4R_XCD_TILE(b, ntiles);      // neighbouring tiles of the table share their X rows: keep them on one XCD
-        if constexpr (DT == 0) dense_grad_direct<SP_WAVES>(*mp, st, tiles_, t, smem);
-        else dense_grad_tile<DT>(*mp, st, tiles_, t, smem);
+        dense_grad_tile<DT>(*mp, st, tiles_, t, smem);
     } else sparse_update_block<MAXCH, MOM>(mp, st, nblk_occ, b - ntiles, smem);
 }
 

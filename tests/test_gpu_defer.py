@@ -78,6 +78,32 @@ def test_deferred_updates_leave_identical_bits(case):
     print('%s: %d row updates (%d with a bias entry) went through flush launches' % (case, int(st1[0]), int(st1[1])))
 
 
+def test_deferred_updates_without_the_step_graph():
+    """Eager launches (use_graph = 0; what the counter passes of tools/final_profile.sh run): the same windows, the same bits."""
+    I, B, ns, T = 3000, 48, 128, 40
+    kw = dict(loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(48,), learning_rate=0.1, bpreg=1.0)
+    outs = []
+    for defer, graph in ((0, 0), (1, 0), (1, 1)):
+        old = os.environ.get('G4R_DEFER')
+        os.environ['G4R_DEFER'] = str(defer)
+        try:
+            o, m = make_pair(I, B, ns, store_rows=50, use_graph=graph, **kw)
+        finally:
+            if old is None:
+                os.environ.pop('G4R_DEFER', None)
+            else:
+                os.environ['G4R_DEFER'] = old
+        plan = random_plan(I, B, T, seed=9, tail=True)
+        m.set_plan(plan)
+        m.train_steps(0, T)
+        assert (m.get_debug('defer_stats', 4)[0] > 0) == bool(defer)
+        outs.append((m.get_losses(0, T).copy(), m.get_param('Wy', (I, 48)).copy(), m.get_param('By', (I,)).copy()))
+        m.close()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_deferral_is_off_where_it_does_not_apply():
     """Momentum (velocity rows), an L2 term and the generic optimizers keep the immediate update."""
     old = os.environ.get('G4R_DEFER')

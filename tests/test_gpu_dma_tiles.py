@@ -63,37 +63,6 @@ def test_score_rows_longer_than_two_lds_copies(loss, fa):
          layers=(32,), learning_rate=0.05, logq=1.0 if loss == 'cross-entropy' else 0.0, bpreg=0.5)
 
 
-@pytest.mark.parametrize('W,D', [(7, 96), (37, 96), (96, 96), (61, 256), (340, 32)])
-def test_stream_k_scoring_forward_split_positions(monkeypatch, W, D):
-    """The persistent stream-K scoring forward (k_score_fwd_sk: W workers, each a contiguous run of (tile, K stage) units; a tile
-    cut between two workers is finished by the head's owner in the fixed order head + tail) at worker counts that put the cuts at
-    every kind of position: inside the first stage pair (W = 96, D = 96: runs of 10.6 units, three stages per tile), many tiles
-    per worker (W = 7), one tile per worker with no cut at all (W = 340 = number of tiles), eight stages per tile (D = 256).
-    The persistent launch is opt-in (it measured no faster than the tile launch): G4R_STREAMK=1 serves launches of >= 3 tiles per CU,
-    G4R_STREAMK=2 any tile count.
-    The ragged batch tail (M below a 64-row tile) and inactive columns run through the same code."""
-    monkeypatch.setenv('G4R_STREAMK', '2')
-    monkeypatch.setenv('G4R_SK_W', str(W))
-    from gru4rec_amd import _native
-    o, m = make_pair(12000, 300, 4000, store_rows=8, loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(D,),
-                     learning_rate=0.1, bpreg=0.5)
-    assert int(m.get_debug('streamk_workers', (1,))[0]) == W
-    m.close()
-    _run('stream-K W=%d D=%d' % (W, D), I=12000, B=300, ns=4000, T=6, store_rows=8, loss='bpr-max', final_act='elu-0.5',
-         constrained_embedding=True, layers=(D,), learning_rate=0.1, bpreg=0.5)
-
-
-def test_stream_k_at_the_cfg4_shape(monkeypatch):
-    """B = 512, 8192 negatives, D = 256 -- 1088 tiles, three workers per CU (768 on an MI355X), every worker's run cut inside tiles."""
-    monkeypatch.setenv('G4R_STREAMK', '1')
-    from gru4rec_amd import _native
-    kw = dict(loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(256,), learning_rate=0.1, bpreg=1.0)
-    o, m = make_pair(20000, 512, 8192, store_rows=6, **kw)
-    assert int(m.get_debug('streamk_workers', (1,))[0]) >= 512
-    m.close()
-    _run('stream-K cfg4 shape', I=20000, B=512, ns=8192, T=4, store_rows=6, tail=False, **kw)
-
-
 @pytest.mark.parametrize('B,ns,D', [(240, 2048, 128), (300, 4000, 48), (256, 3840, 64)])
 def test_tile_or_slab_that_starts_on_an_inactive_in_batch_column(B, ns, D):
     """The tail of an epoch (M < B): the in-batch columns [M, B) are inactive (-1 items).  A 64-column tile of the scoring forward
@@ -103,30 +72,3 @@ def test_tile_or_slab_that_starts_on_an_inactive_in_batch_column(B, ns, D):
     into the inactive range."""
     _run('inactive head B=%d D=%d' % (B, D), I=9000, B=B, ns=ns, T=8, store_rows=10, loss='bpr-max', final_act='elu-0.5',
          constrained_embedding=True, layers=(D,), learning_rate=0.1, bpreg=0.5)
-
-
-@pytest.mark.parametrize('B,ns,D,tail', [(256, 3840, 128, True), (240, 2048, 512, False), (512, 8192, 256, True)])
-def test_compact_copy_of_the_score_rows_changes_no_bit(monkeypatch, B, ns, D, tail):
-    """k_compact_sy: at the k_score_bwd2 shapes the scoring forward and the dh slabs read the step's Wy rows from a compact copy made
-    at the start of the step instead of gathering them from the table (G4R_SYC=0: as before).  Same values through the same
-    arithmetic: losses, item tables, accumulators and dense parameters must be IDENTICAL -- with finished sessions (-1 columns),
-    items repeated between inputs / targets / negatives, and a batch that shrinks below B."""
-    outs = []
-    for syc in ('0', '1', '2'):      # 2: the copy runs on a branch of its own next to the GRU forward (inside the step graph)
-        monkeypatch.setenv('G4R_SYC', syc)
-        I, T = 20000, 6
-        _, m = make_pair(I, B, ns, store_rows=8, use_graph=1, loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(D,),
-                         learning_rate=0.1, bpreg=0.5, momentum=0.1)
-        plan = random_plan(I, B, T, seed=5, tail=tail)
-        if tail:
-            plan['M'][T // 2:] = max(1, B - 37)
-        plan['out_idx'][:, 6:12] = plan['in_idx'][:, :6]
-        m.set_plan(plan)
-        m.train_steps(0, T)
-        assert int(m.get_debug('compact_sy', (1,))[0]) == int(syc != '0')
-        outs.append((m.get_losses(0, T), m.get_param('Wy', (I, D)), m.get_param('acc_Wy', (I, D)), m.get_param('By', (I,)),
-                     m.get_param('Wx', (D, 3 * D), 0), m.get_param('Wh', (D, D), 0), m.get_param('acc_Wh', (D, D), 0)))
-        m.close()
-    for other in outs[1:]:
-        for a, b in zip(outs[0], other):
-            np.testing.assert_array_equal(a, b)
