@@ -47,10 +47,10 @@ void g4r_set_error(const char* fmt, ...) {
     } while (0)
 
 enum { KN_GRU_P1 = 0, KN_GRU_P2, KN_SCORE_FWD, KN_LOSS, KN_SCORE_BWD, KN_BWD_PRE, KN_BWD_A, KN_BWD_B, KN_DENSE, KN_ALLREDUCE,
-       KN_DENSE_APPLY, KN_SPARSE, KN_UPDATE, KN_BWD_FUSED, KN_FWD_FUSED, KN_GATE, KN_FLUSH, KN_SCAN, KN_COUNT };
+       KN_DENSE_APPLY, KN_SPARSE, KN_UPDATE, KN_BWD_FUSED, KN_FWD_FUSED, KN_GATE, KN_FLUSH, KN_SCAN, KN_FINISH, KN_COUNT };
 static const char* KN_NAMES[KN_COUNT] = {"k_gru_p1", "k_gru_p2", "k_score_fwd", "k_loss_rows", "k_score_bwd", "k_gru_bwd_pre",
                                          "k_gru_bwd_a", "k_gru_bwd_b", "k_dense_grad", "rccl_allreduce", "k_dense_apply",
-                                         "k_sparse_update", "k_update", "k_gru_bwd", "k_gru_fwd", "k_gru_gate", "k_sparse_flush", "k_defer_scan"};
+                                         "k_sparse_update", "k_update", "k_gru_bwd", "k_gru_fwd", "k_gru_gate", "k_sparse_flush", "k_defer_scan", "k_finish_rows"};
 
 struct EvRec { int kn; hipEvent_t a, b; };
 
@@ -507,7 +507,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
                 }
             }
             // dy: enough slices of >= 128 (multiples of 32) to give every CU a workgroup, <= 16 (what the consumers add up in one round trip)
-            const bool consumer = (l == 0) ? wdense : !fused_bwd(d, l - 1);
+            const bool consumer = (l == 0) ? (!automask || wdense) : !fused_bwd(d, l - 1);      // (layer 0: k_finish_rows -- by default only next to k_dense_grad2)
             if ((mask & 8) && consumer) {
                 const int K = 3 * D, tiles = cdiv(IN, 64) * nrt, forced = env_int("G4R_BB_KS", 0);
                 int n = std::min(std::max(1, cdiv(m->n_cu, std::max(tiles, 1))), std::max(1, K / 128));
@@ -869,7 +869,9 @@ static inline int row_chunks(const DevModel& d) { const int w = std::max(d.Dtop,
 // (wide layers: the dense gradients run as 64 x 64 tiles in a launch of their own, k_dense_grad2, ahead of the sparse row update)
 static inline bool merged_update(const g4r_model* m) { return !m->dm.generic && !no_merge_tail() && row_chunks(m->dm) <= 2 && !m->wide_dense; }
 // part: 0 = the whole step; 1 = head (everything up to the dense gradients); 2 = tail (all-reduce, dense apply, sparse update)
-static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
+// capturing: called from a stream capture (ensure_graph): independent launches may then sit on a BRANCH of the graph (fork / join through
+// events on comm_stream) -- in eager mode the two cross-stream dependencies would cost more than the overlap gives
+static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0, bool capturing = false) {
     DevModel& d = m->dm;
     const int L = d.n_layers, B = d.B;
     hipStream_t s = m->stream;
@@ -908,6 +910,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     const DevModel* dmp = (const DevModel*)m->d_dm;
     StepState* stp = (StepState*)d.st;
     bool merged = false;      // the sparse update already ran inside k_update
+    bool forked = false;      // the dense-gradient tiles run on a graph branch (comm_stream): joined behind the sparse update
     if (part != 2) {
     for (int l = 0; l < L; ++l) {
         if (fused_fwd(d, l)) {
@@ -990,6 +993,11 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         const size_t smem = std::max(SMEM_TN, m->smem_sparse);
         const dim3 grid(m->ntiles + m->nblk_occ + 1), blk(SP_WAVES * 64);
         const bool one = row_chunks(d) == 1;
+        if (d.bbn[0] > 0) {      // (dy of layer 0 as K-slice partial sums with the merged update: only when asked for, G4R_WIDE2)
+            begin(KN_FINISH);
+            LK(k_finish_rows, dim3(cdiv((long long)B * (d.IN[0] / 4), 256)), dim3(256), 0, s, dmp, stp);
+            end();
+        }
         begin(KN_UPDATE);
         const bool mo = d.mom > 0.f;
 #define G4R_LK_UPDATE(CH, DT_)                                                                                                          \
@@ -1002,10 +1010,22 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         end();
         if (d.apply_dense_inplace || part == 1) { HIPCHK(hipGetLastError()); return 0; }
     } else {
+    // wide layers on one GPU: the dense-gradient tiles (+ fused dense Adagrad) share nothing with the sparse rows -- inside the step graph
+    // they run on a branch next to k_finish_rows + k_sparse_update and join in front of the next step (G4R_FORK=0: one after the other)
+    static const bool want_fork = env_int("G4R_FORK", 1) != 0;
+    forked = capturing && want_fork && m->wide_dense && d.apply_dense_inplace && !recs && !trace && part == 0;
+    hipStream_t ds = s;
+    if (forked) { HIPCHK(hipEventRecord(m->ev_fork, s)); HIPCHK(hipStreamWaitEvent(m->comm_stream, m->ev_fork, 0)); ds = m->comm_stream; }
     begin(KN_DENSE);
-    if (m->wide_dense) LK(k_dense_grad2, dim3(m->ntiles64 + (d.bbn[0] > 0 ? cdiv((long long)B * (d.IN[0] / 4), 256) : 0)), dim3(256), SMEM_T2K, s, dmp, stp, (const DenseTile*)m->d_tiles64, m->ntiles64);
+    if (m->wide_dense) LK(k_dense_grad2, dim3(m->ntiles64), dim3(256), SMEM_T2K, ds, dmp, stp, (const DenseTile*)m->d_tiles64, m->ntiles64);
     else LK(k_dense_grad<32>, dim3(m->ntiles), dim3(GT_NTH_FEW), SMEM_TN, s, dmp, stp, (const DenseTile*)m->d_tiles);
     end();
+    if (forked) HIPCHK(hipEventRecord(m->ev_join, m->comm_stream));
+    if (d.bbn[0] > 0) {      // dy of layer 0 arrived as K-slice partial sums: the input rows' Adagrad pieces, ahead of the sparse row update
+        begin(KN_FINISH);
+        LK(k_finish_rows, dim3(cdiv((long long)B * (d.IN[0] / 4), 256)), dim3(256), 0, s, dmp, stp);
+        end();
+    }
     }
     }
     if (part == 1) { HIPCHK(hipGetLastError()); return 0; }
@@ -1081,7 +1101,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
 #undef G4R_LK_SPARSE
     }
     end();
-    if (overlap) HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0));
+    if (overlap || forked) HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0));
 #undef begin
 #undef LK
     HIPCHK(hipGetLastError());
@@ -1132,7 +1152,7 @@ static int ensure_graph(g4r_model* m) {
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(m->stream, rccl_in_graph ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
     int rc = 0;
-    for (int i = 0; i < G4R_GRAPH_STEPS && !rc; ++i) rc = launch_step(m, nullptr);
+    for (int i = 0; i < G4R_GRAPH_STEPS && !rc; ++i) rc = launch_step(m, nullptr, 0, true);
     hipError_t e = hipStreamEndCapture(m->stream, &graph);
     if (rc || e != hipSuccess || !graph) {
         if (graph) (void)hipGraphDestroy(graph);
@@ -1150,7 +1170,7 @@ static int ensure_graph(g4r_model* m) {
         hipGraph_t g2 = nullptr;
         if (hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             int rc2 = 0;
-            for (int i = 0; i < G4R_GRAPH_STEPS_SMALL && !rc2; ++i) rc2 = launch_step(m, nullptr);
+            for (int i = 0; i < G4R_GRAPH_STEPS_SMALL && !rc2; ++i) rc2 = launch_step(m, nullptr, 0, true);
             hipError_t e2 = hipStreamEndCapture(m->stream, &g2);
             if (!rc2 && e2 == hipSuccess && g2 && hipGraphInstantiate(&m->gexec_small, g2, nullptr, nullptr, 0) != hipSuccess) m->gexec_small = nullptr;
             if (g2) (void)hipGraphDestroy(g2);

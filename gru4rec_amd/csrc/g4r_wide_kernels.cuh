@@ -2,9 +2,9 @@
 // K range of a tile cut into slices, one workgroup each, and the slices left as PARTIAL SUMS that the kernel which consumes the
 // product anyway adds up behind the kernel boundary:
 //   k_gru_p1s   V = [y | H] [Wx ; 0 | Wrz] as partial sums vp[slice][B][3D]      -> k_gru_gate adds them, bias, r / Hr / z
-//   k_gru_bwd_bw dy = dV Wx^T as partial sums dyp[slice][B][IN]                   -> the lower layer's k_gru_bwd_pre, or (layer 0) the
-//                                                                                   row-finishing workgroups of k_dense_grad2
-//   k_dense_grad2 the dense gradients on 64 x 64 tiles (contraction over the batch: nothing to slice) + those row-finishing workgroups
+//   k_gru_bwd_bw dy = dV Wx^T as partial sums dyp[slice][B][IN]                   -> the lower layer's k_gru_bwd_pre, or (layer 0) k_finish_rows
+//   k_dense_grad2 the dense gradients on 64 x 64 tiles (contraction over the batch: nothing to slice), as a launch of its own that runs
+//                 on a BRANCH of the step graph next to k_finish_rows + the sparse row update (they share nothing)
 //
 // Why (BASELINE configs[2]: B = 240, D = 512; profiles/r04_*, profiles/r05_experiments.md): a wide layer's products are a few dozen
 // 64 x 64 tiles -- the round-1 kernels keep the whole K range in one workgroup (k_gru_bwd_b: 128 workgroups of 393 KB of operands,
@@ -190,6 +190,45 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_bw(const DevModel* __restric
     gemm_tile3<3, 32, true>(m0, n0, Klen, arow, brow, m.zrow, NoPre(), epi, smem);
 }
 
+// The layer-0 input rows when k_gru_bwd_bw left dy as K-slice partial sums (DevModel::bbn[0] > 0): one quad of dy per thread -- slices
+// added in slice order, embedding-dropout mask, per-occurrence Adagrad pieces dSx / dAx (or the accumulator in place for an item that
+// occurs once: see k_gru_bwd_b) -- ahead of the sparse row update that consumes them (same stream; the dense-gradient tiles run
+// next to both on a branch of the step graph).
+__global__ __launch_bounds__(256) void k_finish_rows(const DevModel* __restrict__ mp, StepState* st) {
+    const DevModel& m = *mp;
+    const StepCtx c = load_ctx(st);
+    const int IN = m.IN[0], nq = IN >> 2, nsl = m.bbn[0], B = m.B;
+    const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int row = e / nq, c4 = 4 * (e - row * nq);
+    if (row >= c.M) return;
+    const int item = m.occ_idx[row];
+    const GAS float* pp = m.dyp + (size_t)row * IN + c4;
+    const size_t ps = (size_t)B * IN;
+    float4 v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = ld4(pp + (size_t)min(q, nsl - 1) * ps);
+    GAS float* accT = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.accWy : m.accE;
+    const float4 a0 = ld4_at(accT, (size_t)max(item, 0) * IN + c4, item >= 0);
+    const int cnt1 = m.occ_fl[4 * (((m.embed_mode == G4R_EMBED_CONSTRAINED) ? (size_t)0 : (size_t)m.n_items) + max(item, 0)) + 2];
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        if (q < nsl) { g.x += v[q].x; g.y += v[q].y; g.z += v[q].z; g.w += v[q].w; }
+    if (m.drop_e > 0.f) {
+        const float4 mk = drop_mult4(m.seed, (unsigned)c.g, G4R_STREAM_DROP_EMBED, row, c4 >> 2, 1.0f - m.drop_e);
+        g.x *= mk.x; g.y *= mk.y; g.z *= mk.z; g.w *= mk.w;
+    }
+    const size_t o = (size_t)row * IN + c4;
+    const float lr = m.lr;
+    const bool generic = m.generic != 0;
+    const float4 an = make_float4(a0.x + G4R_MUT_ACC(g.x * g.x), a0.y + G4R_MUT_ACC(g.y * g.y), a0.z + G4R_MUT_ACC(g.z * g.z), a0.w + G4R_MUT_ACC(g.w * g.w));
+    const float4 stp = generic ? g : make_float4(G4R_MUT_STEP(lr * g.x * frsq(an.x + G4R_EPS_ADAGRAD)), G4R_MUT_STEP(lr * g.y * frsq(an.y + G4R_EPS_ADAGRAD)),
+                                                 G4R_MUT_STEP(lr * g.z * frsq(an.z + G4R_EPS_ADAGRAD)), G4R_MUT_STEP(lr * g.w * frsq(an.w + G4R_EPS_ADAGRAD)));
+    st4(G4R_DSX(m, c.g) + o, stp);
+    if (!generic && cnt1 == 1 && item >= 0) st4(accT + (size_t)item * IN + c4, an);
+    else st4(m.dAx + o, an);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // Dense GRU gradients on 64 x 64 tiles (contraction over the batch: both operands K-major -> gemm_tile2k):
 //   dWx = yin^T dV ; dWh = (H r)^T dV[:, :D] ; dWrz = H^T dV[:, D:] ; dBh = colsum(dV)   (descriptor entries with nrows == 1: plain
@@ -197,47 +236,11 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_bw(const DevModel* __restric
 // single GPU, or the gradient -> dense_g for the all-reduce.  Against the 32 x 32 tiles of k_update (dense_grad_tile): half the
 // operand bytes per output, the 32x32x2 MFMA, operands two chunks ahead.  Runs as a launch of its own in front of the sparse row
 // update (at wide layers the two roles of k_update did not overlap anyway: DESIGN.md section 6).
-// Workgroups [ntiles, gridDim) finish the layer-0 input rows when k_gru_bwd_bw left dy as K-slice partial sums (DevModel::bbn[0] > 0):
-// one quad of dy per thread -- slices added in slice order, embedding-dropout mask, per-occurrence Adagrad pieces dSx / dAx (or the
-// accumulator in place for an item that occurs once: see k_gru_bwd_b) -- ahead of the sparse row update that consumes them.
 __global__ __launch_bounds__(256, 2) void k_dense_grad2(const DevModel* __restrict__ mp, StepState* st, const DenseTile* __restrict__ tiles_, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const GAS DenseTile* tiles = (const GAS DenseTile*)tiles_;
     const StepCtx c = load_ctx(st);
-    if ((int)blockIdx.x >= ntiles) {
-        const int IN = m.IN[0], nq = IN >> 2, nsl = m.bbn[0], B = m.B;
-        const int e = ((int)blockIdx.x - ntiles) * 256 + (int)threadIdx.x;
-        const int row = e / nq, c4 = 4 * (e - row * nq);
-        if (row >= c.M) return;
-        const int item = m.occ_idx[row];
-        const GAS float* pp = m.dyp + (size_t)row * IN + c4;
-        const size_t ps = (size_t)B * IN;
-        float4 v[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = ld4(pp + (size_t)min(q, nsl - 1) * ps);
-        GAS float* accT = (m.embed_mode == G4R_EMBED_CONSTRAINED) ? m.accWy : m.accE;
-        const float4 a0 = ld4_at(accT, (size_t)max(item, 0) * IN + c4, item >= 0);
-        const int cnt1 = m.occ_fl[4 * (((m.embed_mode == G4R_EMBED_CONSTRAINED) ? (size_t)0 : (size_t)m.n_items) + max(item, 0)) + 2];
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-            if (q < nsl) { g.x += v[q].x; g.y += v[q].y; g.z += v[q].z; g.w += v[q].w; }
-        if (m.drop_e > 0.f) {
-            const float4 mk = drop_mult4(m.seed, (unsigned)c.g, G4R_STREAM_DROP_EMBED, row, c4 >> 2, 1.0f - m.drop_e);
-            g.x *= mk.x; g.y *= mk.y; g.z *= mk.z; g.w *= mk.w;
-        }
-        const size_t o = (size_t)row * IN + c4;
-        const float lr = m.lr;
-        const bool generic = m.generic != 0;
-        const float4 an = make_float4(a0.x + G4R_MUT_ACC(g.x * g.x), a0.y + G4R_MUT_ACC(g.y * g.y), a0.z + G4R_MUT_ACC(g.z * g.z), a0.w + G4R_MUT_ACC(g.w * g.w));
-        const float4 stp = generic ? g : make_float4(G4R_MUT_STEP(lr * g.x * frsq(an.x + G4R_EPS_ADAGRAD)), G4R_MUT_STEP(lr * g.y * frsq(an.y + G4R_EPS_ADAGRAD)),
-                                                     G4R_MUT_STEP(lr * g.z * frsq(an.z + G4R_EPS_ADAGRAD)), G4R_MUT_STEP(lr * g.w * frsq(an.w + G4R_EPS_ADAGRAD)));
-        st4(G4R_DSX(m, c.g) + o, stp);
-        if (!generic && cnt1 == 1 && item >= 0) st4(accT + (size_t)item * IN + c4, an);
-        else st4(m.dAx + o, an);
-        return;
-    }
     const DenseTile tl = tiles[G4R_XCD_TILE(blockIdx.x, ntiles)];
     const int M = c.M, tid = threadIdx.x;
     const float lr = m.lr, momc = m.mom, lmbd = m.lmbd;

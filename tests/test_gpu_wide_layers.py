@@ -76,10 +76,10 @@ def test_wide_kernels_against_the_oracle(name, tail):
     assert not errs, errs
 
 
-@pytest.mark.parametrize('mask', [1, 16, 24, ALL, -1])
+@pytest.mark.parametrize('mask', [1, 8, 16, 24, ALL, -1])
 def test_each_wide_kernel_against_the_kernel_it_replaces(mask):
-    """One new kernel at a time (8 needs 16: the launch that adds dy's slices up for layer 0), all of them, and -1: the default policy,
-    next to the round-1 kernels on the same plan: the losses agree to summation order."""
+    """One new kernel at a time, 8 + 16, all of them, and -1: the default policy, next to the round-1 kernels on the same plan: the
+    losses agree to summation order."""
     I, B, ns, T, kw = SHAPES['d512_b240_xe_logq_drop']
     runs = {}
     for mk in (0, mask):
@@ -130,8 +130,9 @@ def test_slice_lengths(ks):
 
 
 def test_wide_graph_replay_is_bit_identical_to_eager():
-    """32 steps as two graph replays against 32 eager steps: identical bits in every loss and parameter (slices are added in slice
-    order), and a second identical run reproduces the first."""
+    """32 steps as two graph replays -- the dense-gradient tiles on a BRANCH of the graph next to k_finish_rows + the sparse row update --
+    against 32 eager steps (one launch after the other): identical bits in every loss and parameter (slices are added in slice order;
+    the two branches share no byte), and a second identical run reproduces the first."""
     I, B, ns, T, kw = 4000, 240, 1024, 32, SHAPES['d512_b240_xe_logq_drop'][4]
     out = []
     for use_graph in (0, 1, 1):
