@@ -478,7 +478,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     //       (6 D >= 2 B + n_sample: BASELINE configs[2] yes -- k_update 24.4 us as one launch, 17.7 + 7.5 as two; configs[3] shape no --
     //       20.6 merged, 20.3 + 13.4 apart: there the merged launch overlaps its two roles)
     //    8  dy as K-slice partial sums wherever a consumer adds them up: the lower layer's k_gru_bwd_pre (any layer above an unfused
-    //       one), or for layer 0 the row-finishing workgroups of k_dense_grad2, i.e. with 16 (17.5 -> 7.0 us at configs[2])
+    //       one); for layer 0 the row-finishing workgroups of k_dense_grad2 (17.5 -> 7.0 us at configs[2]) or, with the merged k_update,
+    //       k_finish_rows as a small launch in front of it (configs[3] shape: 10.8 -> 5.0 + 4.2 us, step 170.3 -> 167.7)
     //    1  phase 1 as partial sums + k_gru_gate from D = 512 on (25.0 -> 18.3 + 4.5 us at configs[2]; D = 256: 13.9 -> 12.9 + 4.3, off)
     // K-slice lengths for A/B runs: G4R_P1_KS (<= 128), G4R_BB_KS.
     {
@@ -507,7 +508,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
                 }
             }
             // dy: enough slices of >= 128 (multiples of 32) to give every CU a workgroup, <= 16 (what the consumers add up in one round trip)
-            const bool consumer = (l == 0) ? (!automask || wdense) : !fused_bwd(d, l - 1);      // (layer 0: k_finish_rows -- by default only next to k_dense_grad2)
+            const bool consumer = (l == 0) ? true : !fused_bwd(d, l - 1);      // (layer 0: the row-finishing workgroups of k_dense_grad2, or k_finish_rows in front of the merged k_update)
             if ((mask & 8) && consumer) {
                 const int K = 3 * D, tiles = cdiv(IN, 64) * nrt, forced = env_int("G4R_BB_KS", 0);
                 int n = std::min(std::max(1, cdiv(m->n_cu, std::max(tiles, 1))), std::max(1, K / 128));
@@ -869,9 +870,7 @@ static inline int row_chunks(const DevModel& d) { const int w = std::max(d.Dtop,
 // (wide layers: the dense gradients run as 64 x 64 tiles in a launch of their own, k_dense_grad2, ahead of the sparse row update)
 static inline bool merged_update(const g4r_model* m) { return !m->dm.generic && !no_merge_tail() && row_chunks(m->dm) <= 2 && !m->wide_dense; }
 // part: 0 = the whole step; 1 = head (everything up to the dense gradients); 2 = tail (all-reduce, dense apply, sparse update)
-// capturing: called from a stream capture (ensure_graph): independent launches may then sit on a BRANCH of the graph (fork / join through
-// events on comm_stream) -- in eager mode the two cross-stream dependencies would cost more than the overlap gives
-static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0, bool capturing = false) {
+static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     DevModel& d = m->dm;
     const int L = d.n_layers, B = d.B;
     hipStream_t s = m->stream;
@@ -910,7 +909,6 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0, boo
     const DevModel* dmp = (const DevModel*)m->d_dm;
     StepState* stp = (StepState*)d.st;
     bool merged = false;      // the sparse update already ran inside k_update
-    bool forked = false;      // the dense-gradient tiles run on a graph branch (comm_stream): joined behind the sparse update
     if (part != 2) {
     for (int l = 0; l < L; ++l) {
         if (fused_fwd(d, l)) {
@@ -1010,22 +1008,15 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0, boo
         end();
         if (d.apply_dense_inplace || part == 1) { HIPCHK(hipGetLastError()); return 0; }
     } else {
-    // wide layers on one GPU: the dense-gradient tiles (+ fused dense Adagrad) share nothing with the sparse rows -- inside the step graph
-    // they run on a branch next to k_finish_rows + k_sparse_update and join in front of the next step (G4R_FORK=0: one after the other)
-    static const bool want_fork = env_int("G4R_FORK", 1) != 0;
-    forked = capturing && want_fork && m->wide_dense && d.apply_dense_inplace && !recs && !trace && part == 0;
-    hipStream_t ds = s;
-    if (forked) { HIPCHK(hipEventRecord(m->ev_fork, s)); HIPCHK(hipStreamWaitEvent(m->comm_stream, m->ev_fork, 0)); ds = m->comm_stream; }
+    // (the dense-gradient tiles on a BRANCH of the step graph next to the sparse rows -- they share nothing -- were measured: the
+    // fork / join costs more than the overlap gives, 126.6 -> 139.8 us per step at configs[2]; profiles/r05_experiments.md #8)
     begin(KN_DENSE);
-    if (m->wide_dense) LK(k_dense_grad2, dim3(m->ntiles64), dim3(256), SMEM_T2K, ds, dmp, stp, (const DenseTile*)m->d_tiles64, m->ntiles64);
-    else LK(k_dense_grad<32>, dim3(m->ntiles), dim3(GT_NTH_FEW), SMEM_TN, s, dmp, stp, (const DenseTile*)m->d_tiles);
-    end();
-    if (forked) HIPCHK(hipEventRecord(m->ev_join, m->comm_stream));
-    if (d.bbn[0] > 0) {      // dy of layer 0 arrived as K-slice partial sums: the input rows' Adagrad pieces, ahead of the sparse row update
-        begin(KN_FINISH);
-        LK(k_finish_rows, dim3(cdiv((long long)B * (d.IN[0] / 4), 256)), dim3(256), 0, s, dmp, stp);
-        end();
+    if (m->wide_dense) LK(k_dense_grad2, dim3(m->ntiles64 + (d.bbn[0] > 0 ? cdiv((long long)B * (d.IN[0] / 4), 256) : 0)), dim3(256), SMEM_T2K, s, dmp, stp, (const DenseTile*)m->d_tiles64, m->ntiles64);
+    else {
+        if (d.bbn[0] > 0) { LK(k_finish_rows, dim3(cdiv((long long)B * (d.IN[0] / 4), 256)), dim3(256), 0, s, dmp, stp); }
+        LK(k_dense_grad<32>, dim3(m->ntiles), dim3(GT_NTH_FEW), SMEM_TN, s, dmp, stp, (const DenseTile*)m->d_tiles);
     }
+    end();
     }
     }
     if (part == 1) { HIPCHK(hipGetLastError()); return 0; }
@@ -1101,7 +1092,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0, boo
 #undef G4R_LK_SPARSE
     }
     end();
-    if (overlap || forked) HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0));
+    if (overlap) HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0));
 #undef begin
 #undef LK
     HIPCHK(hipGetLastError());
@@ -1152,7 +1143,7 @@ static int ensure_graph(g4r_model* m) {
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(m->stream, rccl_in_graph ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
     int rc = 0;
-    for (int i = 0; i < G4R_GRAPH_STEPS && !rc; ++i) rc = launch_step(m, nullptr, 0, true);
+    for (int i = 0; i < G4R_GRAPH_STEPS && !rc; ++i) rc = launch_step(m, nullptr);
     hipError_t e = hipStreamEndCapture(m->stream, &graph);
     if (rc || e != hipSuccess || !graph) {
         if (graph) (void)hipGraphDestroy(graph);
@@ -1170,7 +1161,7 @@ static int ensure_graph(g4r_model* m) {
         hipGraph_t g2 = nullptr;
         if (hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             int rc2 = 0;
-            for (int i = 0; i < G4R_GRAPH_STEPS_SMALL && !rc2; ++i) rc2 = launch_step(m, nullptr, 0, true);
+            for (int i = 0; i < G4R_GRAPH_STEPS_SMALL && !rc2; ++i) rc2 = launch_step(m, nullptr);
             hipError_t e2 = hipStreamEndCapture(m->stream, &g2);
             if (!rc2 && e2 == hipSuccess && g2 && hipGraphInstantiate(&m->gexec_small, g2, nullptr, nullptr, 0) != hipSuccess) m->gexec_small = nullptr;
             if (g2) (void)hipGraphDestroy(g2);

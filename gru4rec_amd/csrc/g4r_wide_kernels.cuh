@@ -3,8 +3,8 @@
 // product anyway adds up behind the kernel boundary:
 //   k_gru_p1s   V = [y | H] [Wx ; 0 | Wrz] as partial sums vp[slice][B][3D]      -> k_gru_gate adds them, bias, r / Hr / z
 //   k_gru_bwd_bw dy = dV Wx^T as partial sums dyp[slice][B][IN]                   -> the lower layer's k_gru_bwd_pre, or (layer 0) k_finish_rows
-//   k_dense_grad2 the dense gradients on 64 x 64 tiles (contraction over the batch: nothing to slice), as a launch of its own that runs
-//                 on a BRANCH of the step graph next to k_finish_rows + the sparse row update (they share nothing)
+//   k_dense_grad2 the dense gradients on 64 x 64 tiles (contraction over the batch: nothing to slice) as a launch of its own, with the
+//                 row-finishing workgroups of layer 0 behind its tiles
 //
 // Why (BASELINE configs[2]: B = 240, D = 512; profiles/r04_*, profiles/r05_experiments.md): a wide layer's products are a few dozen
 // 64 x 64 tiles -- the round-1 kernels keep the whole K range in one workgroup (k_gru_bwd_b: 128 workgroups of 393 KB of operands,
@@ -190,15 +190,13 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_bw(const DevModel* __restric
     gemm_tile3<3, 32, true>(m0, n0, Klen, arow, brow, m.zrow, NoPre(), epi, smem);
 }
 
-// The layer-0 input rows when k_gru_bwd_bw left dy as K-slice partial sums (DevModel::bbn[0] > 0): one quad of dy per thread -- slices
-// added in slice order, embedding-dropout mask, per-occurrence Adagrad pieces dSx / dAx (or the accumulator in place for an item that
-// occurs once: see k_gru_bwd_b) -- ahead of the sparse row update that consumes them (same stream; the dense-gradient tiles run
-// next to both on a branch of the step graph).
-__global__ __launch_bounds__(256) void k_finish_rows(const DevModel* __restrict__ mp, StepState* st) {
-    const DevModel& m = *mp;
-    const StepCtx c = load_ctx(st);
+// The layer-0 input rows when k_gru_bwd_bw left dy as K-slice partial sums (DevModel::bbn[0] > 0): one quad of dy per thread (element e of
+// the [B][IN / 4] quads) -- slices added in slice order, embedding-dropout mask, per-occurrence Adagrad pieces dSx / dAx (or the
+// accumulator in place for an item that occurs once: see k_gru_bwd_b) -- ahead of the sparse row update that consumes them: as extra
+// workgroups of k_dense_grad2 where that launch exists (no launch of its own: +2.8 us at configs[2] as one), else as k_finish_rows in
+// front of the merged k_update.
+__device__ __forceinline__ void finish_rows(const DevModel& m, const StepCtx& c, int e) {
     const int IN = m.IN[0], nq = IN >> 2, nsl = m.bbn[0], B = m.B;
-    const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
     const int row = e / nq, c4 = 4 * (e - row * nq);
     if (row >= c.M) return;
     const int item = m.occ_idx[row];
@@ -228,6 +226,9 @@ __global__ __launch_bounds__(256) void k_finish_rows(const DevModel* __restrict_
     if (!generic && cnt1 == 1 && item >= 0) st4(accT + (size_t)item * IN + c4, an);
     else st4(m.dAx + o, an);
 }
+__global__ __launch_bounds__(256) void k_finish_rows(const DevModel* __restrict__ mp, StepState* st) {
+    finish_rows(*mp, load_ctx(st), (int)blockIdx.x * 256 + (int)threadIdx.x);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Dense GRU gradients on 64 x 64 tiles (contraction over the batch: both operands K-major -> gemm_tile2k):
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_grad2(const DevModel* __restri
     const DevModel& m = *mp;
     const GAS DenseTile* tiles = (const GAS DenseTile*)tiles_;
     const StepCtx c = load_ctx(st);
+    if ((int)blockIdx.x >= ntiles) { finish_rows(m, c, ((int)blockIdx.x - ntiles) * 256 + (int)threadIdx.x); return; }      // row-finishing workgroups behind the tiles
     const DenseTile tl = tiles[G4R_XCD_TILE(blockIdx.x, ntiles)];
     const int M = c.M, tid = threadIdx.x;
     const float lr = m.lr, momc = m.mom, lmbd = m.lmbd;

@@ -101,10 +101,10 @@ def test_each_wide_kernel_against_the_kernel_it_replaces(mask):
 
 
 def test_default_policy_by_shape():
-    """BASELINE configs[3]'s shape (D = 256, 2 B + n_sample = 9216 rows): the merged k_update stays, nothing of layer 0 is sliced;
-    a wide layer above an unfused one has its dy sliced whatever the update launch."""
+    """BASELINE configs[3]'s shape (D = 256, 2 B + n_sample = 9216 rows): the merged k_update stays (no k_dense_grad2, no k_gru_p1s below
+    D = 512); dy is sliced at every wide layer -- layer 0's slices are added up by k_finish_rows in front of k_update."""
     o, m = make_pair(3000, 512, 8192, store_rows=2, loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(256,), learning_rate=0.1)
-    assert int(m.get_debug('wide_mask', 1)[0]) == 0
+    assert int(m.get_debug('wide_mask', 1)[0]) == 8
     m.close()
     o, m = make_pair(3000, 512, 8192, store_rows=2, loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(256, 256), learning_rate=0.1)
     assert int(m.get_debug('wide_mask', 1)[0]) == 8
