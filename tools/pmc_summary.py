@@ -19,7 +19,7 @@ def mean_by_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] == counter:
             acc[r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0]].append(float(r['Counter_Value']))
-    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items() if k.startswith('k_') and len(v) >= 20}
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items() if k.startswith('k_') and len(v) >= 5}
 
 
 def main():
