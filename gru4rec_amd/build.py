@@ -83,6 +83,22 @@ def build_dir(OUT):
     return os.path.join(HERE, '_build', os.path.splitext(os.path.basename(OUT))[0])
 
 
+def kernels_without_device_code(lib, device_kernels):
+    """Launch stubs of the host code (`__device_stub__<kernel>` symbols) whose kernel is not among the device listing's: hipcc instantiates a
+    __global__ template on the device side only where an explicit instantiation asks for it, the host side wherever a launch names it --
+    such a library links, loads and fails at the first launch of that kernel (`invalid device function`)."""
+    import re
+    blob = open(lib, 'rb').read()
+    out = []
+    for mt in set(re.findall(rb'_Z(\d+)__device_stub__(\w+)', blob)):
+        n = int(mt[0]) - len('__device_stub__')
+        name, rest = mt[1][:n].decode(), mt[1][n:].decode()
+        sym = '_Z%d%s%s' % (n, name, rest)
+        if sym not in device_kernels:
+            out.append(sym)
+    return sorted(out)
+
+
 def _device(OUT, defs, verbose, audit=True, flags=()):
     """hipcc -> OUT.  The device listing hipcc assembles into the library (-save-temps) is kept under _build/ and AUDITED
     (isa_audit.audit): a library whose code names the destination register of a hand-counted asm load before the wait that
@@ -118,6 +134,13 @@ def _device(OUT, defs, verbose, audit=True, flags=()):
         if not (junk.endswith('gfx950.s') or junk.endswith('resources.json') or junk.endswith('.so')):
             os.remove(junk)
     built = os.path.join(tmp, os.path.basename(OUT))
+    missing = kernels_without_device_code(built, isa_audit.resources(asm))
+    if missing:
+        os.remove(built)
+        if os.path.exists(OUT):
+            os.remove(OUT)
+        raise AuditError('the host code launches %d kernel(s) the device code does not hold (a __global__ template is only emitted for an '
+                         'explicit instantiation: g4r_eval_kernels.cuh), first: %s -- library NOT installed' % (len(missing), missing[0]))
     if findings and audit:
         os.remove(built)
         if os.path.exists(OUT):

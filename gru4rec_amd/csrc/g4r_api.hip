@@ -59,6 +59,7 @@ struct g4r_model {
     DevModel dm;                 // host master copy of the device-resident model descriptor
     DevModel* d_dm = nullptr;    // what the kernels read (passed by pointer: 8-byte kernarg)
     int n_cu = 256;              // compute units of the device (tile-count heuristics)
+    int p2_geo_env = -1, ba_geo_env = -1;      // G4R_P2_GEO / G4R_BA_GEO at g4r_create (-1: deep_geometry's policy)
     hipStream_t stream = nullptr;
     hipStream_t comm_stream = nullptr;           // all-reduce + dense Adagrad next to the sparse update (nranks > 1)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -166,6 +167,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 static constexpr auto k_score_store = k_score_all<32, false>;     // scores -> memory
 static constexpr auto k_score_count = k_score_all<32, true>;      // scores compared with the row's target on the fly
 
+static inline int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 // dynamic LDS of the tile-GEMM kernels (g4r_gemm.cuh)
 template <int BM, int BN, int BK, bool AKM, bool BNK>
 static constexpr size_t tile_smem() { return (size_t)TileCfg<BM, BN, BK, AKM, BNK>::SMEM_FLOATS * sizeof(float); }
@@ -191,6 +193,21 @@ static inline bool fused_fwd(const DevModel& d, int l) {
 static inline size_t smem_fused_bwd(int D) { return (size_t)((((BF_ROWS + 32) * (3 * D + 2) + D * (D + 2) + 32 + 3) & ~3) + 4 * 6 * 64) * sizeof(float); }
 static inline bool wide_layer(int D) { return D >= 256; }
 static const size_t SMEM_P1 = tile_smem<GT_BM, GT_BN, P1_BK, false, false>() + GT_BM * sizeof(int);
+// k_gru_p2 / k_gru_bwd_a (32 x 32 tiles over K = D): 4 waves and 128-deep chunks; where the launch leaves CUs idle and K is longer than
+// two such chunks, 8 waves (two wave groups that split every chunk's k range) and 256-deep chunks -- one workgroup per CU either way, half
+// the memory round trips and half the MFMA chain per tile.  Measured (round 5, us): B = 240, D = 512: k_gru_p2 9.7 -> 8.2, k_gru_bwd_a
+// 7.3 -> 6.2; B = 512, D = 256: 6.7 -> 6.4 / 4.5 -> 4.35 (left on the 4-wave form); 8 waves x 128 (9.2) and, for k_gru_bwd_a, 8 waves x
+// 512 = the whole K in one chunk (6.4) were no better.  G4R_P2_GEO / G4R_BA_GEO = 0 / 1 override (tests).
+static constexpr auto k_gru_p2_w4 = k_gru_p2<GT_NTH, GT_BK>;
+static constexpr auto k_gru_p2_w8d = k_gru_p2<512, 256>;
+static const size_t SMEM_P2_256 = tile_smem<GT_BM, GT_BN, 256, false, false>() + GT_BM * sizeof(int);
+static constexpr auto k_gru_bwd_a_w4 = k_gru_bwd_a<GT_NTH, GT_BK>;
+static constexpr auto k_gru_bwd_a_w8d = k_gru_bwd_a<512, 256>;
+static const size_t SMEM_BA_256 = tile_smem<GT_BM, GT_BN, 256, false, true>();
+static inline int deep_geometry(int forced, int n_cu, int D, int rows) {
+    if (forced >= 0) return forced != 0;
+    return D >= 384 && cdiv(D, GT_BN) * cdiv(rows, GT_BM) <= n_cu;
+}
 static const size_t SMEM_BB = tile_smem<GT_BM, GT_BN, BB_BK, false, true>() + GT_BM * sizeof(int);
 static constexpr auto k_score_fwd_k128 = k_score_fwd<GT_BN, GT_BK>;
 // long score rows: 64-deep K chunks (more resident workgroups).  Measured at B = 512, N = 8704, D = 256 (us): 64 x 32 tiles
@@ -210,7 +227,6 @@ static const size_t SMEM_SF64 = tile_smem<SF_BM, SFW_BN, SFW_BK, false, true>() 
 static constexpr auto k_score_bwd_n = k_score_bwd<32, GT_BK>;
 static constexpr auto k_score_bwd_w = k_score_bwd<64, 64>;
 static const size_t SMEM_SBW = std::max(tile_smem<64, 64, 64, true, false>(), tile_smem<64, 64, 64, false, false>());
-static inline int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static inline bool wide_scores(const DevModel& d) {
     const bool off = false;
     const int minB = 256, minN = 4096;
@@ -282,6 +298,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     g4r_model* m = new g4r_model();
     m->cfg = *cfg;
     m->n_cu = std::max(n_cu, 1);
+    m->p2_geo_env = env_int("G4R_P2_GEO", -1);
+    m->ba_geo_env = env_int("G4R_BA_GEO", -1);
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return fail("stream create"); }
     if (hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -558,7 +576,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     const int big = 156 * 1024;      // leaves room for the few bytes of static LDS some kernels use (__syncthreads_or)
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_p1_n32, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_p1_n64, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_gru_p2, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gru_p2_w4, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gru_p2_w8d, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_k128, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_k64, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_t2, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -568,7 +587,8 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_fwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd_w, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd2, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_a, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_a_w4, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_a_w8d, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_b, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_dense_grad<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_sparse_update<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -929,7 +949,11 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         else LK(k_gru_p1_n32, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1, s, dmp, stp, l, 1, l == 0 ? 1 : 0, nopa);
         end();
         begin(KN_GRU_P2);
-        LK(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH), SMEM_NN, s, dmp, stp, l, 1, nopa);
+        {
+            const dim3 g2(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM));
+            if (deep_geometry(m->p2_geo_env, m->n_cu, d.D[l], B)) LK(k_gru_p2_w8d, g2, dim3(512), SMEM_P2_256, s, dmp, stp, l, 1, nopa);
+            else LK(k_gru_p2_w4, g2, dim3(GT_NTH), SMEM_NN, s, dmp, stp, l, 1, nopa);
+        }
         end();
     }
     begin(KN_SCORE_FWD);
@@ -976,7 +1000,11 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         const g4r_model::WideGeo& G = m->wg[l];
         const int nrt64 = cdiv(B, 64);
         begin(KN_BWD_A);
-        LK(k_gru_bwd_a, dim3(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM)), dim3(GT_NTH), SMEM_NT, s, dmp, stp, l);
+        {
+            const dim3 ga(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM));
+            if (deep_geometry(m->ba_geo_env, m->n_cu, d.D[l], B)) LK(k_gru_bwd_a_w8d, ga, dim3(512), SMEM_BA_256, s, dmp, stp, l);
+            else LK(k_gru_bwd_a_w4, ga, dim3(GT_NTH), SMEM_NT, s, dmp, stp, l);
+        }
         end();
         begin(KN_BWD_B);
         if (l == 0 && d.embed_mode == G4R_EMBED_ONEHOT) LK(k_onehot_step, dim3(cdiv((long long)B * d.Ein, 4 * 256)), dim3(256), 0, s, dmp, stp);
@@ -1583,8 +1611,12 @@ static int predict_forward(g4r_model* m, const int* d_in_idx, int mrows, const i
         else
             hipLaunchKernelGGL(k_gru_p1_n32, dim3(cdiv(3 * d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(GT_NTH_FEW), SMEM_P1, m->stream,
                                (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, 0, pa);
-        hipLaunchKernelGGL(k_gru_p2, dim3(cdiv(d.D[l], GT_BN), cdiv(mrows, GT_BM)), dim3(GT_NTH), SMEM_NN, m->stream,
-                           (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, pa);
+        {
+            const dim3 g2(cdiv(d.D[l], GT_BN), cdiv(mrows, GT_BM));
+            if (deep_geometry(m->p2_geo_env, m->n_cu, d.D[l], mrows))
+                hipLaunchKernelGGL(k_gru_p2_w8d, g2, dim3(512), SMEM_P2_256, m->stream, (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, pa);
+            else hipLaunchKernelGGL(k_gru_p2_w4, g2, dim3(GT_NTH), SMEM_NN, m->stream, (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, pa);
+        }
     }
     m->ppar ^= 1;
     const bool sm = (d.final_act == G4R_ACT_SOFTMAX || d.final_act == G4R_ACT_SOFTMAX_LOGIT);   // gru4rec.py:499-500
@@ -2281,6 +2313,10 @@ int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
         int mk = m->wide_dense ? 16 : 0;
         for (int l = 0; l < d.n_layers; ++l) mk |= m->wg[l].use;
         host[0] = (float)mk; return 0;
+    }
+    else if (s == "deep_geo") {      // layer 0 at the training batch: 1 = k_gru_p2 on 8 waves x 256-deep chunks, 2 = k_gru_bwd_a (deep_geometry)
+        if (count < 1) return fail("count");
+        host[0] = (float)(deep_geometry(m->p2_geo_env, m->n_cu, d.D[0], d.B) + 2 * deep_geometry(m->ba_geo_env, m->n_cu, d.D[0], d.B)); return 0;
     }
     else if (s == "ksplit") { if (count < 1) return fail("count"); host[0] = (float)d.ksplit; return 0; }
     else if (s == "dev_syncs") { if (count < 1) return fail("count"); host[0] = (float)m->n_dev_syncs; return 0; }

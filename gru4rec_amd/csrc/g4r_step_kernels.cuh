@@ -207,7 +207,10 @@ __global__ __launch_bounds__(GT_NTH_FEW) void k_gru_p1(const DevModel* __restric
 }
 
 // GRU phase 2: c = act(Hr * Wh + Vc) ; h = (1 - z) H + z c ; hidden dropout ; reset switch (gru4rec.py:474-479)
-__global__ __launch_bounds__(GT_NTH) void k_gru_p2(const DevModel* __restrict__ mp, StepState* st, int l, int train, GruFwdPredict pa) {
+// NTH / BK: 4 waves and 128-deep chunks where the launch fills the chip; 8 waves (two wave groups that split every chunk's k range) and
+// 256-deep chunks where it does not -- there the tile waits out one memory round trip per chunk and one MFMA chain per k-step.
+template <int NTH, int BK>
+__global__ __launch_bounds__(NTH) void k_gru_p2(const DevModel* __restrict__ mp, StepState* st, int l, int train, GruFwdPredict pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const int D = m.D[l];
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(GT_NTH) void k_gru_p2(const DevModel* __restrict__ 
             Hnext[o] = h;
         }
     };
-    gemm_tile<GT_BM, GT_BN, GT_BK, false, false, GT_NTH>(m0, n0, D, aload, bload, pre, epi, smem);
+    gemm_tile<GT_BM, GT_BN, BK, false, false, NTH>(m0, n0, D, aload, bload, pre, epi, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1145,7 +1148,9 @@ __global__ __launch_bounds__(256) void k_gru_bwd_pre(const DevModel* __restrict_
 }
 
 // dr' = (da Wh^T) * H * r (1 - r)  -> dV[:, D:2D]      (B provider reads Wh rows: B[k][n] = Wh[n][k])
-__global__ __launch_bounds__(GT_NTH) void k_gru_bwd_a(const DevModel* __restrict__ mp, StepState* st, int l) {
+// (NTH / BK as for k_gru_p2)
+template <int NTH, int BK>
+__global__ __launch_bounds__(NTH) void k_gru_bwd_a(const DevModel* __restrict__ mp, StepState* st, int l) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const StepCtx c = load_ctx(st);
@@ -1173,7 +1178,7 @@ __global__ __launch_bounds__(GT_NTH) void k_gru_bwd_a(const DevModel* __restrict
         if (row >= M || n >= D) return;
         dV[(size_t)row * D3 + D + n] = v * p.y * p.x * (1.f - p.x);
     };
-    gemm_tile<GT_BM, GT_BN, GT_BK, false, true, GT_NTH>(m0, n0, D, aload, bload, pre, epi, smem);
+    gemm_tile<GT_BM, GT_BN, BK, false, true, NTH>(m0, n0, D, aload, bload, pre, epi, smem);
 }
 
 // dy = dV Wx^T -> embedding-row gradient dSx (layer 0, through the embedding-dropout mask) or the lower layer's dh

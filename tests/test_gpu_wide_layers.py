@@ -100,6 +100,15 @@ def test_each_wide_kernel_against_the_kernel_it_replaces(mask):
         assert np.abs(a - b).max() <= 2e-4 * scale, (nm, float(np.abs(a - b).max()), float(scale))
 
 
+def test_deep_chunk_policy_by_shape():
+    """8 waves x 256-deep chunks for k_gru_p2 / k_gru_bwd_a from 384 units on while the tiles leave CUs idle (BASELINE configs[2]: 512 units,
+    B = 240); BASELINE configs[3] (256 units) and a batch of 1024 rows at 512 units (512 tiles) stay on 4 waves x 128."""
+    for (B, D), want in (((240, 512), 3), ((512, 256), 0), ((1024, 512), 0)):
+        o, m = make_pair(3000, B, 1024, store_rows=2, loss='bpr-max', final_act='elu-0.5', constrained_embedding=True, layers=(D,), learning_rate=0.1)
+        assert int(m.get_debug('deep_geo', 1)[0]) == want, (B, D)
+        m.close()
+
+
 def test_default_policy_by_shape():
     """BASELINE configs[3]'s shape (D = 256, 2 B + n_sample = 9216 rows): the merged k_update stays (no k_dense_grad2, no k_gru_p1s below
     D = 512); dy is sliced at every wide layer -- layer 0's slices are added up by k_finish_rows in front of k_update."""
@@ -130,9 +139,8 @@ def test_slice_lengths(ks):
 
 
 def test_wide_graph_replay_is_bit_identical_to_eager():
-    """32 steps as two graph replays -- the dense-gradient tiles on a BRANCH of the graph next to k_finish_rows + the sparse row update --
-    against 32 eager steps (one launch after the other): identical bits in every loss and parameter (slices are added in slice order;
-    the two branches share no byte), and a second identical run reproduces the first."""
+    """32 steps as two graph replays against 32 eager steps (one launch after the other): identical bits in every loss and parameter
+    (slices are added in slice order, by whichever workgroup gets there), and a second identical run reproduces the first."""
     I, B, ns, T, kw = 4000, 240, 1024, 32, SHAPES['d512_b240_xe_logq_drop'][4]
     out = []
     for use_graph in (0, 1, 1):
@@ -147,3 +155,24 @@ def test_wide_graph_replay_is_bit_identical_to_eager():
     for other in out[1:]:
         for a, b in zip(out[0], other):
             np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize('geo', [0, 1])
+@pytest.mark.parametrize('name', ['d512_b240_xe_logq_drop', 'two_layers_256_320', 'd256_b96_bprmax'])
+def test_phase2_geometries(name, geo):
+    """k_gru_p2 / k_gru_bwd_a<threads, chunk depth> (G4R_P2_GEO / G4R_BA_GEO: 0 = 4 waves x 128, 1 = 8 waves x 256) at K = 512, 256, and
+    320 (whole chunks and partial ones) against the oracle: losses and every parameter."""
+    I, B, ns, T, kw = SHAPES[name]
+    with _env(G4R_P2_GEO=geo, G4R_BA_GEO=geo):
+        o, m = make_pair(I, B, ns, store_rows=T + 2, **kw)
+    assert int(m.get_debug('deep_geo', 1)[0]) == 3 * geo
+    plan = _plan(I, B, T, o, tail=True)
+    m.set_plan(plan)
+    want = [o.train_step(plan['in_idx'][t], plan['out_idx'][t], int(plan['M'][t]), plan['reset'][t]) for t in range(T)]
+    m.train_steps(0, T)
+    errs = []
+    report('--- phase-2 geometry %d at %s' % (geo, name))
+    close('loss curve', m.get_losses(0, T), np.array(want), atol=5e-6, rtol=5e-4, errs=errs)
+    compare_params(o, m, errs, 'p2geo%d-%s' % (geo, name), Mrows=int(plan['M'].min()))
+    m.close()
+    assert not errs, errs

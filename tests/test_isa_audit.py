@@ -97,3 +97,19 @@ def test_the_shipped_library_names_its_compiler_and_has_a_clean_audit_record():
         import json
         info = json.load(open(rec))
         assert info['audit_findings'] == [] and any('k_score_bwd2' in k for k in info['asm_register_loads'])
+
+
+def test_every_kernel_the_host_code_launches_has_device_code():
+    """A __global__ template the host code launches without an explicit instantiation links, loads and fails at its first launch;
+    build._device refuses such a library (kernels_without_device_code).  The shipped library: no such kernel; the check itself: a
+    kernel taken out of the device table is reported by its symbol."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from gru4rec_amd import _native, build
+    rec = os.path.join(build.build_dir(build.OUT), 'resources.json')
+    if not (os.path.exists(_native.LIB_PATH) and os.path.exists(rec)):
+        pytest.skip('library / build record not here')
+    import json
+    kernels = json.load(open(rec))['kernels']
+    assert build.kernels_without_device_code(_native.LIB_PATH, kernels) == []
+    victim = next(k for k in kernels if 'k_gru_p2' in k)
+    assert build.kernels_without_device_code(_native.LIB_PATH, {k: v for k, v in kernels.items() if k != victim}) == [victim]
