@@ -25,7 +25,7 @@
 #include <utility>
 #include <vector>
 
-void g4r_set_error(const char* fmt, ...);      // g4r_api.hip
+void g4r_set_error(const char* fmt, ...);      // g4r_host_model.hpp
 
 namespace {
 
