@@ -2368,7 +2368,10 @@ __global__ __launch_bounds__(SP_WAVES * 64, MAXCH == 1 ? 4 : 2) void k_sparse_up
     const float v1 = m.ap0, v3 = m.ap1, lr = m.lr, lmbd = m.lmbd, momc = m.mom, clip = m.gclip[0];
     const bool adagrad = (adapt == G4R_ADAPT_ADAGRAD);
     const int oSx = m.xoffSx, oSy = m.xoffSy, oSB = m.xoffSBy;
-    // row state
+    // row state.  LATE (rows of four quads per lane): what only the final rule reads -- parameter, second statistic, count, velocity --
+    // is requested behind the walk over the occurrences instead of in front of it: 64 registers less held across the walk (the
+    // variant had 85 spilled registers; these rows pay one more round trip, once per owned item)
+    constexpr bool LATE = MAXCH >= 4;
     float4 p0[MAXCH], a0[MAXCH], u0[MAXCH], c0[MAXCH], w0[MAXCH], S[MAXCH], Q[MAXCH], T1[MAXCH], gk[MAXCH];
     auto sq = [](float4 x) { return make_float4(x.x * x.x, x.y * x.y, x.z * x.z, x.w * x.w); };
     auto add4 = [](float4& a, float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
@@ -2398,8 +2401,8 @@ __global__ __launch_bounds__(SP_WAVES * 64, MAXCH == 1 ? 4 : 2) void k_sparse_up
 #pragma unroll
     for (int q = 0; q < MAXCH; ++q) {
         const size_t o = (size_t)max(item, 0) * W + 4 * min(col + 64 * q, nc4 - 1);      // (a wave without an occurrence reads row 0 and drops out below)
-        p0[q] = ld4(P + o); a0[q] = ld4(A + o);
-        u0[q] = A2 ? ld4(A2 + o) : z4; c0[q] = Cn ? ld4(Cn + o) : z4; w0[q] = mom ? ld4(V + o) : z4;
+        a0[q] = ld4(A + o);
+        if constexpr (!LATE) { p0[q] = ld4(P + o); u0[q] = A2 ? ld4(A2 + o) : z4; c0[q] = Cn ? ld4(Cn + o) : z4; w0[q] = mom ? ld4(V + o) : z4; }
         gk[q] = grow(min(k, R - 1), q);
         S[q] = z4; Q[q] = z4; T1[q] = z4;
     }
@@ -2505,7 +2508,7 @@ __global__ __launch_bounds__(SP_WAVES * 64, MAXCH == 1 ? 4 : 2) void k_sparse_up
             }
             // NB gradient rows per round trip: the sampler repeats the head of the catalogue 20-50 x per step, and the owner walks
             // its occurrences alone -- with 4 rows per trip the hottest item's 13 dependent trips set the launch's length
-            constexpr int NB = 4;      // (16 rows per trip at MAXCH = 1 cost 40 registers -> one workgroup per CU instead of two: the launch got slower)
+            constexpr int NB = LATE ? 2 : 4;      // (16 rows per trip at MAXCH = 1 cost 40 registers -> one workgroup per CU instead of two: the launch got slower)
             for (int i0 = 0; i0 < cnt; i0 += NB * RPI) {
                 float4 g[NB][MAXCH];
 #pragma unroll
@@ -2540,6 +2543,13 @@ __global__ __launch_bounds__(SP_WAVES * 64, MAXCH == 1 ? 4 : 2) void k_sparse_up
                 }
             };
             comb(S[0]); comb(Q[0]); comb(T1[0]); comb(Aadd[0]);
+        }
+    }
+    if constexpr (LATE) {
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) {
+            const size_t o = (size_t)item * W + 4 * min(col + 64 * q, nc4 - 1);
+            p0[q] = ld4(P + o); u0[q] = A2 ? ld4(A2 + o) : z4; c0[q] = Cn ? ld4(Cn + o) : z4; w0[q] = mom ? ld4(V + o) : z4;
         }
     }
 #pragma unroll
