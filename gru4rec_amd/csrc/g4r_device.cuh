@@ -354,6 +354,19 @@ __device__ __forceinline__ float act_fwd(int kind, float p0, float p1, float x) 
         default: return x;
     }
 }
+// act_fwd's values without a branch around the exponential of elu / selu (element loops of the loss kernel: both sides of that
+// branch run in nearly every wave, the branch only adds its bookkeeping); a NaN input still comes out as NaN
+__device__ __forceinline__ float act_fwd_sel(int kind, float p0, float p1, float x) {
+    if (kind == G4R_ACT_ELU || kind == G4R_ACT_SELU) {
+        const float xm = x > 0.0f ? 0.0f : x;
+        float t = (kind == G4R_ACT_ELU) ? p0 * (fexp(xm) - 1.0f) : p0 * (p1 * (fexp(xm) - 1.0f));
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(t));      // hipcc otherwise turns the select below back into a branch around the exponential
+#endif
+        return x >= 0.0f ? (kind == G4R_ACT_ELU ? fabsf(x) : p0 * fabsf(x)) : neg_branch(t);
+    }
+    return act_fwd(kind, p0, p1, x);
+}
 // derivative expressed through the OUTPUT y (for the piecewise activations the sign BIT of y tells the branch, see above)
 __device__ __forceinline__ float act_bwd_from_out(int kind, float p0, float p1, float y) {
     const bool pos = !(__builtin_bit_cast(unsigned, y) >> 31);

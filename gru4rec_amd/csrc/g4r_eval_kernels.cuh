@@ -243,14 +243,22 @@ template __global__ void k_sparse_update<2, false>(const DevModel*, StepState*, 
 template __global__ void k_sparse_update<2, true>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update_generic<1>(const DevModel*, StepState*, int, int);
 template __global__ void k_sparse_update_generic<2>(const DevModel*, StepState*, int, int);
-template __global__ void k_loss_rows<false, 0>(const DevModel*, StepState*);
-template __global__ void k_loss_rows<false, 1>(const DevModel*, StepState*);
-template __global__ void k_loss_rows<false, 2>(const DevModel*, StepState*);
-template __global__ void k_loss_rows<false, 3>(const DevModel*, StepState*);
-template __global__ void k_loss_rows<true, 0>(const DevModel*, StepState*);
-template __global__ void k_loss_rows<true, 1>(const DevModel*, StepState*);
-template __global__ void k_loss_rows<true, 2>(const DevModel*, StepState*);
-template __global__ void k_loss_rows<true, 3>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<false, 0, 1>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<false, 0, 4>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<false, 1, 1>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<false, 1, 4>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<false, 2, 1>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<false, 2, 4>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<false, 3, 1>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<false, 3, 4>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<true, 0, 1>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<true, 0, 4>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<true, 1, 1>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<true, 1, 4>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<true, 2, 1>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<true, 2, 4>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<true, 3, 1>(const DevModel*, StepState*);
+template __global__ void k_loss_rows<true, 3, 4>(const DevModel*, StepState*);
 template __global__ void k_sparse_update<4, false>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update<4, true>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update_generic<4>(const DevModel*, StepState*, int, int);

@@ -318,6 +318,9 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     m->smem_loss = (size_t)(2 * d.ldSc + 18 * LOSS_NW) * sizeof(float);
     m->loss_long = m->smem_loss > (size_t)(156 * 1024);      // one row copy in LDS, the other in the score row itself (k_loss_rows<true>)
     if (m->loss_long) m->smem_loss = (size_t)(d.ldSc + 18 * LOSS_NW) * sizeof(float);
+    // four columns per thread and trip from 4 columns per thread on (measured, round 5: B = 512 with 8192 negatives 15.2 -> 13.0 us;
+    // 2176 / 2528 columns: 4.7 / 4.4 us either way)
+    m->loss_quads = env_int("G4R_LOSS_V", d.ldSc >= 4 * LOSS_T ? 4 : 1) == 4;
     const int big = 156 * 1024;      // leaves room for the few bytes of static LDS some kernels use (__syncthreads_or)
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_p1_n32, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_p1_n64, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -351,7 +354,9 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_update<2, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_store, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-#define G4R_LOSS_ATTR(L, S) HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<L, S>, hipFuncAttributeMaxDynamicSharedMemorySize, big))
+#define G4R_LOSS_ATTR(L, S)                                                                                                    \
+    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<L, S, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));           \
+    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<L, S, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, big))
     G4R_LOSS_ATTR(false, 0); G4R_LOSS_ATTR(false, 1); G4R_LOSS_ATTR(false, 2); G4R_LOSS_ATTR(false, 3);
     G4R_LOSS_ATTR(true, 0); G4R_LOSS_ATTR(true, 1); G4R_LOSS_ATTR(true, 2); G4R_LOSS_ATTR(true, 3);
 #undef G4R_LOSS_ATTR

@@ -60,6 +60,7 @@ struct g4r_model {
     int ntiles = 0, nblkA = 0, nblkB = 0, ndtA = 0, ndtB = 0, nrtB = 0, nblk_occ = 0, nblk_occ_g = 0;
     size_t smem_score = 0, smem_loss = 0, smem_sparse = 0;
     bool loss_long = false;      // k_loss_rows<true>: score rows too long for two LDS copies
+    bool loss_quads = false;     // k_loss_rows<., ., 4>: four columns per thread and trip (long score rows; G4R_LOSS_V=1/4 overrides)
     // wide layers (g4r_wide_kernels.cuh): per layer which kernels run (bit 1 k_gru_p1s + k_gru_gate, 8 k_gru_bwd_bw) and their K-slice
     // geometry; wide_dense: the 64 x 64 dense-gradient tiles (k_dense_grad2, mask bit 16) as a launch of their own for the whole model
     struct WideGeo { int use = 0, ny = 1, nh = 1, kys = 0, khs = 0, bbn = 1, bbk = 0; };

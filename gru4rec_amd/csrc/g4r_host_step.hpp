@@ -86,14 +86,15 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         const int spec = (d.final_act == G4R_ACT_ELU && d.loss == G4R_LOSS_BPR_MAX) ? 1
                        : (d.final_act == G4R_ACT_SOFTMAX && d.loss == G4R_LOSS_XE) ? 2
                        : (d.final_act == G4R_ACT_ELU && d.loss == G4R_LOSS_TOP1_MAX) ? 3 : 0;
-#define G4R_LK_LOSS(L)                                                                              \
-        do {                                                                                        \
-            if (spec == 1) LK((k_loss_rows<L, 1>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);      \
-            else if (spec == 2) LK((k_loss_rows<L, 2>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp); \
-            else if (spec == 3) LK((k_loss_rows<L, 3>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp); \
-            else LK((k_loss_rows<L, 0>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);                \
+#define G4R_LK_LOSS(L, V)                                                                              \
+        do {                                                                                           \
+            if (spec == 1) LK((k_loss_rows<L, 1, V>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);      \
+            else if (spec == 2) LK((k_loss_rows<L, 2, V>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp); \
+            else if (spec == 3) LK((k_loss_rows<L, 3, V>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp); \
+            else LK((k_loss_rows<L, 0, V>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);                \
         } while (0)
-        if (m->loss_long) G4R_LK_LOSS(true); else G4R_LK_LOSS(false);
+        if (m->loss_long) { if (m->loss_quads) G4R_LK_LOSS(true, 4); else G4R_LK_LOSS(true, 1); }
+        else { if (m->loss_quads) G4R_LK_LOSS(false, 4); else G4R_LK_LOSS(false, 1); }
 #undef G4R_LK_LOSS
     }
     end();
