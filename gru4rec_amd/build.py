@@ -9,6 +9,7 @@ SRC_HOST = os.path.join(HERE, 'csrc', 'g4r_io.cpp')      # host-only translation
 OUT = os.path.join(HERE, 'libgru4rec_hip.so')
 DEPS = [os.path.join(HERE, 'csrc', f) for f in ('g4r_api.hip', 'g4r_device.cuh', 'g4r_gemm.cuh', 'g4r_step_kernels.cuh',
                                                  'g4r_eval_kernels.cuh', 'g4r_sync_kernels.cuh', 'g4r_micro_kernels.cuh', 'g4r_wide_kernels.cuh', 'g4r_io.cpp',
+                                                 'g4r_fwd_kernels.cuh', 'g4r_loss_kernel.cuh', 'g4r_bwd_kernels.cuh', 'g4r_update_kernels.cuh',
                                                  'g4r_host_model.hpp', 'g4r_host_create.hpp', 'g4r_host_plan.hpp', 'g4r_host_step.hpp', 'g4r_host_predict.hpp',
                                                  'g4r_host_comm.hpp', 'g4r_host_sync.hpp', 'g4r_host_debug.hpp')] + \
        [os.path.join(os.path.dirname(HERE), 'include', 'gru4rec_hip.h')]

@@ -1,4 +1,4 @@
-"""Deferred row updates (g4r_step_kernels.cuh: k_defer_scan / k_sparse_flush): a row whose item is not gathered again before the end of
+"""Deferred row updates (g4r_update_kernels.cuh: k_defer_scan / k_sparse_flush): a row whose item is not gathered again before the end of
 the current window of steps (one replay of the step graph) is applied by the window's flush launch instead of by its step's update
 launch.  The claim is EXACTNESS: same operands, same arithmetic, so every loss, parameter and accumulator has the same BITS as with
 G4R_DEFER=0 -- across windows, call boundaries, sample-store refills inside a call, batch tails, catalogues small enough that most

@@ -141,7 +141,7 @@ def _check_replicas(tag, kw, oracles, models, want, I, T, loosen=4.0):
 
 @pytest.mark.parametrize('case', sorted(CASES))
 def test_reduce_form_against_the_oracle_run_as_replicas(case):
-    """sparse_exact = 3, the form GRU4Rec.sparse_exact = True ships (g4r_step_kernels.cuh: k_exact_occ / k_sparse_update_generic with
+    """sparse_exact = 3, the form GRU4Rec.sparse_exact = True ships (g4r_update_kernels.cuh: k_exact_occ / k_sparse_update_generic with
     xmode 3): all ranks share one row of negatives per step; the joint occurrence list is X | Y of rank 0, X | Y of rank 1, ..., then
     the negatives ONCE, their gradient rows (and bias gradients) summed over the ranks in rank order; every row x 1 / N; then the
     reference's duplicate rule (gru4rec.py:335-340,407-431) over that list, identically on every replica; dense gradients averaged.
