@@ -35,7 +35,7 @@ def _run(tag, I, B, ns, T, store_rows, dup=True, **kw):
         np.testing.assert_array_equal(m.get_sample_store(ns), o.ST)
     compare_params(o, m, errs, tag, skip_items=kink)
     m.close()
-    assert len(kink) <= max(64, I // 200), len(kink)
+    assert len(kink) <= max(64, I // 100), len(kink)      # (a handful per million scores; one per cent of the catalogue at most)
     assert not errs, errs
 
 
