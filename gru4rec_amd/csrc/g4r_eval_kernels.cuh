@@ -251,13 +251,9 @@ template __global__ void k_loss_rows<false, 2, 1>(const DevModel*, StepState*);
 template __global__ void k_loss_rows<false, 2, 4>(const DevModel*, StepState*);
 template __global__ void k_loss_rows<false, 3, 1>(const DevModel*, StepState*);
 template __global__ void k_loss_rows<false, 3, 4>(const DevModel*, StepState*);
-template __global__ void k_loss_rows<true, 0, 1>(const DevModel*, StepState*);
 template __global__ void k_loss_rows<true, 0, 4>(const DevModel*, StepState*);
-template __global__ void k_loss_rows<true, 1, 1>(const DevModel*, StepState*);
 template __global__ void k_loss_rows<true, 1, 4>(const DevModel*, StepState*);
-template __global__ void k_loss_rows<true, 2, 1>(const DevModel*, StepState*);
 template __global__ void k_loss_rows<true, 2, 4>(const DevModel*, StepState*);
-template __global__ void k_loss_rows<true, 3, 1>(const DevModel*, StepState*);
 template __global__ void k_loss_rows<true, 3, 4>(const DevModel*, StepState*);
 template __global__ void k_sparse_update<4, false>(const DevModel*, StepState*, int);
 template __global__ void k_sparse_update<4, true>(const DevModel*, StepState*, int);

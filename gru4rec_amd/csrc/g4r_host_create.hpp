@@ -355,7 +355,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_score_store, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_count, hipFuncAttributeMaxDynamicSharedMemorySize, big));
 #define G4R_LOSS_ATTR(L, S)                                                                                                    \
-    HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<L, S, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));           \
+    if (!L) HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<false, S, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big)); \
     HIPCHK(hipFuncSetAttribute((const void*)k_loss_rows<L, S, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, big))
     G4R_LOSS_ATTR(false, 0); G4R_LOSS_ATTR(false, 1); G4R_LOSS_ATTR(false, 2); G4R_LOSS_ATTR(false, 3);
     G4R_LOSS_ATTR(true, 0); G4R_LOSS_ATTR(true, 1); G4R_LOSS_ATTR(true, 2); G4R_LOSS_ATTR(true, 3);

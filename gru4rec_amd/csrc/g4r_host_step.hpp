@@ -93,7 +93,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
             else if (spec == 3) LK((k_loss_rows<L, 3, V>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp); \
             else LK((k_loss_rows<L, 0, V>), dim3(B), dim3(LOSS_T), m->smem_loss, s, dmp, stp);                \
         } while (0)
-        if (m->loss_long) { if (m->loss_quads) G4R_LK_LOSS(true, 4); else G4R_LK_LOSS(true, 1); }
+        if (m->loss_long) G4R_LK_LOSS(true, 4);      // (rows that long always take four columns per thread)
         else { if (m->loss_quads) G4R_LK_LOSS(false, 4); else G4R_LK_LOSS(false, 1); }
 #undef G4R_LK_LOSS
     }
