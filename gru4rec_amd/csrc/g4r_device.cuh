@@ -137,7 +137,7 @@ struct DevModel {
     GP(int) col_item;  // [ldSc] item of each score column, -1 = inactive
     // inputs of the NEXT step, staged at fixed addresses by the bookkeeping block of the update kernel (and by k_set_state /
     // after a sample-store refill), so that the first kernels of a step load them next to the step state instead of behind it
-    GP(int) cur_in;    // [B]    in_idx row of the step about to run
+    GP(int) cur_in;    // [2 B]  in_idx row of the step about to run | its reset flags (one int per row)
     GP(int) cur_col;   // [ldSc] item of every score column of the step about to run (targets | -1 | samples | -1)
     // [tables][n_items][4]: (last occurrence + 1, R - first occurrence, count, 0) of every item touched this step, written
     // with atomics by the kernels that publish occ_idx and zeroed again by the row's owner in k_sparse_update
@@ -180,6 +180,8 @@ struct DevModel {
     GP(int) dcand;       // [slots][dRcap] 1: occurrence k of that step is its item's last use inside the window (k_defer_scan)
     GP(int) dlist;       // [slots][dRcap] item of an occurrence whose row update is pending (written by its owner wave), else -1
     GP(unsigned) dstat;  // [1024][2] rows / bias entries applied by flush launches, per workgroup id mod 1024 (statistics)
+    // narrow layers (g4r_lean_kernels.cuh): dr' = da Wh^T leaves k_gru_da as ceil(D / 16) K-slice partial planes drp[slice][B][D]; k_gru_dy adds them
+    GP(float) drp;
 };
 // step plane of global step g
 #define G4R_SLOT(m, g) ((size_t)((g) & (long long)(m).defer_mask))

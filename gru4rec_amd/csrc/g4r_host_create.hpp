@@ -15,6 +15,51 @@ const char* g4r_last_error(void) { return g_err.c_str(); }
 const char* g4r_version(void) { return "gru4rec_hip 0.4 (gfx950; hipcc " G4R_HIPCC_VERSION "; isa-audited)"; }
 int g4r_sizeof_config(void) { return (int)sizeof(g4r_config); }
 
+// argument blocks of the narrow-layer kernels (g4r_lean_kernels.cuh): everything they read from the model, from pointers that are final here
+static int build_lean_args(g4r_model* m) {
+    DevModel& d = m->dm;
+    const int L = d.n_layers;
+    std::vector<LeanV> av(L); std::vector<LeanH> ah(L); std::vector<LeanDa> aa(L); std::vector<LeanDy> ay(L);
+    bool any = false;
+    for (int l = 0; l < L; ++l) {
+        if (!lean_gru(d, l)) continue;
+        any = true;
+        const bool constrained = d.embed_mode == G4R_EMBED_CONSTRAINED;
+        LeanV& v = av[l]; memset(&v, 0, sizeof(v));
+        v.Wx = d.dense_p + d.offWx[l]; v.Wrz = d.dense_p + d.offWrz[l]; v.Bh = d.dense_p + d.offBh[l];
+        v.H0 = d.H[l][0]; v.H1 = d.H[l][1];
+        v.ysrc = (l == 0) ? (constrained ? d.Wy : d.E) : d.hd[l - 1];
+        v.cur_in = d.cur_in; v.Vc = d.Vc[l]; v.r = d.r[l]; v.Hr = d.Hr[l]; v.z = d.z[l]; v.yin0 = d.yin0;
+        v.occ_idx = d.occ_idx; v.occ_fl = d.occ_fl + 4 * (constrained ? (size_t)0 : (size_t)d.n_items);
+        v.st = d.st; v.seed = d.seed; v.B = d.B; v.D = d.D[l]; v.IN = d.IN[l]; v.R = d.R; v.first = (l == 0) ? 1 : 0; v.pub_fl = d.xmode == 0 ? 1 : 0;
+        v.drop_e = d.drop_e;
+        LeanH& h = ah[l]; memset(&h, 0, sizeof(h));
+        h.Wh = d.dense_p + d.offWh[l]; h.H0 = d.H[l][0]; h.H1 = d.H[l][1]; h.Hr = d.Hr[l]; h.Vc = d.Vc[l]; h.z = d.z[l];
+        h.cur_rst = d.cur_in + d.B; h.c = d.c[l]; h.hd = d.hd[l]; h.st = d.st; h.seed = d.seed; h.B = d.B; h.D = d.D[l];
+        h.hidden_act = d.hidden_act; h.stream = (int)(G4R_STREAM_DROP_HIDDEN + (unsigned)l); h.ha_p0 = d.ha_p0; h.ha_p1 = d.ha_p1; h.drop_h = d.drop_h;
+        LeanDa& q = aa[l]; memset(&q, 0, sizeof(q));
+        q.Wh = h.Wh; q.H0 = h.H0; q.H1 = h.H1; q.z = d.z[l]; q.c = d.c[l];
+        if (l == L - 1) { q.dsrc = d.dhpart; q.ks = d.ksplit; }
+        else if (d.bbn[l + 1] > 0) { q.dsrc = d.dyp; q.ks = d.bbn[l + 1]; }
+        else { q.dsrc = d.dyl[l]; q.ks = 1; }
+        q.dV = d.dV[l]; q.drp = d.drp; q.st = d.st; q.seed = d.seed; q.B = d.B; q.D = d.D[l]; q.hidden_act = d.hidden_act; q.stream = h.stream;
+        q.ha_p0 = d.ha_p0; q.ha_p1 = d.ha_p1; q.drop_h = d.drop_h;
+        LeanDy& y = ay[l]; memset(&y, 0, sizeof(y));
+        y.Wx = v.Wx; y.H0 = h.H0; y.H1 = h.H1; y.r = d.r[l]; y.drp = d.drp; y.dV = d.dV[l]; y.occ_idx = d.occ_idx; y.occ_fl = v.occ_fl;
+        y.accT = constrained ? d.accWy : d.accE; y.dSx = d.dSx; y.dAx = d.dAx; y.dylo = (l > 0) ? d.dyl[l - 1] : nullptr;
+        y.st = d.st; y.seed = d.seed; y.dSx_stride = d.dSx_stride; y.B = d.B; y.D = d.D[l]; y.IN = d.IN[l]; y.layer0 = (l == 0) ? 1 : 0;
+        y.generic = d.generic; y.defer_mask = d.defer_mask; y.lr = d.lr; y.drop_e = d.drop_e;
+    }
+    if (!any) return 0;
+    if (dalloc(m, &m->d_leanV, (size_t)L) || dalloc(m, &m->d_leanH, (size_t)L) || dalloc(m, &m->d_leanDa, (size_t)L) || dalloc(m, &m->d_leanDy, (size_t)L)) return -1;
+    HIPCHK(hipMemcpyAsync(m->d_leanV, av.data(), L * sizeof(LeanV), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_leanH, ah.data(), L * sizeof(LeanH), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_leanDa, aa.data(), L * sizeof(LeanDa), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_leanDy, ay.data(), L * sizeof(LeanDy), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
 int g4r_create(const g4r_config* cfg, g4r_model** out) {
     if (!cfg || !out) return fail("null argument");
     if (cfg->n_layers < 1 || cfg->n_layers > G4R_MAX_LAYERS) return fail("n_layers out of range");
@@ -121,6 +166,11 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         DA(d.dV[l], bd * 3); DA(d.dyl[l], bd); DA(d.Vc[l], bd);
     }
     DA(m->d_tmpH, (size_t)B * maxD);
+    {      // narrow layers: the K-slice partial planes of dr' (k_gru_da -> k_gru_dy)
+        size_t drp_floats = 0;
+        for (int l = 0; l < L; ++l) if (lean_gru(d, l)) drp_floats = std::max(drp_floats, (size_t)cdiv(d.D[l], 16) * B * d.D[l]);
+        if (drp_floats) DA(d.drp, drp_floats);
+    }
     DA(d.yin0, (size_t)B * std::max(d.IN[0], 4));
     DA(d.Sc, (size_t)B * d.ldSc);
     {
@@ -168,13 +218,13 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         for (auto& e : m->ev_df) if (hipEventCreate(&e) != hipSuccess) { g4r_destroy(m); return fail("event create"); }
     }
     DA(d.lossrow, B);
-    DA(d.col_item, d.ldSc); DA(d.cur_in, B); DA(d.cur_col, d.ldSc);
+    DA(d.col_item, d.ldSc); DA(d.cur_in, 2 * (size_t)B); DA(d.cur_col, d.ldSc);
     DA(d.occ_fl, (size_t)(cfg->embed_mode != G4R_EMBED_CONSTRAINED ? 2 : 1) * I * 4);
     DA(d.st, 1);
     // scoring backward geometry: role A tiles (n x d, one spare d column for dSBy), role B tiles (b x d x k-chunk)
     {
         // k_gru_bwd_fused sums the slabs next to everything else it loads: half as many, twice as deep (k_score_bwd +0.4 us at cfg2)
-        const int slabs_target = getenv("G4R_KSLABS") ? atoi(getenv("G4R_KSLABS")) : (fused_bwd(d, d.n_layers - 1) ? 9 : 17);
+        const int slabs_target = getenv("G4R_KSLABS") ? atoi(getenv("G4R_KSLABS")) : ((fused_bwd(d, d.n_layers - 1) || lean_gru(d, d.n_layers - 1)) ? 9 : 17);
         d.kch = GT_BK * std::max(1, (cdiv(d.ldSc, GT_BK) + slabs_target / 2) / slabs_target);      // ~17 slabs whatever the number of negatives
         if (score_bwd2(d) && !getenv("G4R_KSLABS")) {
             // k_score_bwd2: its 64 x 64 tiles cost microseconds of MFMA each and all of them are resident at once, so the launch
@@ -271,7 +321,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
                 }
             }
             // dy: enough slices of >= 128 (multiples of 32) to give every CU a workgroup, <= 16 (what the consumers add up in one round trip)
-            const bool consumer = (l == 0) ? true : !fused_bwd(d, l - 1);      // (layer 0: the row-finishing workgroups of k_dense_grad2, or k_finish_rows in front of the merged k_update)
+            const bool consumer = (l == 0) ? true : (!fused_bwd(d, l - 1) || lean_gru(d, l - 1));      // (layer 0: the row-finishing workgroups of k_dense_grad2, or k_finish_rows in front of the merged k_update)
             if ((mask & 8) && consumer) {
                 const int K = 3 * D, tiles = cdiv(IN, 64) * nrt, forced = env_int("G4R_BB_KS", 0);
                 int n = std::min(std::max(1, cdiv(m->n_cu, std::max(tiles, 1))), std::max(1, K / 128));
@@ -374,6 +424,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     if (getenv("G4R_CLK")) {
         if (dalloc(m, &d.dbgclk, 64 + 8 * (size_t)d.R) || dalloc(m, &d.dbgtile, 8 * (size_t)(4096 + 4096))) { g4r_destroy(m); return -1; }
     }
+    if (build_lean_args(m)) { g4r_destroy(m); return -1; }
     if (dalloc(m, &m->d_dm, 1) || sync_dm(m)) { g4r_destroy(m); return -1; }
     *out = m;
     return 0;

@@ -25,10 +25,10 @@ void g4r_set_error(const char* fmt, ...) {
     } while (0)
 
 enum { KN_GRU_P1 = 0, KN_GRU_P2, KN_SCORE_FWD, KN_LOSS, KN_SCORE_BWD, KN_BWD_PRE, KN_BWD_A, KN_BWD_B, KN_DENSE, KN_ALLREDUCE,
-       KN_DENSE_APPLY, KN_SPARSE, KN_UPDATE, KN_BWD_FUSED, KN_FWD_FUSED, KN_GATE, KN_FLUSH, KN_SCAN, KN_FINISH, KN_COUNT };
+       KN_DENSE_APPLY, KN_SPARSE, KN_UPDATE, KN_BWD_FUSED, KN_FWD_FUSED, KN_GATE, KN_FLUSH, KN_SCAN, KN_FINISH, KN_GRU_V, KN_GRU_H, KN_GRU_DA, KN_GRU_DY, KN_COUNT };
 static const char* KN_NAMES[KN_COUNT] = {"k_gru_p1", "k_gru_p2", "k_score_fwd", "k_loss_rows", "k_score_bwd", "k_gru_bwd_pre",
                                          "k_gru_bwd_a", "k_gru_bwd_b", "k_dense_grad", "rccl_allreduce", "k_dense_apply",
-                                         "k_sparse_update", "k_update", "k_gru_bwd", "k_gru_fwd", "k_gru_gate", "k_sparse_flush", "k_defer_scan", "k_finish_rows"};
+                                         "k_sparse_update", "k_update", "k_gru_bwd", "k_gru_fwd", "k_gru_gate", "k_sparse_flush", "k_defer_scan", "k_finish_rows", "k_gru_v", "k_gru_h", "k_gru_da", "k_gru_dy"};
 
 struct EvRec { int kn; hipEvent_t a, b; };
 
@@ -72,6 +72,7 @@ struct g4r_model {
     int ntiles64 = 0;
     float* d_tmpH = nullptr;
     // graph
+    LeanV* d_leanV = nullptr; LeanH* d_leanH = nullptr; LeanDa* d_leanDa = nullptr; LeanDy* d_leanDy = nullptr;      // [layers] argument blocks (g4r_lean_kernels.cuh)
     hipGraphExec_t gexec = nullptr;
     hipGraphExec_t gexec_small = nullptr;        // single GPU: G4R_GRAPH_STEPS_SMALL steps, for what a run leaves after the big replays
     hipGraphExec_t gexec_head = nullptr;         // N > 1 fallback: one step's kernels up to the dense gradients, RCCL eager behind it
@@ -158,6 +159,13 @@ static const size_t SMEM_TN = tile_smem<GT_BM, GT_BN, GT_BK, true, false>();    
 static constexpr auto k_gru_p1_n32 = k_gru_p1<GT_BN, P1_BK>;
 static constexpr auto k_gru_p1_n64 = k_gru_p1<64, 256>;
 static const size_t SMEM_P1_N64 = tile_smem<GT_BM, 64, 256, false, false>() + GT_BM * sizeof(int);
+// GRU forward / backward of a narrow layer as the four lean launches of g4r_lean_kernels.cuh (k_gru_v, k_gru_h / k_gru_da, k_gru_dy): training,
+// in and D up to LN_MAXD.  G4R_NO_LEAN=1 (read once): the fused single-launch kernels of round 2 instead (A/B runs, tests of both forms).
+static inline bool lean_gru(const DevModel& d, int l) {
+    static const bool off = getenv("G4R_NO_LEAN") != nullptr;
+    return !off && d.D[l] <= LN_MAXD && d.IN[l] <= LN_MAXD && d.D[l] % 4 == 0 && d.IN[l] % 4 == 0 && d.IN[l] >= 4 &&
+           !(l == 0 && d.embed_mode == G4R_EMBED_ONEHOT);
+}
 // GRU backward in one launch (k_gru_bwd_fused) for layers whose operands fit its LDS plan
 static inline bool fused_bwd(const DevModel& d, int l) {
     static const bool off = getenv("G4R_NO_FUSED_BWD") != nullptr;

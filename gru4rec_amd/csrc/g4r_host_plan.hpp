@@ -181,7 +181,7 @@ int g4r_set_plan(g4r_model* m, const int32_t* in_idx, const int32_t* out_idx, co
     m->d_in = m->d_out = m->d_M = m->d_cmaps = nullptr; m->d_reset = nullptr;
     // one trailing row: the bookkeeping of the last step stages "step T" (never run)
     if (dalloc(m, &m->d_in, (size_t)(T + 1) * B, true) || dalloc(m, &m->d_out, (size_t)(T + 1) * B, true) ||
-        dalloc(m, &m->d_reset, (size_t)T * B, false) || dalloc(m, &m->d_M, (size_t)T + 1, true))
+        dalloc(m, &m->d_reset, (size_t)(T + 1) * B, true) || dalloc(m, &m->d_M, (size_t)T + 1, true))
         return -1;
     HIPCHK(hipMemcpyAsync(m->d_in, in_idx, (size_t)T * B * sizeof(int), hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemcpyAsync(m->d_out, out_idx, (size_t)T * B * sizeof(int), hipMemcpyHostToDevice, m->stream));

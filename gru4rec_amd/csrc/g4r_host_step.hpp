@@ -49,6 +49,18 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     bool merged = false;      // the sparse update already ran inside k_update
     if (part != 2) {
     for (int l = 0; l < L; ++l) {
+        if (lean_gru(d, l)) {
+            const int ntd = cdiv(d.D[l], 16), nrb = cdiv(B, 16);
+            begin(KN_GRU_V);
+            if (l > 0) LK((k_gru_v<false, false>), dim3(ntd, nrb, 3), dim3(512), 0, s, (const LeanV*)(m->d_leanV + l));
+            else if (d.drop_e > 0.f) LK((k_gru_v<true, true>), dim3(ntd, nrb, 3), dim3(512), 0, s, (const LeanV*)(m->d_leanV + l));
+            else LK((k_gru_v<true, false>), dim3(ntd, nrb, 3), dim3(512), 0, s, (const LeanV*)(m->d_leanV + l));
+            end();
+            begin(KN_GRU_H);
+            LK(k_gru_h, dim3(ntd, nrb), dim3(512), 0, s, (const LeanH*)(m->d_leanH + l));
+            end();
+            continue;
+        }
         if (fused_fwd(d, l)) {
             begin(KN_FWD_FUSED);
             LK(k_gru_fwd_fused, dim3(cdiv(d.D[l], 32), cdiv(B, FF_ROWS)), dim3(512), (size_t)fwd_fused_lds(d.IN[l], d.D[l]).total * sizeof(float), s, dmp, stp, l, l == 0 ? 1 : 0);
@@ -107,6 +119,16 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     else LK(k_score_bwd_n, dim3(m->nblkA + m->nblkB), dim3(GT_NTH), std::max(SMEM_TN, SMEM_NN) + (size_t)d.kch * sizeof(int), s, dmp, stp, m->nblkA, m->ndtA, m->ndtB, m->nrtB);
     end();
     for (int l = L - 1; l >= 0; --l) {
+        if (lean_gru(d, l)) {
+            const int nrb = cdiv(B, 16);
+            begin(KN_GRU_DA);
+            LK(k_gru_da, dim3(cdiv(d.D[l], 16), nrb), dim3(512), 0, s, (const LeanDa*)(m->d_leanDa + l));
+            end();
+            begin(KN_GRU_DY);
+            LK(k_gru_dy, dim3(cdiv(d.IN[l], 16), nrb), dim3(1024), 0, s, (const LeanDy*)(m->d_leanDy + l));
+            end();
+            continue;
+        }
         if (fused_bwd(d, l)) {
             begin(KN_BWD_FUSED);
             LK(k_gru_bwd_fused, dim3(cdiv(d.IN[l], 32), cdiv(B, BF_ROWS)), dim3(512), smem_fused_bwd(d.D[l]), s, dmp, stp, l);

@@ -1,0 +1,398 @@
+// g4r_lean_kernels.cuh -- part of g4r_step_kernels.cuh (included there, in order; needs its prelude).  Holds the GRU forward and backward of a
+// NARROW layer (in, D <= 128: BASELINE configs[0], [1], [4]) as four latency-lean launches: k_gru_v, k_gru_h (forward), k_gru_da, k_gru_dy (backward).
+//
+// Why four launches where round 2 had fused two (k_gru_fwd_fused / k_gru_bwd_fused).  Round 6 measured the pieces (tools/probes/chain_probe.hip,
+// profiles/r06_chain_probe.txt): a dependent launch in the step's hipGraph costs 1.5 us, a dependent memory round trip inside a kernel 0.15-0.45 us,
+// a workgroup pulls 144 KB of freshly rewritten weights in 1.2 us, eight dependent scalar loads cost 0.1 us -- but an in-launch hand-off between
+// workgroups costs 1.3-1.7 us, and ONE wave issues one instruction per ~7 clocks when each depends on the last (512 dependent v_fma: 1.2 us).
+// The fused kernels pay for both: the candidate needs (H r) Wh over ALL columns of r, so each of the four column tiles of a row block recomputes
+// r (350 of its 550 fp32 MFMAs, 80 of its 147 KB of weights) on the 32 CUs the launch occupies -- 2.4 us of MFMA issue + 2.6 us of operand requests
+// + 2.3 us of LDS epilogues + four barriers in a 8.8 us body (tools/clk.py, profiles/r06_clk_cfg2_baseline.txt).  A kernel boundary IS the cheap
+// cross-workgroup exchange on this chip.  So: cut at the two data dependencies (r before the candidate; dr' before dy), and make each piece as
+// short as the hardware allows -- which at these sizes means as FEW INSTRUCTIONS PER WAVE as possible:
+//   * one 16 x 16 output tile per workgroup (56-168 workgroups per launch instead of 32), its K range dealt out one 16-deep super-step per wave;
+//   * NO LDS staging of operands: every lane loads its MFMA fragments straight from global memory.  A[row][k] rows are read as float4 along k --
+//     lane (li, lg) of super-step s holds quad 4 s + lg, and MFMA u of the super-step multiplies component u: a permutation of k inside 16 that both
+//     operands share -- B[k][n] as the matching four dwords (row-major weights) or as float4 along k (transposed weights: the backward);
+//   * everything a kernel reads from the model comes out of ONE compact argument block (LeanV / LeanH / LeanDa / LeanDy, device resident, built at
+//     g4r_create from pointers that never change afterwards): two or three wide scalar loads at the top instead of a dozen lazy descriptor reads;
+//     uniform bases + 32-bit lane offsets (global_load ..., v_off, s[base]), a 3-D grid instead of integer divisions;
+//   * every load of a wave is issued before the first is consumed (one memory round trip per wave, two where an index comes first);
+//   * one barrier per kernel: the waves' K-slice partial tiles go to LDS component-wise, waves 0..3 each add one component (wave order: fixed)
+//     and run the epilogue for one output value per lane.
+// The r-dependency of the backward is turned into a sum the consumer does anyway: k_gru_da owns 16 COLUMNS of da (K slice j of dr' = da Wh^T) and
+// leaves dr'_j = da[:, slice j] Wh[:, slice j]^T for all D columns as a partial plane; k_gru_dy adds the <= 8 planes in slice order while it builds
+// its A fragments ((sum) * H * r (1 - r): the factor is applied after the sum, so the partial planes are plain linear pieces).
+// Arithmetic: the same fp32 MFMA fmaf chains, in a different (fixed) order than the fused kernels -- results agree with the oracle within the
+// same bounds (tests/test_gpu_parity.py::test_first_step_intermediates and the goldens run both forms), graph replay == eager bit for bit.
+// Math: gru4rec.py:471-479 (forward), T.grad :383-384 (backward); SURVEY section 8 a6 / a9.
+#pragma once
+
+#define LN_MAXD 128      // in, D <= 128: at most 8 super-steps of 16 per K segment
+
+// loads through a uniform base + 32-bit byte offset (the saddr form: no 64-bit lane arithmetic)
+__device__ __forceinline__ float ldu(const GAS float* base, unsigned boff) { return *(const GAS float*)((const GAS char*)base + boff); }
+__device__ __forceinline__ int ldu_i(const GAS int* base, unsigned boff) { return *(const GAS int*)((const GAS char*)base + boff); }
+__device__ __forceinline__ float4 ldu4(const GAS float* base, unsigned boff) { return *(const GAS float4*)((const GAS char*)base + boff); }
+__device__ __forceinline__ void stu(GAS float* base, unsigned boff, float v) { *(GAS float*)((GAS char*)base + boff) = v; }
+__device__ __forceinline__ void stu4(GAS float* base, unsigned boff, float4 v) { *(GAS float4*)((GAS char*)base + boff) = v; }
+
+// argument blocks (device resident, one per layer; g4r_host_create.hpp: build_lean_args).  Pointers only to buffers that live as long as the model.
+struct LeanV {
+    GP(const float) Wx; GP(const float) Wrz; GP(const float) Bh; GP(const float) H0; GP(const float) H1;
+    GP(const float) ysrc;        // layer 0: the input table (Wy / E); else the lower layer's output hd[l - 1]
+    GP(const int) cur_in;        // staged in_idx row of the step (layer 0)
+    GP(float) Vc; GP(float) r; GP(float) Hr; GP(float) z; GP(float) yin0;
+    GP(int) occ_idx; GP(int) occ_fl;      // occ_fl: already at the input table's block
+    GP(StepState) st;
+    unsigned long long seed;
+    int B, D, IN, R, first, pub_fl;
+    float drop_e, pad;
+};
+struct LeanH {
+    GP(const float) Wh; GP(const float) H0; GP(const float) H1; GP(const float) Hr; GP(const float) Vc; GP(const float) z;
+    GP(const int) cur_rst;       // staged reset flags of the step (one int per row)
+    GP(float) c; GP(float) hd;
+    GP(const StepState) st;
+    unsigned long long seed;
+    int B, D, hidden_act, stream;
+    float ha_p0, ha_p1, drop_h, pad;
+};
+struct LeanDa {
+    GP(const float) Wh; GP(const float) H0; GP(const float) H1; GP(const float) z; GP(const float) c;
+    GP(const float) dsrc;        // slabs of dh (top layer) / K-slice partial sums of a wide upper layer's dy / the upper layer's dy
+    GP(float) dV; GP(float) drp;
+    GP(const StepState) st;
+    unsigned long long seed;
+    int B, D, ks, hidden_act, stream, pad0;      // ks: planes of dsrc to add (1: dsrc is dh itself)
+    float ha_p0, ha_p1, drop_h, pad;
+};
+struct LeanDy {
+    GP(const float) Wx; GP(const float) H0; GP(const float) H1; GP(const float) r; GP(const float) drp;
+    GP(float) dV; GP(const int) occ_idx; GP(const int) occ_fl; GP(float) accT;
+    GP(float) dSx; GP(float) dAx; GP(float) dylo;
+    GP(const StepState) st;
+    unsigned long long seed;
+    long long dSx_stride;
+    int B, D, IN, layer0, generic, defer_mask;
+    float lr, drop_e;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Forward, launch 1: V = [y | H] [Wx ; 0 | Wrz] + Bh for ONE 16 x 16 tile per workgroup (gru4rec.py:472-473).
+// grid (ceil(D / 16), ceil(B / 16), 3): blockIdx.z = part; part 0: candidate input part V_c = y Wx[:, 0:D] (K = in) -> Vc; part 1: r = sigmoid(.),
+// Hr = H r; part 2: z = sigmoid(.)  (K = in + D).  Eight waves: wave w takes super-step w of the y segment AND of the H segment.  Layer 0 (L0)
+// gathers Wy[X] / E[X] rows (+ embedding dropout, DROPE); workgroup (0, row block, 0) publishes them (yin0: the dense-gradient tiles read them
+// back) and the X part of occ_idx / occ_fl.
+template <bool L0, bool DROPE>
+__global__ __launch_bounds__(512) void k_gru_v(const LeanV* __restrict__ ap) {
+    __shared__ float sJ[4 * 8 * 64];
+    const LeanV a = *ap;
+    const unsigned tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const unsigned wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned part = blockIdx.z, m0 = blockIdx.y * 16, rowA = m0 + li;
+    const unsigned D = a.D, IN = a.IN, B = a.B;
+    // row item first (the gather waits for it); staged by the previous step's bookkeeping: no wait for the state
+    int item = 0;
+    if (L0) item = ldu_i(a.cur_in, 4u * min(rowA, B - 1));
+    const GAS StepState* sg = a.st;
+    const long long g = a.first ? sg->g_a : sg->g_b;
+    const int M = a.first ? sg->M_a : sg->M_b;
+    const long long t = a.first ? sg->t_a : sg->t_b;
+    const unsigned ncol = 16 * blockIdx.x + li, nc = min(ncol, D - 1);
+    const unsigned Q = 4 * wid + lg;                   // quad of this lane in either segment
+    const bool oky = Q < (IN >> 2), okh = part != 0 && Q < (D >> 2);
+    const unsigned Qy = oky ? Q : 0, Qh = okh ? Q : 0;
+    // B fragments: Wx[4 Qy + u][part D + n] (row stride 3 D), Wrz[4 Qh + u][(part - 1) D + n] (row stride 2 D)
+    const unsigned D3b = 12 * D, D2b = 8 * D;
+    const unsigned offx = 4 * Qy * D3b + 4 * (part * D + nc), offh = 4 * Qh * D2b + 4 * ((part ? part - 1 : 0) * D + nc);
+    float bx[4], bh[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bx[u] = ldu(a.Wx, offx + u * D3b);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bh[u] = ldu(a.Wrz, offh + u * D2b);
+    const float bias = ldu(a.Bh, 4 * (part * D + nc));
+    if (a.first && blockIdx.x == 0 && blockIdx.y == 0 && part == 0 && tid == 0) { GAS StepState* sw = a.st; sw->t_b = t; sw->g_b = g; sw->M_b = M; }
+    const GAS float* Hcur = (g & 1) ? a.H1 : a.H0;
+    const bool rowok = (int)rowA < M;
+    if (L0) {
+        if (!rowok) item = -1;
+        if (blockIdx.x == 0 && part == 0 && wid == 0 && lg == 0 && rowA < B) {
+            a.occ_idx[rowA] = item;
+            if (item >= 0 && a.pub_fl) {      // first / last occurrence of the item in this step's gathered-row list (k_update)
+                int* fl = (int*)a.occ_fl + 4 * (size_t)item;
+                atomicMax(fl, (int)rowA + 1);
+                atomicMax(fl + 1, a.R - (int)rowA);
+                atomicAdd(fl + 2, 1);
+            }
+        }
+    }
+    if ((int)m0 >= M) return;
+    const unsigned rowc = min(rowA, (unsigned)(M - 1));
+    float4 ah = ldu4(Hcur, 4 * (rowc * D + 4 * Qh));
+    float4 ay;
+    if (L0) ay = ld4(a.ysrc + (size_t)max(item, 0) * IN + 4 * Qy);
+    else ay = ldu4(a.ysrc, 4 * (rowc * IN + 4 * Qy));
+    // epilogue operand of waves 0 .. 3 (component rg = wave): H at (row m0 + 4 lg + wave, column)
+    const unsigned rowe = m0 + 4 * lg + (wid & 3);
+    const float hep = ldu(Hcur, 4 * (min(rowe, (unsigned)(M - 1)) * D + nc));
+    if (DROPE) {
+        const float4 mk = drop_mult4(a.seed, (unsigned)g, G4R_STREAM_DROP_EMBED, rowA, Qy, 1.0f - a.drop_e);
+        ay.x *= mk.x; ay.y *= mk.y; ay.z *= mk.z; ay.w *= mk.w;
+    }
+    if (!(oky && rowok)) ay = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(okh && rowok)) ah = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (L0 && blockIdx.x == 0 && part == 0 && oky && rowok) stu4(a.yin0, 4 * (rowA * IN + 4 * Qy), ay);
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (part) {      // (uniform; the candidate's input part has no hidden segment)
+        acc0 = mfma16(ah.x, bh[0], acc0);
+        acc1 = mfma16(ah.y, bh[1], acc1);
+        acc0 = mfma16(ah.z, bh[2], acc0);
+        acc1 = mfma16(ah.w, bh[3], acc1);
+    }
+    acc0 = mfma16(ay.x, bx[0], acc0);
+    acc1 = mfma16(ay.y, bx[1], acc1);
+    acc0 = mfma16(ay.z, bx[2], acc0);
+    acc1 = mfma16(ay.w, bx[3], acc1);
+    const f32x4 acc = acc0 + acc1;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) sJ[(rg * 8 + wid) * 64 + lane] = acc[rg];
+    __syncthreads();
+    if (wid >= 4) return;
+    float v = bias;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += sJ[(wid * 8 + w) * 64 + lane];      // K slices in wave order
+    if (ncol >= D || (int)rowe >= M) return;
+    const unsigned o = 4 * (rowe * D + ncol);
+    if (part == 0) stu(a.Vc, o, v);
+    else if (part == 1) { const float rr = sigmoidf_(v); stu(a.r, o, rr); stu(a.Hr, o, hep * rr); }
+    else stu(a.z, o, sigmoidf_(v));
+}
+
+// (hipcc emits the device code of a __global__ template only for explicit instantiations)
+template __global__ void k_gru_v<true, false>(const LeanV*);
+template __global__ void k_gru_v<true, true>(const LeanV*);
+template __global__ void k_gru_v<false, false>(const LeanV*);
+
+// Forward, launch 2: c = act(Hr Wh + Vc); h = (1 - z) H + z c; hidden dropout; reset switch -> next H; saves c, hd (gru4rec.py:474-479).
+// grid (ceil(D / 16), ceil(B / 16)), eight waves: wave w takes super-step w of K = D.
+__global__ __launch_bounds__(512) void k_gru_h(const LeanH* __restrict__ ap) {
+    __shared__ float sJ[4 * 8 * 64];
+    const LeanH a = *ap;
+    const unsigned tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const unsigned wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned m0 = blockIdx.y * 16, rowA = m0 + li, D = a.D;
+    const GAS StepState* sg = a.st;
+    const long long g = sg->g_b;
+    const int M = sg->M_b;
+    const unsigned ncol = 16 * blockIdx.x + li, nc = min(ncol, D - 1);
+    const unsigned Q = 4 * wid + lg;
+    const bool okq = Q < (D >> 2);
+    const unsigned Qc = okq ? Q : 0, Db = 4 * D;
+    const unsigned offw = 4 * Qc * Db + 4 * nc;
+    float bw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bw[u] = ldu(a.Wh, offw + u * Db);
+    if ((int)m0 >= M) return;
+    const bool rowok = (int)rowA < M;
+    const unsigned rowc = min(rowA, (unsigned)(M - 1));
+    float4 av = ldu4(a.Hr, 4 * (rowc * D + 4 * Qc));
+    // epilogue operands of waves 0 .. 3
+    const unsigned rowe = m0 + 4 * lg + (wid & 3), rowec = min(rowe, (unsigned)(M - 1));
+    const unsigned oe = 4 * (rowec * D + nc);
+    const GAS float* Hcur = (g & 1) ? a.H1 : a.H0;
+    GAS float* Hnext = (GAS float*)((g & 1) ? a.H0 : a.H1);
+    const float vce = ldu(a.Vc, oe), ze = ldu(a.z, oe), he = ldu(Hcur, oe);
+    const int rst = ldu_i(a.cur_rst, 4 * rowec);
+    if (!(okq && rowok)) av = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc0 = mfma16(av.x, bw[0], acc0);
+    acc1 = mfma16(av.y, bw[1], acc1);
+    acc0 = mfma16(av.z, bw[2], acc0);
+    acc1 = mfma16(av.w, bw[3], acc1);
+    const f32x4 acc = acc0 + acc1;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) sJ[(rg * 8 + wid) * 64 + lane] = acc[rg];
+    __syncthreads();
+    if (wid >= 4) return;
+    float v = vce;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += sJ[(wid * 8 + w) * 64 + lane];
+    if (ncol >= D || (int)rowe >= M) return;
+    const float cc = act_fwd(a.hidden_act, a.ha_p0, a.ha_p1, v);
+    float h = (1.0f - ze) * he + ze * cc;
+    if (a.drop_h > 0.f) h *= drop_mult(a.seed, (unsigned)g, (unsigned)a.stream, rowe, ncol, 1.0f - a.drop_h);
+    const unsigned o = 4 * (rowe * D + ncol);
+    stu(a.c, o, cc);
+    stu(a.hd, o, h);
+    stu(Hnext, o, rst ? 0.f : h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward, launch 1 (no BPTT: H is a constant input, gru4rec.py:460-463,576).  Workgroup (K slice j = 16 columns of the layer, 16 rows):
+//   dh = split-K slabs of k_score_bwd in fixed order (top layer) / the upper layer's dy, through the hidden-dropout mask;
+//   da = dh z act'(c), dz' = dh (c - H) z (1 - z) for its 16 x 16 elements -> dV[:, 0:D], dV[:, 2D:3D];
+//   dr'_j = da[:, slice j] Wh[:, slice j]^T for ALL D columns -> partial plane drp[j] (k_gru_dy adds the planes and applies H r (1 - r)).
+// Eight waves, no LDS, no barrier: every wave builds the da fragment itself (the same loads) and takes column tile `wave`.
+#define LN_SLB 10      // slabs per batch of loads
+__global__ __launch_bounds__(512) void k_gru_da(const LeanDa* __restrict__ ap) {
+    const LeanDa a = *ap;
+    const unsigned tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const unsigned wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned D = a.D, B = a.B;
+    const unsigned j = blockIdx.x, m0 = blockIdx.y * 16, row = m0 + li;
+    if (16 * wid >= D) return;      // this wave's column tile lies outside the layer
+    const GAS StepState* sg = a.st;
+    const long long g = sg->g_b;
+    const int M = sg->M_b;
+    const unsigned col = 16 * j + 4 * lg;
+    const bool colok = col < D;      // (D is a multiple of 4: a quad is inside or outside)
+    const unsigned colc = colok ? col : 0;
+    // B fragment: Wh[n][16 j + 4 lg ..] of the wave's column tile
+    const unsigned n = 16 * wid + li;
+    const float4 bq = ldu4(a.Wh, 4 * (min(n, D - 1) * D + colc));
+    if ((int)m0 >= M) return;
+    const unsigned off = 4 * (min(row, (unsigned)(M - 1)) * D + colc);
+    const float4 h4 = ldu4((g & 1) ? a.H1 : a.H0, off), z4 = ldu4(a.z, off), c4 = ldu4(a.c, off);
+    const unsigned ps = 4 * B * D;
+    float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ks = a.ks;
+    for (int k0 = 0; k0 < ks; k0 += LN_SLB) {      // planes in fixed order, batches of LN_SLB loads
+        float4 v[LN_SLB];
+#pragma unroll
+        for (int q = 0; q < LN_SLB; ++q) v[q] = ldu4(a.dsrc, off + (unsigned)min(k0 + q, ks - 1) * ps);
+#pragma unroll
+        for (int q = 0; q < LN_SLB; ++q) {
+            const float w = (k0 + q < ks) ? 1.f : 0.f;
+            dh.x = fmaf(w, v[q].x, dh.x); dh.y = fmaf(w, v[q].y, dh.y); dh.z = fmaf(w, v[q].z, dh.z); dh.w = fmaf(w, v[q].w, dh.w);
+        }
+    }
+    if (a.drop_h > 0.f) {
+        const float4 mk = drop_mult4(a.seed, (unsigned)g, (unsigned)a.stream, row, colc >> 2, 1.0f - a.drop_h);
+        dh.x *= mk.x; dh.y *= mk.y; dh.z *= mk.z; dh.w *= mk.w;
+    }
+    const bool ok = (int)row < M && colok;
+    const float hh[4] = {h4.x, h4.y, h4.z, h4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w};
+    const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, dd[4] = {dh.x, dh.y, dh.z, dh.w};
+    float da[4], dzp[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float ad = act_bwd_from_out(a.hidden_act, a.ha_p0, a.ha_p1, cc[u]);
+        const float dz = dd[u] * (cc[u] - hh[u]), dc = dd[u] * zz[u];
+        da[u] = ok ? dc * ad : 0.f;
+        dzp[u] = ok ? dz * zz[u] * (1.f - zz[u]) : 0.f;
+    }
+    if (wid == 0 && ok) {
+        const unsigned ov = 4 * (row * 3 * D + col);
+        stu4(a.dV, ov, make_float4(da[0], da[1], da[2], da[3]));
+        stu4(a.dV, ov + 8 * D, make_float4(dzp[0], dzp[1], dzp[2], dzp[3]));
+    }
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc = mfma16(da[0], bq.x, acc);
+    acc = mfma16(da[1], bq.y, acc);
+    acc = mfma16(da[2], bq.z, acc);
+    acc = mfma16(da[3], bq.w, acc);
+    if (n < D) {
+        const unsigned ob = j * ps + 4 * ((m0 + 4 * lg) * D + n);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+            if ((int)(m0 + 4 * lg + rg) < M) stu(a.drp, ob + rg * 4 * D, acc[rg]);
+    }
+}
+
+// Backward, launch 2: dy tile = [da | dr' | dz'] Wx^T (K = 3 D), 16 rows x 16 input columns per workgroup, sixteen waves over K:
+// waves 0 .. 3 the da part, 4 .. 7 the dz' part (two super-steps each, A fragments straight from dV), 8 .. 15 the dr' part (one super-step
+// each) -- its A fragment is built here: dr' = (sum of the <= 8 partial planes of k_gru_da, plane order) * H * r (1 - r); column tile 0
+// writes it to dV[:, D:2D] for the dense-gradient tiles.  Epilogue (waves 0 .. 3, as k_gru_bwd_b): layer 0 embedding-dropout mask and the
+// Adagrad pieces dSx / dAx (or the accumulator in place for a single-occurrence item), else the lower layer's dh.
+#define LN_PL 8        // partial planes (= ceil(D / 16) <= 8)
+__global__ __launch_bounds__(1024) void k_gru_dy(const LeanDy* __restrict__ ap) {
+    __shared__ float sJ[4 * 16 * 64];
+    const LeanDy a = *ap;
+    const unsigned tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const unsigned wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned D = a.D, IN = a.IN, B = a.B, Dq = D >> 2, D3b = 12 * D;
+    const unsigned m0 = blockIdx.y * 16, row = m0 + li;
+    const unsigned ncol = 16 * blockIdx.x + li, nc = min(ncol, IN - 1);
+    const GAS StepState* sg = a.st;
+    const long long g = sg->g_b;
+    const int M = sg->M_b;
+    // epilogue operands of waves 0 .. 3 (layer 0): item of the output row -> its accumulator element, its occurrence count
+    const unsigned rowe = m0 + 4 * lg + (wid & 3);
+    int itm = -1;
+    if (a.layer0 && wid < 4) itm = ldu_i(a.occ_idx, 4 * min(rowe, B - 1));
+    // role of the wave
+    const bool isr = wid >= 8;
+    const unsigned part = isr ? 1 : (wid >> 2) * 2;                  // 0 da, 1 dr', 2 dz'
+    const unsigned ss = isr ? wid - 8 : 2 * (wid & 3);               // first super-step inside the part
+    const unsigned Q0 = 4 * ss + lg, Q1 = Q0 + 4;
+    const bool ok0 = Q0 < Dq, ok1 = !isr && Q1 < Dq;
+    const unsigned Qa = ok0 ? Q0 : 0, Qb = ok1 ? Q1 : 0;
+    const unsigned offw = 4 * (nc * 3 * D + part * D);
+    const float4 b0 = ldu4(a.Wx, offw + 16 * Qa), b1 = ldu4(a.Wx, offw + 16 * Qb);
+    if ((int)m0 >= M) return;
+    const bool rowok = (int)row < M;
+    const unsigned rowc = min(row, (unsigned)(M - 1));
+    float4 a0, a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!isr) {
+        const unsigned offa = 4 * (rowc * 3 * D + part * D);
+        a0 = ldu4(a.dV, offa + 16 * Qa);
+        a1 = ldu4(a.dV, offa + 16 * Qb);
+    } else {
+        const unsigned ps = 4 * B * D, off = 4 * (rowc * D + 4 * Qa), NTD = (D + 15) >> 4;
+        float4 pv[LN_PL];
+#pragma unroll
+        for (int q = 0; q < LN_PL; ++q) pv[q] = ldu4(a.drp, off + min((unsigned)q, NTD - 1) * ps);
+        const float4 h4 = ldu4((g & 1) ? a.H1 : a.H0, off), r4 = ldu4(a.r, off);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < LN_PL; ++q) {      // plane order
+            const float w = ((unsigned)q < NTD) ? 1.f : 0.f;
+            s.x = fmaf(w, pv[q].x, s.x); s.y = fmaf(w, pv[q].y, s.y); s.z = fmaf(w, pv[q].z, s.z); s.w = fmaf(w, pv[q].w, s.w);
+        }
+        s.x *= h4.x * r4.x * (1.f - r4.x); s.y *= h4.y * r4.y * (1.f - r4.y);
+        s.z *= h4.z * r4.z * (1.f - r4.z); s.w *= h4.w * r4.w * (1.f - r4.w);
+        a0 = s;
+        if (blockIdx.x == 0 && ok0 && rowok) stu4(a.dV, 4 * (row * 3 * D + D + 4 * Qa), s);
+    }
+    float a2 = 0.f;
+    int cnt2 = 0;
+    if (a.layer0 && wid < 4) {
+        if (!((int)rowe < M)) itm = -1;
+        a2 = a.accT[(size_t)max(itm, 0) * IN + nc];
+        cnt2 = a.occ_fl[4 * (size_t)max(itm, 0) + 2];
+    }
+    if (!(ok0 && rowok)) a0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(ok1 && rowok)) a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc0 = mfma16(a0.x, b0.x, acc0);
+    acc1 = mfma16(a0.y, b0.y, acc1);
+    acc0 = mfma16(a0.z, b0.z, acc0);
+    acc1 = mfma16(a0.w, b0.w, acc1);
+    if (!isr) {
+        acc0 = mfma16(a1.x, b1.x, acc0);
+        acc1 = mfma16(a1.y, b1.y, acc1);
+        acc0 = mfma16(a1.z, b1.z, acc0);
+        acc1 = mfma16(a1.w, b1.w, acc1);
+    }
+    const f32x4 acc = acc0 + acc1;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) sJ[(rg * 16 + wid) * 64 + lane] = acc[rg];
+    __syncthreads();
+    if (wid >= 4) return;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v += sJ[(wid * 16 + w) * 64 + lane];      // K slices in wave order
+    if (ncol >= IN || (int)rowe >= M) return;
+    const unsigned o = 4 * (rowe * IN + ncol);
+    if (a.layer0) {
+        if (a.drop_e > 0.f) v *= drop_mult(a.seed, (unsigned)g, G4R_STREAM_DROP_EMBED, rowe, ncol, 1.0f - a.drop_e);
+        const float an = a2 + G4R_MUT_ACC(v * v);
+        GAS float* dSx = a.dSx + (size_t)(g & (long long)a.defer_mask) * (size_t)a.dSx_stride;
+        stu(dSx, o, a.generic ? v : G4R_MUT_STEP(a.lr * v * frsq(an + G4R_EPS_ADAGRAD)));
+        if (!a.generic && cnt2 == 1 && itm >= 0) a.accT[(size_t)itm * IN + ncol] = an;      // single occurrence: in place (see k_score_bwd)
+        else stu(a.dAx, o, an);
+    } else {
+        stu(a.dylo, o, v);
+    }
+}

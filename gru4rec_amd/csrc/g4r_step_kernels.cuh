@@ -44,7 +44,8 @@ __device__ __forceinline__ void stage_step_inputs(const DevModel& m, long long t
     const GAS int* out = m.out_idx + t * B;
     const GAS int* smp = m.ST + (size_t)(m.gl > 0 ? g % m.gl : 0) * m.ns;
     GAS int *ci = m.cur_in, *cc = m.cur_col;
-    for (int b = tid; b < B; b += nth) ci[b] = in[b];
+    const GAS unsigned char* rst = m.reset + t * B;      // (the plan carries one trailing, zeroed row)
+    for (int b = tid; b < B; b += nth) { ci[b] = in[b]; ci[B + b] = rst[b]; }      // cur_in[B ..]: the step's reset flags (k_gru_h)
     // 8 columns per thread and pass, all loads of a pass in flight together (clamped addresses, selects afterwards)
     for (int base = 0; base < ld; base += 8 * nth) {
         int vo[8], vs[8];
@@ -92,6 +93,7 @@ struct GruFwdPredict {
 #include "g4r_fwd_kernels.cuh"
 #include "g4r_loss_kernel.cuh"
 #include "g4r_bwd_kernels.cuh"
+#include "g4r_lean_kernels.cuh"
 #include "g4r_update_kernels.cuh"
 
 // ---------------------------------------------------------------------------------------------
