@@ -137,7 +137,7 @@ struct DevModel {
     GP(int) col_item;  // [ldSc] item of each score column, -1 = inactive
     // inputs of the NEXT step, staged at fixed addresses by the bookkeeping block of the update kernel (and by k_set_state /
     // after a sample-store refill), so that the first kernels of a step load them next to the step state instead of behind it
-    GP(int) cur_in;    // [2 B]  in_idx row of the step about to run | its reset flags (one int per row)
+    GP(int) cur_in;    // [2 B + 8]  in_idx row of the step about to run | its reset flags (one int per row) | (g lo, g hi, M, t lo, t hi)
     GP(int) cur_col;   // [ldSc] item of every score column of the step about to run (targets | -1 | samples | -1)
     // [tables][n_items][4]: (last occurrence + 1, R - first occurrence, count, 0) of every item touched this step, written
     // with atomics by the kernels that publish occ_idx and zeroed again by the row's owner in k_sparse_update

@@ -32,24 +32,25 @@ static int build_lean_args(g4r_model* m) {
         v.cur_in = d.cur_in; v.Vc = d.Vc[l]; v.r = d.r[l]; v.Hr = d.Hr[l]; v.z = d.z[l]; v.yin0 = d.yin0;
         v.occ_idx = d.occ_idx; v.occ_fl = d.occ_fl + 4 * (constrained ? (size_t)0 : (size_t)d.n_items);
         v.st = d.st; v.seed = d.seed; v.B = d.B; v.D = d.D[l]; v.IN = d.IN[l]; v.R = d.R; v.first = (l == 0) ? 1 : 0; v.pub_fl = d.xmode == 0 ? 1 : 0;
-        v.drop_e = d.drop_e;
+        v.drop_e = d.drop_e; v.dbg = d.dbgclk; v.n_items = d.n_items;
         LeanH& h = ah[l]; memset(&h, 0, sizeof(h));
         h.Wh = d.dense_p + d.offWh[l]; h.H0 = d.H[l][0]; h.H1 = d.H[l][1]; h.Hr = d.Hr[l]; h.Vc = d.Vc[l]; h.z = d.z[l];
         h.cur_rst = d.cur_in + d.B; h.c = d.c[l]; h.hd = d.hd[l]; h.st = d.st; h.seed = d.seed; h.B = d.B; h.D = d.D[l];
-        h.hidden_act = d.hidden_act; h.stream = (int)(G4R_STREAM_DROP_HIDDEN + (unsigned)l); h.ha_p0 = d.ha_p0; h.ha_p1 = d.ha_p1; h.drop_h = d.drop_h;
+        h.hidden_act = d.hidden_act; h.stream = (int)(G4R_STREAM_DROP_HIDDEN + (unsigned)l); h.ha_p0 = d.ha_p0; h.ha_p1 = d.ha_p1; h.drop_h = d.drop_h; h.dbg = d.dbgclk;
         LeanDa& q = aa[l]; memset(&q, 0, sizeof(q));
         q.Wh = h.Wh; q.H0 = h.H0; q.H1 = h.H1; q.z = d.z[l]; q.c = d.c[l];
         if (l == L - 1) { q.dsrc = d.dhpart; q.ks = d.ksplit; }
         else if (d.bbn[l + 1] > 0) { q.dsrc = d.dyp; q.ks = d.bbn[l + 1]; }
         else { q.dsrc = d.dyl[l]; q.ks = 1; }
         q.dV = d.dV[l]; q.drp = d.drp; q.st = d.st; q.seed = d.seed; q.B = d.B; q.D = d.D[l]; q.hidden_act = d.hidden_act; q.stream = h.stream;
-        q.ha_p0 = d.ha_p0; q.ha_p1 = d.ha_p1; q.drop_h = d.drop_h;
+        q.ha_p0 = d.ha_p0; q.ha_p1 = d.ha_p1; q.drop_h = d.drop_h; q.dbg = d.dbgclk;
         LeanDy& y = ay[l]; memset(&y, 0, sizeof(y));
         y.Wx = v.Wx; y.H0 = h.H0; y.H1 = h.H1; y.r = d.r[l]; y.drp = d.drp; y.dV = d.dV[l]; y.occ_idx = d.occ_idx; y.occ_fl = v.occ_fl;
         y.accT = constrained ? d.accWy : d.accE; y.dSx = d.dSx; y.dAx = d.dAx; y.dylo = (l > 0) ? d.dyl[l - 1] : nullptr;
         y.st = d.st; y.seed = d.seed; y.dSx_stride = d.dSx_stride; y.B = d.B; y.D = d.D[l]; y.IN = d.IN[l]; y.layer0 = (l == 0) ? 1 : 0;
-        y.generic = d.generic; y.defer_mask = d.defer_mask; y.lr = d.lr; y.drop_e = d.drop_e;
+        y.generic = d.generic; y.defer_mask = d.defer_mask; y.lr = d.lr; y.drop_e = d.drop_e; y.dbg = d.dbgclk; y.n_items = d.n_items;
     }
+    m->h_leanV = av; m->h_leanH = ah; m->h_leanDa = aa; m->h_leanDy = ay;      // (host copies: launch_step passes their hot fields as kernel arguments)
     if (!any) return 0;
     if (dalloc(m, &m->d_leanV, (size_t)L) || dalloc(m, &m->d_leanH, (size_t)L) || dalloc(m, &m->d_leanDa, (size_t)L) || dalloc(m, &m->d_leanDy, (size_t)L)) return -1;
     HIPCHK(hipMemcpyAsync(m->d_leanV, av.data(), L * sizeof(LeanV), hipMemcpyHostToDevice, m->stream));
@@ -218,7 +219,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
         for (auto& e : m->ev_df) if (hipEventCreate(&e) != hipSuccess) { g4r_destroy(m); return fail("event create"); }
     }
     DA(d.lossrow, B);
-    DA(d.col_item, d.ldSc); DA(d.cur_in, 2 * (size_t)B); DA(d.cur_col, d.ldSc);
+    DA(d.col_item, d.ldSc); DA(d.cur_in, 2 * (size_t)B + 8); DA(d.cur_col, d.ldSc);
     DA(d.occ_fl, (size_t)(cfg->embed_mode != G4R_EMBED_CONSTRAINED ? 2 : 1) * I * 4);
     DA(d.st, 1);
     // scoring backward geometry: role A tiles (n x d, one spare d column for dSBy), role B tiles (b x d x k-chunk)

@@ -72,6 +72,7 @@ struct g4r_model {
     int ntiles64 = 0;
     float* d_tmpH = nullptr;
     // graph
+    std::vector<LeanV> h_leanV; std::vector<LeanH> h_leanH; std::vector<LeanDa> h_leanDa; std::vector<LeanDy> h_leanDy;
     LeanV* d_leanV = nullptr; LeanH* d_leanH = nullptr; LeanDa* d_leanDa = nullptr; LeanDy* d_leanDy = nullptr;      // [layers] argument blocks (g4r_lean_kernels.cuh)
     hipGraphExec_t gexec = nullptr;
     hipGraphExec_t gexec_small = nullptr;        // single GPU: G4R_GRAPH_STEPS_SMALL steps, for what a run leaves after the big replays

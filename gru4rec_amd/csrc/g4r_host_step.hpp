@@ -24,6 +24,10 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         recs->push_back(r);
     };
     static const bool trace = getenv("G4R_TRACE") != nullptr;
+    // measurement aid (tools/kn_cost.py): bit k set = the launches of kernel slot k (KN_*) are left out of the step -- the step's results are
+    // garbage, its duration tells what that launch costs the captured step (HIP events and rocprofv3 both put a ~3 us floor under a dispatch
+    // that the graph does not pay: an empty kernel costs 1.5 us there, tools/probes/chain_probe.hip)
+    static const unsigned long long skip_kn = getenv("G4R_SKIP_KN") ? strtoull(getenv("G4R_SKIP_KN"), nullptr, 0) : 0ull;
     int trace_kn = -1;
     auto begin0 = begin;
     auto begin_t = [&](int kn) {
@@ -41,6 +45,7 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
 #define begin begin_t
 #define LK(kern, grid, block, smem, strm, ...)                                                             \
     do {                                                                                                  \
+        if (skip_kn && trace_kn >= 0 && ((skip_kn >> trace_kn) & 1ull)) break;                            \
         if (recs) hipExtLaunchKernelGGL(kern, grid, block, smem, strm, cur_a, cur_b, 0, __VA_ARGS__);     \
         else hipLaunchKernelGGL(kern, grid, block, smem, strm, __VA_ARGS__);                              \
     } while (0)
@@ -52,12 +57,21 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         if (lean_gru(d, l)) {
             const int ntd = cdiv(d.D[l], 16), nrb = cdiv(B, 16);
             begin(KN_GRU_V);
-            if (l > 0) LK((k_gru_v<false, false>), dim3(ntd, nrb, 3), dim3(512), 0, s, (const LeanV*)(m->d_leanV + l));
-            else if (d.drop_e > 0.f) LK((k_gru_v<true, true>), dim3(ntd, nrb, 3), dim3(512), 0, s, (const LeanV*)(m->d_leanV + l));
-            else LK((k_gru_v<true, false>), dim3(ntd, nrb, 3), dim3(512), 0, s, (const LeanV*)(m->d_leanV + l));
+            {
+                const LeanV& v = m->h_leanV[l];
+                const unsigned dims = (unsigned)d.D[l] | ((unsigned)d.IN[l] << 16);
+#define G4R_LK_V(L0_, DR_) LK((k_gru_v<L0_, DR_>), dim3(ntd, nrb, 3), dim3(512), 0, s, (const LeanV*)(m->d_leanV + l), (StepState*)v.st, (const int*)v.cur_in, \
+                              (const float*)v.Wx, (const float*)v.Wrz, (const float*)v.H0, (const float*)v.H1, dims, (unsigned)B)
+                if (l > 0) G4R_LK_V(false, false); else if (d.drop_e > 0.f) G4R_LK_V(true, true); else G4R_LK_V(true, false);
+#undef G4R_LK_V
+            }
             end();
             begin(KN_GRU_H);
-            LK(k_gru_h, dim3(ntd, nrb), dim3(512), 0, s, (const LeanH*)(m->d_leanH + l));
+            {
+                const LeanH& h = m->h_leanH[l];
+                LK(k_gru_h, dim3(ntd, nrb), dim3(512), 0, s, (const LeanH*)(m->d_leanH + l), (const float*)h.Wh, (const float*)h.Hr,
+                   (const float*)h.Vc, (const float*)h.z, (const int*)h.cur_rst, (const float*)h.H0, (const float*)h.H1, (unsigned)d.D[l], (unsigned)B);
+            }
             end();
             continue;
         }
@@ -122,10 +136,18 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         if (lean_gru(d, l)) {
             const int nrb = cdiv(B, 16);
             begin(KN_GRU_DA);
-            LK(k_gru_da, dim3(cdiv(d.D[l], 16), nrb), dim3(512), 0, s, (const LeanDa*)(m->d_leanDa + l));
+            {
+                const LeanDa& q = m->h_leanDa[l];
+                LK(k_gru_da, dim3(cdiv(d.D[l], 16), nrb), dim3(128), 0, s, (const LeanDa*)(m->d_leanDa + l), (const int*)(d.cur_in + 2 * B), (const float*)q.dsrc,
+                   (const float*)q.Wh, (const float*)q.z, (const float*)q.c, (const float*)q.H0, (const float*)q.H1, (unsigned)d.D[l] | ((unsigned)q.ks << 16), (unsigned)B);
+            }
             end();
             begin(KN_GRU_DY);
-            LK(k_gru_dy, dim3(cdiv(d.IN[l], 16), nrb), dim3(1024), 0, s, (const LeanDy*)(m->d_leanDy + l));
+            {
+                const LeanDy& y = m->h_leanDy[l];
+                LK(k_gru_dy, dim3(cdiv(d.IN[l], 16), nrb), dim3(1024), 0, s, (const LeanDy*)(m->d_leanDy + l), (const int*)(d.cur_in + 2 * B), (const int*)y.occ_idx,
+                   (const float*)y.dV, (const float*)y.drp, (const float*)y.Wx, (const float*)y.r, (unsigned)d.D[l] | ((unsigned)d.IN[l] << 16), (unsigned)B);
+            }
             end();
             continue;
         }

@@ -37,6 +37,17 @@ __device__ __forceinline__ float4 ldu4(const GAS float* base, unsigned boff) { r
 __device__ __forceinline__ void stu(GAS float* base, unsigned boff, float v) { *(GAS float*)((GAS char*)base + boff) = v; }
 __device__ __forceinline__ void stu4(GAS float* base, unsigned boff, float4 v) { *(GAS float4*)((GAS char*)base + boff) = v; }
 
+// phase stamps of workgroup (1, 1), thread 0 (G4R_CLK_TRACE builds; tools/clk_lean.py): slot base per kernel, 100 MHz wall clock
+#if defined(G4R_CLK_TRACE)
+#define LCLK_INIT(dbgp, slot) GAS long long* clk_ = ((dbgp) && blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && threadIdx.x == 0) ? (dbgp) + (slot) : nullptr
+#define LCLK(i) do { if (clk_) clk_[i] = wall_clock64(); } while (0)
+#define LCLK_USE(x) do { if (clk_ && (x) == 123.456f) clk_[15] = 0; } while (0)
+#else
+#define LCLK_INIT(dbgp, slot)
+#define LCLK(i)
+#define LCLK_USE(x)
+#endif
+
 // argument blocks (device resident, one per layer; g4r_host_create.hpp: build_lean_args).  Pointers only to buffers that live as long as the model.
 struct LeanV {
     GP(const float) Wx; GP(const float) Wrz; GP(const float) Bh; GP(const float) H0; GP(const float) H1;
@@ -47,7 +58,9 @@ struct LeanV {
     GP(StepState) st;
     unsigned long long seed;
     int B, D, IN, R, first, pub_fl;
-    float drop_e, pad;
+    float drop_e;
+    int n_items;
+    GP(long long) dbg;
 };
 struct LeanH {
     GP(const float) Wh; GP(const float) H0; GP(const float) H1; GP(const float) Hr; GP(const float) Vc; GP(const float) z;
@@ -57,6 +70,7 @@ struct LeanH {
     unsigned long long seed;
     int B, D, hidden_act, stream;
     float ha_p0, ha_p1, drop_h, pad;
+    GP(long long) dbg;           // phase stamps (G4R_CLK builds)
 };
 struct LeanDa {
     GP(const float) Wh; GP(const float) H0; GP(const float) H1; GP(const float) z; GP(const float) c;
@@ -66,6 +80,7 @@ struct LeanDa {
     unsigned long long seed;
     int B, D, ks, hidden_act, stream, pad0;      // ks: planes of dsrc to add (1: dsrc is dh itself)
     float ha_p0, ha_p1, drop_h, pad;
+    GP(long long) dbg;
 };
 struct LeanDy {
     GP(const float) Wx; GP(const float) H0; GP(const float) H1; GP(const float) r; GP(const float) drp;
@@ -76,29 +91,56 @@ struct LeanDy {
     long long dSx_stride;
     int B, D, IN, layer0, generic, defer_mask;
     float lr, drop_e;
+    GP(long long) dbg;
+    int n_items, pad;
 };
 
 // ---------------------------------------------------------------------------------------------
+// How every kernel below is laid out in time (tools/clk_lean.py, profiles/r06_clk_lean_*.txt): a line the previous launch wrote costs
+// 0.4-0.6 us to fetch, the step state (rewritten every step) as much -- so NO load may wait for the state or for the argument block:
+//   t = 0     the pointers and sizes the first loads need arrive in SGPRs with the wave (kernarg preload: 16 dwords); the step's (g, M, t)
+//             -- staged behind cur_in by the previous step's bookkeeping -- row items, weights and activations are requested at once as
+//             VECTOR loads, rows clamped by the batch size (not by the step's M), BOTH H buffers.  (hipcc sinks a scalar load of the state
+//             to its first use, behind the branches in front of it: its latency was fully exposed; a vector load stays where it is written.)
+//   ~0.2 us   the argument block is there (lean_pin: every field in SGPRs at one point, instead of a lazy scalar load per use);
+//   ~0.5 us   state and first-level loads are there: masks (row < M), H parity, second-level gathers (item -> table row);
+//   then      MFMAs, one LDS hand-over, epilogue.
+// A CU's vector memory path moves 64 B per clock (144 KB = 1.2 us, chain_probe): waves of one workgroup must not load the same bytes
+// eight times (k_gru_da's first form: 106 KB per workgroup = 0.8 us).
+template <typename T> __device__ __forceinline__ void lean_pin1(T v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"s"(v));
+#endif
+}
+template <typename... T> __device__ __forceinline__ void lean_pin(T... v) { (lean_pin1(v), ...); }
+struct LeanState { unsigned g; int M; unsigned t_lo; };
+// staged (g lo, g hi, M, t lo, t hi) -> wave-uniform registers (every lane loaded the same 16 bytes)
+__device__ __forceinline__ LeanState lean_state(int4 mt) {
+    LeanState s;
+    s.g = (unsigned)__builtin_amdgcn_readfirstlane(mt.x); s.M = __builtin_amdgcn_readfirstlane(mt.z); s.t_lo = (unsigned)__builtin_amdgcn_readfirstlane(mt.w);
+    return s;
+}
+
 // Forward, launch 1: V = [y | H] [Wx ; 0 | Wrz] + Bh for ONE 16 x 16 tile per workgroup (gru4rec.py:472-473).
 // grid (ceil(D / 16), ceil(B / 16), 3): blockIdx.z = part; part 0: candidate input part V_c = y Wx[:, 0:D] (K = in) -> Vc; part 1: r = sigmoid(.),
 // Hr = H r; part 2: z = sigmoid(.)  (K = in + D).  Eight waves: wave w takes super-step w of the y segment AND of the H segment.  Layer 0 (L0)
 // gathers Wy[X] / E[X] rows (+ embedding dropout, DROPE); workgroup (0, row block, 0) publishes them (yin0: the dense-gradient tiles read them
-// back) and the X part of occ_idx / occ_fl.
+// back) and the X part of occ_idx / occ_fl; workgroup (0, 0, 0) republishes the step state for the kernels that read StepState::*_b.
 template <bool L0, bool DROPE>
-__global__ __launch_bounds__(512) void k_gru_v(const LeanV* __restrict__ ap) {
+__global__ __launch_bounds__(512) void k_gru_v(const LeanV* __restrict__ ap, StepState* st_, const int* cur_in_, const float* Wx_, const float* Wrz_,
+                                               const float* H0_, const float* H1_, unsigned dims, unsigned B) {
     __shared__ float sJ[4 * 8 * 64];
-    const LeanV a = *ap;
     const unsigned tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const unsigned wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned part = blockIdx.z, m0 = blockIdx.y * 16, rowA = m0 + li;
-    const unsigned D = a.D, IN = a.IN, B = a.B;
-    // row item first (the gather waits for it); staged by the previous step's bookkeeping: no wait for the state
+    const unsigned D = dims & 0xFFFFu, IN = dims >> 16;
+    const GAS float *Wx = (const GAS float*)Wx_, *Wrz = (const GAS float*)Wrz_, *H0 = (const GAS float*)H0_, *H1 = (const GAS float*)H1_;
+    const GAS int* cur_in = (const GAS int*)cur_in_;
+    // row item first (the gather waits for it), then the step's (g, M, t); both staged by the previous step's bookkeeping
+    const unsigned rowB = min(rowA, B - 1);
     int item = 0;
-    if (L0) item = ldu_i(a.cur_in, 4u * min(rowA, B - 1));
-    const GAS StepState* sg = a.st;
-    const long long g = a.first ? sg->g_a : sg->g_b;
-    const int M = a.first ? sg->M_a : sg->M_b;
-    const long long t = a.first ? sg->t_a : sg->t_b;
+    if (L0) item = ldu_i(cur_in, 4u * rowB);
+    const int4 mt = ldi4(cur_in + 2 * B);
     const unsigned ncol = 16 * blockIdx.x + li, nc = min(ncol, D - 1);
     const unsigned Q = 4 * wid + lg;                   // quad of this lane in either segment
     const bool oky = Q < (IN >> 2), okh = part != 0 && Q < (D >> 2);
@@ -108,13 +150,34 @@ __global__ __launch_bounds__(512) void k_gru_v(const LeanV* __restrict__ ap) {
     const unsigned offx = 4 * Qy * D3b + 4 * (part * D + nc), offh = 4 * Qh * D2b + 4 * ((part ? part - 1 : 0) * D + nc);
     float bx[4], bh[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) bx[u] = ldu(a.Wx, offx + u * D3b);
+    for (int u = 0; u < 4; ++u) bx[u] = ldu(Wx, offx + u * D3b);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) bh[u] = ldu(a.Wrz, offh + u * D2b);
+    for (int u = 0; u < 4; ++u) bh[u] = ldu(Wrz, offh + u * D2b);
+    // the H quad of the lane's row and the epilogue's H element, out of both buffers (the parity comes with the state)
+    const unsigned offa = 4 * (rowB * D + 4 * Qh);
+    const float4 ah0 = ldu4(H0, offa), ah1 = ldu4(H1, offa);
+    const unsigned rowe = m0 + 4 * lg + (wid & 3);     // epilogue of waves 0 .. 3: component rg = wave
+    const unsigned offe = 4 * (min(rowe, B - 1) * D + nc);
+    const float he0 = ldu(H0, offe), he1 = ldu(H1, offe);
+    // ---- the argument block is needed from here
+    const LeanV a = *ap;
+    lean_pin(a.Bh, a.ysrc, a.Vc, a.r, a.Hr, a.z, a.yin0, a.occ_idx, a.occ_fl, a.seed, a.R, a.first, a.pub_fl, a.drop_e, a.n_items, a.dbg);
+    LCLK_INIT(a.dbg, 0); LCLK(1);
     const float bias = ldu(a.Bh, 4 * (part * D + nc));
-    if (a.first && blockIdx.x == 0 && blockIdx.y == 0 && part == 0 && tid == 0) { GAS StepState* sw = a.st; sw->t_b = t; sw->g_b = g; sw->M_b = M; }
-    const GAS float* Hcur = (g & 1) ? a.H1 : a.H0;
-    const bool rowok = (int)rowA < M;
+    float4 ay;
+    if (L0) ay = ld4(a.ysrc + (size_t)min((unsigned)max(item, 0), (unsigned)a.n_items - 1) * IN + 4 * Qy);      // (rows past M hold any staged id: clamped, masked below)
+    else ay = ldu4(a.ysrc, 4 * (rowB * IN + 4 * Qy));
+    LCLK(2);
+    // ---- the state is needed from here
+    const LeanState sx = lean_state(mt);
+    const int M = sx.M;
+    if (a.first && blockIdx.x == 0 && blockIdx.y == 0 && part == 0 && tid == 0) {
+        GAS StepState* sw = (GAS StepState*)st_;
+        sw->t_b = (long long)(((unsigned long long)(unsigned)mt.w) | ((unsigned long long)(unsigned)cur_in[2 * B + 4] << 32));
+        sw->g_b = (long long)(((unsigned long long)(unsigned)mt.x) | ((unsigned long long)(unsigned)mt.y << 32));
+        sw->M_b = M;
+    }
+    const bool rowok = (int)rowA < M, odd = (sx.g & 1u) != 0;
     if (L0) {
         if (!rowok) item = -1;
         if (blockIdx.x == 0 && part == 0 && wid == 0 && lg == 0 && rowA < B) {
@@ -128,21 +191,17 @@ __global__ __launch_bounds__(512) void k_gru_v(const LeanV* __restrict__ ap) {
         }
     }
     if ((int)m0 >= M) return;
-    const unsigned rowc = min(rowA, (unsigned)(M - 1));
-    float4 ah = ldu4(Hcur, 4 * (rowc * D + 4 * Qh));
-    float4 ay;
-    if (L0) ay = ld4(a.ysrc + (size_t)max(item, 0) * IN + 4 * Qy);
-    else ay = ldu4(a.ysrc, 4 * (rowc * IN + 4 * Qy));
-    // epilogue operand of waves 0 .. 3 (component rg = wave): H at (row m0 + 4 lg + wave, column)
-    const unsigned rowe = m0 + 4 * lg + (wid & 3);
-    const float hep = ldu(Hcur, 4 * (min(rowe, (unsigned)(M - 1)) * D + nc));
+    LCLK(3);
+    float4 ah = odd ? ah1 : ah0;
+    const float hep = odd ? he1 : he0;
     if (DROPE) {
-        const float4 mk = drop_mult4(a.seed, (unsigned)g, G4R_STREAM_DROP_EMBED, rowA, Qy, 1.0f - a.drop_e);
+        const float4 mk = drop_mult4(a.seed, sx.g, G4R_STREAM_DROP_EMBED, rowA, Qy, 1.0f - a.drop_e);
         ay.x *= mk.x; ay.y *= mk.y; ay.z *= mk.z; ay.w *= mk.w;
     }
     if (!(oky && rowok)) ay = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!(okh && rowok)) ah = make_float4(0.f, 0.f, 0.f, 0.f);
     if (L0 && blockIdx.x == 0 && part == 0 && oky && rowok) stu4(a.yin0, 4 * (rowA * IN + 4 * Qy), ay);
+    LCLK(4);
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (part) {      // (uniform; the candidate's input part has no hidden segment)
         acc0 = mfma16(ah.x, bh[0], acc0);
@@ -155,10 +214,12 @@ __global__ __launch_bounds__(512) void k_gru_v(const LeanV* __restrict__ ap) {
     acc0 = mfma16(ay.z, bx[2], acc0);
     acc1 = mfma16(ay.w, bx[3], acc1);
     const f32x4 acc = acc0 + acc1;
+    LCLK_USE(acc[0]); LCLK(5);
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) sJ[(rg * 8 + wid) * 64 + lane] = acc[rg];
     __syncthreads();
     if (wid >= 4) return;
+    LCLK(6);
     float v = bias;
 #pragma unroll
     for (int w = 0; w < 8; ++w) v += sJ[(wid * 8 + w) * 64 + lane];      // K slices in wave order
@@ -167,65 +228,75 @@ __global__ __launch_bounds__(512) void k_gru_v(const LeanV* __restrict__ ap) {
     if (part == 0) stu(a.Vc, o, v);
     else if (part == 1) { const float rr = sigmoidf_(v); stu(a.r, o, rr); stu(a.Hr, o, hep * rr); }
     else stu(a.z, o, sigmoidf_(v));
+    LCLK(7);
 }
 
 // (hipcc emits the device code of a __global__ template only for explicit instantiations)
-template __global__ void k_gru_v<true, false>(const LeanV*);
-template __global__ void k_gru_v<true, true>(const LeanV*);
-template __global__ void k_gru_v<false, false>(const LeanV*);
+#define G4R_LEAN_V_ARGS const LeanV*, StepState*, const int*, const float*, const float*, const float*, const float*, unsigned, unsigned
+template __global__ void k_gru_v<true, false>(G4R_LEAN_V_ARGS);
+template __global__ void k_gru_v<true, true>(G4R_LEAN_V_ARGS);
+template __global__ void k_gru_v<false, false>(G4R_LEAN_V_ARGS);
 
 // Forward, launch 2: c = act(Hr Wh + Vc); h = (1 - z) H + z c; hidden dropout; reset switch -> next H; saves c, hd (gru4rec.py:474-479).
-// grid (ceil(D / 16), ceil(B / 16)), eight waves: wave w takes super-step w of K = D.
-__global__ __launch_bounds__(512) void k_gru_h(const LeanH* __restrict__ ap) {
+// grid (ceil(D / 16), ceil(B / 16)), eight waves: wave w takes super-step w of K = D.  rst_: cur_in + B (reset flags), followed by the state.
+__global__ __launch_bounds__(512) void k_gru_h(const LeanH* __restrict__ ap, const float* Wh_, const float* Hr_, const float* Vc_,
+                                               const float* z_, const int* rst_, const float* H0_, const float* H1_, unsigned D, unsigned B) {
     __shared__ float sJ[4 * 8 * 64];
-    const LeanH a = *ap;
     const unsigned tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const unsigned wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned m0 = blockIdx.y * 16, rowA = m0 + li, D = a.D;
-    const GAS StepState* sg = a.st;
-    const long long g = sg->g_b;
-    const int M = sg->M_b;
+    const unsigned m0 = blockIdx.y * 16, rowA = m0 + li;
+    const GAS int* rstp = (const GAS int*)rst_;
+    const int4 mt = ldi4(rstp + B);
     const unsigned ncol = 16 * blockIdx.x + li, nc = min(ncol, D - 1);
     const unsigned Q = 4 * wid + lg;
     const bool okq = Q < (D >> 2);
     const unsigned Qc = okq ? Q : 0, Db = 4 * D;
     const unsigned offw = 4 * Qc * Db + 4 * nc;
+    float4 av = ldu4((const GAS float*)Hr_, 4 * (min(rowA, B - 1) * D + 4 * Qc));
     float bw[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) bw[u] = ldu(a.Wh, offw + u * Db);
-    if ((int)m0 >= M) return;
-    const bool rowok = (int)rowA < M;
-    const unsigned rowc = min(rowA, (unsigned)(M - 1));
-    float4 av = ldu4(a.Hr, 4 * (rowc * D + 4 * Qc));
+    for (int u = 0; u < 4; ++u) bw[u] = ldu((const GAS float*)Wh_, offw + u * Db);
     // epilogue operands of waves 0 .. 3
-    const unsigned rowe = m0 + 4 * lg + (wid & 3), rowec = min(rowe, (unsigned)(M - 1));
-    const unsigned oe = 4 * (rowec * D + nc);
-    const GAS float* Hcur = (g & 1) ? a.H1 : a.H0;
-    GAS float* Hnext = (GAS float*)((g & 1) ? a.H0 : a.H1);
-    const float vce = ldu(a.Vc, oe), ze = ldu(a.z, oe), he = ldu(Hcur, oe);
-    const int rst = ldu_i(a.cur_rst, 4 * rowec);
-    if (!(okq && rowok)) av = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned rowe = m0 + 4 * lg + (wid & 3), roweB = min(rowe, B - 1);
+    const unsigned oe = 4 * (roweB * D + nc);
+    const float vce = ldu((const GAS float*)Vc_, oe), ze = ldu((const GAS float*)z_, oe);
+    const float he0 = ldu((const GAS float*)H0_, oe), he1 = ldu((const GAS float*)H1_, oe);
+    const int rst = ldu_i(rstp, 4 * roweB);
+    const LeanH a = *ap;
+    lean_pin(a.c, a.hd, a.seed, a.hidden_act, a.stream, a.ha_p0, a.ha_p1, a.drop_h, a.dbg);
+    LCLK_INIT(a.dbg, 16); LCLK(1);
+    const LeanState sx = lean_state(mt);
+    const int M = sx.M;
+    if ((int)m0 >= M) return;
+    LCLK(2);
+    const bool odd = (sx.g & 1u) != 0;
+    const float he = odd ? he1 : he0;
+    GAS float* Hnext = (GAS float*)(odd ? H0_ : H1_);
+    if (!(okq && (int)rowA < M)) av = make_float4(0.f, 0.f, 0.f, 0.f);
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc0 = mfma16(av.x, bw[0], acc0);
     acc1 = mfma16(av.y, bw[1], acc1);
     acc0 = mfma16(av.z, bw[2], acc0);
     acc1 = mfma16(av.w, bw[3], acc1);
     const f32x4 acc = acc0 + acc1;
+    LCLK_USE(acc[0]); LCLK(5);
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) sJ[(rg * 8 + wid) * 64 + lane] = acc[rg];
     __syncthreads();
     if (wid >= 4) return;
+    LCLK(6);
     float v = vce;
 #pragma unroll
     for (int w = 0; w < 8; ++w) v += sJ[(wid * 8 + w) * 64 + lane];
     if (ncol >= D || (int)rowe >= M) return;
     const float cc = act_fwd(a.hidden_act, a.ha_p0, a.ha_p1, v);
     float h = (1.0f - ze) * he + ze * cc;
-    if (a.drop_h > 0.f) h *= drop_mult(a.seed, (unsigned)g, (unsigned)a.stream, rowe, ncol, 1.0f - a.drop_h);
+    if (a.drop_h > 0.f) h *= drop_mult(a.seed, sx.g, (unsigned)a.stream, rowe, ncol, 1.0f - a.drop_h);
     const unsigned o = 4 * (rowe * D + ncol);
     stu(a.c, o, cc);
     stu(a.hd, o, h);
     stu(Hnext, o, rst ? 0.f : h);
+    LCLK(7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -233,53 +304,75 @@ __global__ __launch_bounds__(512) void k_gru_h(const LeanH* __restrict__ ap) {
 //   dh = split-K slabs of k_score_bwd in fixed order (top layer) / the upper layer's dy, through the hidden-dropout mask;
 //   da = dh z act'(c), dz' = dh (c - H) z (1 - z) for its 16 x 16 elements -> dV[:, 0:D], dV[:, 2D:3D];
 //   dr'_j = da[:, slice j] Wh[:, slice j]^T for ALL D columns -> partial plane drp[j] (k_gru_dy adds the planes and applies H r (1 - r)).
-// Eight waves, no LDS, no barrier: every wave builds the da fragment itself (the same loads) and takes column tile `wave`.
+// Two waves, no LDS, no barrier: each builds the da fragment itself (the same 13 KB of loads) and takes four of the <= 8 column tiles.
 #define LN_SLB 10      // slabs per batch of loads
-__global__ __launch_bounds__(512) void k_gru_da(const LeanDa* __restrict__ ap) {
-    const LeanDa a = *ap;
+__global__ __launch_bounds__(128) void k_gru_da(const LeanDa* __restrict__ ap, const int* meta_, const float* dsrc_, const float* Wh_, const float* z_,
+                                                const float* c_, const float* H0_, const float* H1_, unsigned dims, unsigned B) {
     const unsigned tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const unsigned wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned D = a.D, B = a.B;
+    const unsigned D = dims & 0xFFFFu;
+    const int ks = (int)(dims >> 16);
     const unsigned j = blockIdx.x, m0 = blockIdx.y * 16, row = m0 + li;
-    if (16 * wid >= D) return;      // this wave's column tile lies outside the layer
-    const GAS StepState* sg = a.st;
-    const long long g = sg->g_b;
-    const int M = sg->M_b;
+    const int4 mt = ldi4((const GAS int*)meta_);
     const unsigned col = 16 * j + 4 * lg;
     const bool colok = col < D;      // (D is a multiple of 4: a quad is inside or outside)
     const unsigned colc = colok ? col : 0;
-    // B fragment: Wh[n][16 j + 4 lg ..] of the wave's column tile
-    const unsigned n = 16 * wid + li;
-    const float4 bq = ldu4(a.Wh, 4 * (min(n, D - 1) * D + colc));
-    if ((int)m0 >= M) return;
-    const unsigned off = 4 * (min(row, (unsigned)(M - 1)) * D + colc);
-    const float4 h4 = ldu4((g & 1) ? a.H1 : a.H0, off), z4 = ldu4(a.z, off), c4 = ldu4(a.c, off);
+    const unsigned off = 4 * (min(row, B - 1) * D + colc);
     const unsigned ps = 4 * B * D;
-    float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int ks = a.ks;
-    for (int k0 = 0; k0 < ks; k0 += LN_SLB) {      // planes in fixed order, batches of LN_SLB loads
-        float4 v[LN_SLB];
+    const GAS float* dsrc = (const GAS float*)dsrc_;
+    // the first batch of planes, the gates, the B fragments Wh[n][16 j + 4 lg ..] of the wave's four column tiles: one round trip
+    float4 v[LN_SLB];
 #pragma unroll
-        for (int q = 0; q < LN_SLB; ++q) v[q] = ldu4(a.dsrc, off + (unsigned)min(k0 + q, ks - 1) * ps);
+    for (int q = 0; q < LN_SLB; ++q) v[q] = ldu4(dsrc, off + (unsigned)min(q, ks - 1) * ps);
+    const float4 z4 = ldu4((const GAS float*)z_, off), c4 = ldu4((const GAS float*)c_, off);
+    const float4 h40 = ldu4((const GAS float*)H0_, off), h41 = ldu4((const GAS float*)H1_, off);
+    float4 bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[q] = ldu4((const GAS float*)Wh_, 4 * (min(16 * (4 * wid + q) + li, D - 1) * D + colc));
+    const LeanDa a = *ap;
+    lean_pin(a.dV, a.drp, a.seed, a.hidden_act, a.stream, a.ha_p0, a.ha_p1, a.drop_h, a.dbg);
+    LCLK_INIT(a.dbg, 32); LCLK(1);
+    float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < LN_SLB; ++q) {      // planes in fixed order
+        const float w = (q < ks) ? 1.f : 0.f;
+        dh.x = fmaf(w, v[q].x, dh.x); dh.y = fmaf(w, v[q].y, dh.y); dh.z = fmaf(w, v[q].z, dh.z); dh.w = fmaf(w, v[q].w, dh.w);
+    }
+    for (int k0 = LN_SLB; k0 < ks; k0 += LN_SLB) {      // more planes than one batch holds
+        float4 v2[LN_SLB];
+#pragma unroll
+        for (int q = 0; q < LN_SLB; ++q) v2[q] = ldu4(dsrc, off + (unsigned)min(k0 + q, ks - 1) * ps);
 #pragma unroll
         for (int q = 0; q < LN_SLB; ++q) {
             const float w = (k0 + q < ks) ? 1.f : 0.f;
-            dh.x = fmaf(w, v[q].x, dh.x); dh.y = fmaf(w, v[q].y, dh.y); dh.z = fmaf(w, v[q].z, dh.z); dh.w = fmaf(w, v[q].w, dh.w);
+            dh.x = fmaf(w, v2[q].x, dh.x); dh.y = fmaf(w, v2[q].y, dh.y); dh.z = fmaf(w, v2[q].z, dh.z); dh.w = fmaf(w, v2[q].w, dh.w);
         }
     }
+    LCLK_USE(dh.x); LCLK(2);
+    const LeanState sx = lean_state(mt);
+    const int M = sx.M;
+    if ((int)m0 >= M) return;
+    LCLK(3);
+    const float4 h4 = (sx.g & 1u) ? h41 : h40;
     if (a.drop_h > 0.f) {
-        const float4 mk = drop_mult4(a.seed, (unsigned)g, (unsigned)a.stream, row, colc >> 2, 1.0f - a.drop_h);
+        const float4 mk = drop_mult4(a.seed, sx.g, (unsigned)a.stream, row, colc >> 2, 1.0f - a.drop_h);
         dh.x *= mk.x; dh.y *= mk.y; dh.z *= mk.z; dh.w *= mk.w;
     }
     const bool ok = (int)row < M && colok;
     const float hh[4] = {h4.x, h4.y, h4.z, h4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w};
     const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, dd[4] = {dh.x, dh.y, dh.z, dh.w};
-    float da[4], dzp[4];
+    float da[4], dzp[4], ad[4];
+    if (a.hidden_act == G4R_ACT_TANH) {      // the default, kept out of the per-element switch
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ad[u] = 1.0f - cc[u] * cc[u];
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ad[u] = act_bwd_from_out(a.hidden_act, a.ha_p0, a.ha_p1, cc[u]);
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const float ad = act_bwd_from_out(a.hidden_act, a.ha_p0, a.ha_p1, cc[u]);
         const float dz = dd[u] * (cc[u] - hh[u]), dc = dd[u] * zz[u];
-        da[u] = ok ? dc * ad : 0.f;
+        da[u] = ok ? dc * ad[u] : 0.f;
         dzp[u] = ok ? dz * zz[u] * (1.f - zz[u]) : 0.f;
     }
     if (wid == 0 && ok) {
@@ -287,17 +380,30 @@ __global__ __launch_bounds__(512) void k_gru_da(const LeanDa* __restrict__ ap) {
         stu4(a.dV, ov, make_float4(da[0], da[1], da[2], da[3]));
         stu4(a.dV, ov + 8 * D, make_float4(dzp[0], dzp[1], dzp[2], dzp[3]));
     }
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc = mfma16(da[0], bq.x, acc);
-    acc = mfma16(da[1], bq.y, acc);
-    acc = mfma16(da[2], bq.z, acc);
-    acc = mfma16(da[3], bq.w, acc);
-    if (n < D) {
-        const unsigned ob = j * ps + 4 * ((m0 + 4 * lg) * D + n);
+    LCLK(4);
+    // the product TRANSPOSED (A = the Wh fragment, B = the da fragment: the same registers, operands swapped): a lane then holds four
+    // consecutive columns n = 16 tile + 4 lg .. of ONE batch row li -- one 16-byte store per tile instead of four scattered dwords
+    f32x4 acc[4];
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-            if ((int)(m0 + 4 * lg + rg) < M) stu(a.drp, ob + rg * 4 * D, acc[rg]);
+    for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = mfma16(bq[q].x, da[0], acc[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = mfma16(bq[q].y, da[1], acc[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = mfma16(bq[q].z, da[2], acc[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = mfma16(bq[q].w, da[3], acc[q]);
+    LCLK_USE(acc[0][0]); LCLK(5);
+    if ((int)row < M) {
+        const unsigned ob = j * ps + 4 * (row * D + 4 * lg);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned n = 16 * (4 * wid + q) + 4 * lg;      // (D is a multiple of 4: the four columns are inside or outside)
+            if (n < D) stu4(a.drp, ob + 64 * (4 * wid + q), make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]));
+        }
     }
+    LCLK(6);
 }
 
 // Backward, launch 2: dy tile = [da | dr' | dz'] Wx^T (K = 3 D), 16 rows x 16 input columns per workgroup, sixteen waves over K:
@@ -306,93 +412,110 @@ __global__ __launch_bounds__(512) void k_gru_da(const LeanDa* __restrict__ ap) {
 // writes it to dV[:, D:2D] for the dense-gradient tiles.  Epilogue (waves 0 .. 3, as k_gru_bwd_b): layer 0 embedding-dropout mask and the
 // Adagrad pieces dSx / dAx (or the accumulator in place for a single-occurrence item), else the lower layer's dh.
 #define LN_PL 8        // partial planes (= ceil(D / 16) <= 8)
-__global__ __launch_bounds__(1024) void k_gru_dy(const LeanDy* __restrict__ ap) {
+__global__ __launch_bounds__(1024) void k_gru_dy(const LeanDy* __restrict__ ap, const int* meta_, const int* occ_idx_, const float* dV_, const float* drp_,
+                                                 const float* Wx_, const float* r_, unsigned dims, unsigned B) {
     __shared__ float sJ[4 * 16 * 64];
-    const LeanDy a = *ap;
     const unsigned tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const unsigned wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned D = a.D, IN = a.IN, B = a.B, Dq = D >> 2, D3b = 12 * D;
-    const unsigned m0 = blockIdx.y * 16, row = m0 + li;
+    const unsigned D = dims & 0xFFFFu, IN = dims >> 16, Dq = D >> 2;
+    const unsigned m0 = blockIdx.y * 16, row = m0 + li, rowB = min(row, B - 1);
     const unsigned ncol = 16 * blockIdx.x + li, nc = min(ncol, IN - 1);
-    const GAS StepState* sg = a.st;
-    const long long g = sg->g_b;
-    const int M = sg->M_b;
-    // epilogue operands of waves 0 .. 3 (layer 0): item of the output row -> its accumulator element, its occurrence count
-    const unsigned rowe = m0 + 4 * lg + (wid & 3);
-    int itm = -1;
-    if (a.layer0 && wid < 4) itm = ldu_i(a.occ_idx, 4 * min(rowe, B - 1));
-    // role of the wave
-    const bool isr = wid >= 8;
-    const unsigned part = isr ? 1 : (wid >> 2) * 2;                  // 0 da, 1 dr', 2 dz'
-    const unsigned ss = isr ? wid - 8 : 2 * (wid & 3);               // first super-step inside the part
-    const unsigned Q0 = 4 * ss + lg, Q1 = Q0 + 4;
-    const bool ok0 = Q0 < Dq, ok1 = !isr && Q1 < Dq;
-    const unsigned Qa = ok0 ? Q0 : 0, Qb = ok1 ? Q1 : 0;
-    const unsigned offw = 4 * (nc * 3 * D + part * D);
-    const float4 b0 = ldu4(a.Wx, offw + 16 * Qa), b1 = ldu4(a.Wx, offw + 16 * Qb);
-    if ((int)m0 >= M) return;
-    const bool rowok = (int)row < M;
-    const unsigned rowc = min(row, (unsigned)(M - 1));
-    float4 a0, a1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!isr) {
-        const unsigned offa = 4 * (rowc * 3 * D + part * D);
-        a0 = ldu4(a.dV, offa + 16 * Qa);
-        a1 = ldu4(a.dV, offa + 16 * Qb);
+    const unsigned rowe = m0 + 4 * lg + (wid & 3);     // epilogue of waves 0 .. 3: component rg = wave
+    const GAS float* Wx = (const GAS float*)Wx_;
+    f32x4 acc;
+    int4 mt;
+    float a2 = 0.f;
+    int cnt2 = 0, itm = -1;
+    LeanState sx;
+    if (wid < 8) {
+        // ---- da / dz' part: A fragments straight from dV (k_gru_da wrote them)
+        if (wid < 4) itm = ldu_i((const GAS int*)occ_idx_, 4 * min(rowe, B - 1));      // epilogue (layer 0): item of the output row
+        mt = ldi4((const GAS int*)meta_);
+        const unsigned part = (wid >> 2) * 2;                   // 0 da, 2 dz'
+        const unsigned Q0 = 8 * (wid & 3) + lg, Q1 = Q0 + 4;    // two super-steps
+        const bool ok0 = Q0 < Dq, ok1 = Q1 < Dq;
+        const unsigned Qa = ok0 ? Q0 : 0, Qb = ok1 ? Q1 : 0;
+        const unsigned offw = 4 * (nc * 3 * D + part * D), offa = 4 * (rowB * 3 * D + part * D);
+        float4 a0 = ldu4((const GAS float*)dV_, offa + 16 * Qa), a1 = ldu4((const GAS float*)dV_, offa + 16 * Qb);
+        const float4 b0 = ldu4(Wx, offw + 16 * Qa), b1 = ldu4(Wx, offw + 16 * Qb);
+        const LeanDy a = *ap;
+        lean_pin(a.accT, a.occ_fl, a.n_items, a.layer0);
+        if (a.layer0 && wid < 4) {      // -> the item's accumulator element, its occurrence count
+            const unsigned ic = min((unsigned)max(itm, 0), (unsigned)a.n_items - 1);      // (rows past M hold an old id: clamped, unused)
+            a2 = a.accT[(size_t)ic * IN + nc];
+            cnt2 = a.occ_fl[4 * (size_t)ic + 2];
+        }
+        sx = lean_state(mt);
+        const bool rowok = (int)row < sx.M;
+        if (!(ok0 && rowok)) a0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(ok1 && rowok)) a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc0 = mfma16(a0.x, b0.x, acc0);
+        acc1 = mfma16(a0.y, b0.y, acc1);
+        acc0 = mfma16(a0.z, b0.z, acc0);
+        acc1 = mfma16(a0.w, b0.w, acc1);
+        acc0 = mfma16(a1.x, b1.x, acc0);
+        acc1 = mfma16(a1.y, b1.y, acc1);
+        acc0 = mfma16(a1.z, b1.z, acc0);
+        acc1 = mfma16(a1.w, b1.w, acc1);
+        acc = acc0 + acc1;
     } else {
-        const unsigned ps = 4 * B * D, off = 4 * (rowc * D + 4 * Qa), NTD = (D + 15) >> 4;
+        // ---- dr' part: planes of k_gru_da -> (sum) * H * r (1 - r)
+        mt = ldi4((const GAS int*)meta_);
+        const unsigned Q0 = 4 * (wid - 8) + lg;
+        const bool ok0 = Q0 < Dq;
+        const unsigned Qa = ok0 ? Q0 : 0;
+        const unsigned offr = 4 * (rowB * D + 4 * Qa), NTD = (D + 15) >> 4, ps = 4 * B * D;
         float4 pv[LN_PL];
 #pragma unroll
-        for (int q = 0; q < LN_PL; ++q) pv[q] = ldu4(a.drp, off + min((unsigned)q, NTD - 1) * ps);
-        const float4 h4 = ldu4((g & 1) ? a.H1 : a.H0, off), r4 = ldu4(a.r, off);
+        for (int q = 0; q < LN_PL; ++q) pv[q] = ldu4((const GAS float*)drp_, offr + min((unsigned)q, NTD - 1) * ps);
+        const float4 r4 = ldu4((const GAS float*)r_, offr);
+        const float4 b0 = ldu4(Wx, 4 * (nc * 3 * D + D) + 16 * Qa);
+        const LeanDy a = *ap;
+        lean_pin(a.H0, a.H1, a.dV);
+        const float4 h40 = ldu4(a.H0, offr), h41 = ldu4(a.H1, offr);
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < LN_PL; ++q) {      // plane order
             const float w = ((unsigned)q < NTD) ? 1.f : 0.f;
             s.x = fmaf(w, pv[q].x, s.x); s.y = fmaf(w, pv[q].y, s.y); s.z = fmaf(w, pv[q].z, s.z); s.w = fmaf(w, pv[q].w, s.w);
         }
+        sx = lean_state(mt);
+        const float4 h4 = (sx.g & 1u) ? h41 : h40;
         s.x *= h4.x * r4.x * (1.f - r4.x); s.y *= h4.y * r4.y * (1.f - r4.y);
         s.z *= h4.z * r4.z * (1.f - r4.z); s.w *= h4.w * r4.w * (1.f - r4.w);
-        a0 = s;
+        const bool rowok = (int)row < sx.M;
         if (blockIdx.x == 0 && ok0 && rowok) stu4(a.dV, 4 * (row * 3 * D + D + 4 * Qa), s);
+        if (!(ok0 && rowok)) s = make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc0 = mfma16(s.x, b0.x, acc0);
+        acc1 = mfma16(s.y, b0.y, acc1);
+        acc0 = mfma16(s.z, b0.z, acc0);
+        acc1 = mfma16(s.w, b0.w, acc1);
+        acc = acc0 + acc1;
     }
-    float a2 = 0.f;
-    int cnt2 = 0;
-    if (a.layer0 && wid < 4) {
-        if (!((int)rowe < M)) itm = -1;
-        a2 = a.accT[(size_t)max(itm, 0) * IN + nc];
-        cnt2 = a.occ_fl[4 * (size_t)max(itm, 0) + 2];
-    }
-    if (!(ok0 && rowok)) a0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!(ok1 && rowok)) a1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc0 = mfma16(a0.x, b0.x, acc0);
-    acc1 = mfma16(a0.y, b0.y, acc1);
-    acc0 = mfma16(a0.z, b0.z, acc0);
-    acc1 = mfma16(a0.w, b0.w, acc1);
-    if (!isr) {
-        acc0 = mfma16(a1.x, b1.x, acc0);
-        acc1 = mfma16(a1.y, b1.y, acc1);
-        acc0 = mfma16(a1.z, b1.z, acc0);
-        acc1 = mfma16(a1.w, b1.w, acc1);
-    }
-    const f32x4 acc = acc0 + acc1;
+    const int M = sx.M;
+    if ((int)m0 >= M) return;      // (uniform over the workgroup: no wave is left at the barrier)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) sJ[(rg * 16 + wid) * 64 + lane] = acc[rg];
     __syncthreads();
     if (wid >= 4) return;
+    const LeanDy a = *ap;
+    LCLK_INIT(a.dbg, 48); LCLK(6);
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) v += sJ[(wid * 16 + w) * 64 + lane];      // K slices in wave order
     if (ncol >= IN || (int)rowe >= M) return;
     const unsigned o = 4 * (rowe * IN + ncol);
     if (a.layer0) {
-        if (a.drop_e > 0.f) v *= drop_mult(a.seed, (unsigned)g, G4R_STREAM_DROP_EMBED, rowe, ncol, 1.0f - a.drop_e);
+        if (a.drop_e > 0.f) v *= drop_mult(a.seed, sx.g, G4R_STREAM_DROP_EMBED, rowe, ncol, 1.0f - a.drop_e);
         const float an = a2 + G4R_MUT_ACC(v * v);
-        GAS float* dSx = a.dSx + (size_t)(g & (long long)a.defer_mask) * (size_t)a.dSx_stride;
+        GAS float* dSx = a.dSx + (size_t)(sx.g & (unsigned)a.defer_mask) * (size_t)a.dSx_stride;
         stu(dSx, o, a.generic ? v : G4R_MUT_STEP(a.lr * v * frsq(an + G4R_EPS_ADAGRAD)));
         if (!a.generic && cnt2 == 1 && itm >= 0) a.accT[(size_t)itm * IN + ncol] = an;      // single occurrence: in place (see k_score_bwd)
         else stu(a.dAx, o, an);
     } else {
         stu(a.dylo, o, v);
     }
+    LCLK(7);
 }

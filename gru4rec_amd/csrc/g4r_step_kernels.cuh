@@ -46,6 +46,10 @@ __device__ __forceinline__ void stage_step_inputs(const DevModel& m, long long t
     GAS int *ci = m.cur_in, *cc = m.cur_col;
     const GAS unsigned char* rst = m.reset + t * B;      // (the plan carries one trailing, zeroed row)
     for (int b = tid; b < B; b += nth) { ci[b] = in[b]; ci[B + b] = rst[b]; }      // cur_in[B ..]: the step's reset flags (k_gru_h)
+    // cur_in[2 B ..]: the step's (t, g, M) once more, for kernels that take them with their first VECTOR loads: hipcc sinks a scalar
+    // load of the step state to its first use (behind the branches in front of it), where its 0.5 us of latency -- the state is
+    // rewritten every step -- is fully exposed (g4r_lean_kernels.cuh)
+    if (tid == 0) { ci[2 * B] = (int)(unsigned)g; ci[2 * B + 1] = (int)(g >> 32); ci[2 * B + 2] = M; ci[2 * B + 3] = (int)(unsigned)t; ci[2 * B + 4] = (int)(t >> 32); }
     // 8 columns per thread and pass, all loads of a pass in flight together (clamped addresses, selects afterwards)
     for (int base = 0; base < ld; base += 8 * nth) {
         int vo[8], vs[8];

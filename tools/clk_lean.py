@@ -16,6 +16,11 @@ for rep in range(5):
     m.train_steps(200 + rep, 1)
     R = 2 * cfg['batch_size'] + cfg['n_sample']
     raw = m.get_debug('dbgclk', (2 * (64 + 8 * R),)).view(np.int64)
-    v = raw[0:7]
-    print('k_gru_v wg(8,1) wave 0, us: B requests %.2f | state + publications %.2f | A requests %.2f | waits + MFMAs %.2f | barrier %.2f | join + epilogue %.2f | total %.2f' % (
-        *(np.diff(v) / 100.), (v[6] - v[0]) / 100.))
+    def show(name, v, idx):
+        v = np.asarray(v, dtype=np.int64)
+        t0 = v[idx[0]]
+        print('%-9s stamps (us after stamp %d): ' % (name, idx[0]) + '  '.join('[%d] %.2f' % (i, (v[i] - t0) / 100.) for i in idx[1:]))
+    show('k_gru_v', raw[0:16], [1, 2, 3, 4, 5, 6, 7])
+    show('k_gru_h', raw[16:32], [1, 2, 5, 6, 7])
+    show('k_gru_da', raw[32:48], [1, 2, 3, 4, 5, 6])
+    show('k_gru_dy', raw[48:64], [6, 7])
