@@ -36,7 +36,8 @@ COMMON_FLAGS = ['-mllvm', '-amdgpu-kernarg-preload-count=16']
 MUTANTS = {1: 'sparse accumulator increments x 1.01', 2: 'sparse Adagrad steps x 1.01', 3: 'dense accumulator increments x 1.01',
            4: "round 3's stale-register pipeline of gemm_tile2k (tied wait operands in two branches): fails the ISA audit, so it is the "
               "one library built with audit=False",
-           5: 'the 1 / nranks factor of the exact-replica joint update (REDUCE / MEAN forms) x 1.01'}
+           5: 'the 1 / nranks factor of the exact-replica joint update (REDUCE / MEAN forms) x 1.01',
+           6: 'the Adagrad step of ONE item row per step (the item of score column 0) x 1.5: a single wrong row must not pass'}
 
 
 def mutant_path(k):

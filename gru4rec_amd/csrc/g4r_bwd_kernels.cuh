@@ -60,7 +60,7 @@ __global__ __launch_bounds__(GT_NTH) void k_score_bwd(const DevModel* __restrict
         auto epi = [&](int n, int d, float g, float4 p) {
             if (n >= N || d > D) return;
             const float an = p.x + G4R_MUT_ACC(g * g);
-            float step = (p.y != 0.f) ? G4R_MUT_STEP(lr * g * frsq(an + G4R_EPS_ADAGRAD)) : 0.f;
+            float step = (p.y != 0.f) ? G4R_MUT_ROW(n, G4R_MUT_STEP(lr * g * frsq(an + G4R_EPS_ADAGRAD))) : 0.f;
             if (generic) step = (p.y != 0.f) ? g : 0.f;      // raw per-occurrence gradient: the update kernel applies the rule
             const bool single = !generic && p.y != 0.f && __float_as_int(p.z) == 1;
             const int item = single ? sIt[n - n0] : 0;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, G4R_BWD2_WPE) void k_score_bwd2(const DevModel
         auto epi = [&](int n, int d, float g, float4 p) {
             if (n >= N) return;
             const float an = p.x + G4R_MUT_ACC(g * g);
-            float step = (p.y != 0.f) ? G4R_MUT_STEP(lr * g * frsq(an + G4R_EPS_ADAGRAD)) : 0.f;
+            float step = (p.y != 0.f) ? G4R_MUT_ROW(n, G4R_MUT_STEP(lr * g * frsq(an + G4R_EPS_ADAGRAD))) : 0.f;
             if (generic) step = (p.y != 0.f) ? g : 0.f;
             dSy[(size_t)n * D + d] = step;
             if (!generic && p.y != 0.f && __float_as_int(p.z) == 1) accWy[(size_t)sIt[n - n0] * D + d] = an;

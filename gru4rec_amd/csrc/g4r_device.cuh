@@ -30,6 +30,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define G4R_MUT_DACC(x) (x)
 #endif
 
+#if defined(G4R_MUTATE) && G4R_MUTATE == 6      // the Adagrad step of ONE item row per step (the item of score column 0: the first target) x 1.5
+#define G4R_MUT_ROW(n, x) ((n) == 0 ? (x) * 1.5f : (x))
+#else
+#define G4R_MUT_ROW(n, x) (x)
+#endif
 #if defined(G4R_MUTATE) && G4R_MUTATE == 5      // the 1 / nranks factor of the exact-replica joint update (REDUCE / MEAN forms) x 1.01
 #define G4R_MUT_XSCALE(x) ((x) * 1.01f)
 #else

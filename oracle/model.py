@@ -424,13 +424,28 @@ class OracleGRU4Rec:
             lq = np.concatenate([self.lq_tgt[Yp[:M]], self.lq_smp[Yp[M:]]]).astype(self.dtype)
             s = s - dt(self.logq) * lq[None, :]
         s = s.astype(self.dtype)
+        # Scores on the KINK of a piecewise final activation (relu / leaky / elu / selu: T.switch(X >= 0), gru4rec.py:189-223): a
+        # score whose magnitude is within the fp32 rounding of its own terms (|s| <= kink_ulps * eps32 * (sum_k |h_k w_k| + |b|)) is
+        # positive in one summation order and negative in another, and its derivative takes either slope.  Test infrastructure:
+        # `kink_flip` makes this oracle take the OTHER slope on exactly those elements, so that a test can bound the rows they touch
+        # by the two runs instead of leaving them out (tests/test_gpu_parity.py: compare_params).
+        kmask = None
+        if str(self.final_act[0]) in ('relu', 'leaky', 'elu', 'selu') and (return_debug or getattr(self, 'kink_flip', False)):
+            terms = np.abs(y).astype(np.float64) @ np.abs(Sy).astype(np.float64).T + np.abs(SBy).astype(np.float64)[None, :]
+            if self.logq:
+                terms = terms + abs(float(self.logq)) * np.abs(lq).astype(np.float64)[None, :]
+            kmask = np.abs(s).astype(np.float64) <= float(getattr(self, 'kink_ulps', 4.0)) * float(np.finfo(np.float32).eps) * terms
         colmask = np.ones(N, dtype=bool)
         yhat = final_act_fwd(*self.final_act, s, colmask).astype(self.dtype)
         diag = np.arange(M)
         Lsum, dyhat = loss_fwd_bwd(self.loss, yhat, M, diag, colmask, self.bpreg, self.smoothing)
         cost = dt(Lsum) / dt(B)
         # ---- backward (T.grad, gru4rec.py:383-384)
-        ds = (final_act_bwd(*self.final_act, s, yhat, dyhat, colmask) / dt(B)).astype(self.dtype)
+        s_bwd = s
+        if kmask is not None and getattr(self, 'kink_flip', False) and kmask.any():
+            tiny = dt(np.finfo(np.float32).tiny)
+            s_bwd = np.where(kmask, np.where(s >= 0, -tiny, tiny), s).astype(self.dtype)      # the other branch of the switch
+        ds = (final_act_bwd(*self.final_act, s_bwd, yhat, dyhat, colmask) / dt(B)).astype(self.dtype)
         dSy = ds.T @ y
         dSBy = ds.sum(axis=0)
         dtop = ds @ Sy
@@ -462,7 +477,8 @@ class OracleGRU4Rec:
         dbg = None
         if return_debug:
             dbg = dict(Sx=Sx, Sy=Sy, s=s, yhat=yhat, ds=ds, dSy=dSy, dSBy=dSBy, dtop=dtop, dSx=dSx,
-                       caches=caches, dense_grads=dense_grads, Yp=Yp, cost=cost)
+                       caches=caches, dense_grads=dense_grads, Yp=Yp, cost=cost,
+                       kink_cols=(np.where(kmask.any(axis=0))[0] if kmask is not None else np.zeros(0, dtype=np.int64)))
         # data-parallel hook (not in the reference): all-reduce of the dense GRU gradients across ranks
         if getattr(self, 'dense_grad_hook', None) is not None:
             dense_grads = self.dense_grad_hook(dense_grads)

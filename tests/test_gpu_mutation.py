@@ -6,6 +6,8 @@ mutant; every one of those runs has to come back red, and the tensor it names ha
   mutant 2  every sparse Adagrad step x 1.01                             -> dWy / dBy (1 % of a step)
   mutant 3  every dense accumulator increment x 1.01                     -> acc_Wx / acc_Wh / ...
   mutant 5  the 1 / nranks factor of the exact-replica joint update x 1.01 -> the REDUCE / MEAN oracle-as-replicas tests
+  mutant 6  the Adagrad step of ONE item row per step x 1.5 (the item of score column 0) -> dWy: a single wrong row must fail, also in
+            the exact-shape tests that compare the rows of kink items apart (round 5 left those rows out; now they are bounded)
 
 (Round 2's `atol = 1e-4` on every tensor let an accumulator that is wrong by 100 x pass.)  The same selection runs green on the
 product library in the ordinary suite."""
@@ -27,7 +29,8 @@ SELECTION = ['tests/test_gpu_parity.py::test_first_step_intermediates[bprmax_elu
 # one step from zero accumulators: what must fail and what must still pass (p1 = the first-step test's tag)
 FIRST_STEP = {1: (('p1 acc_Wy', 'p1 acc_By'), ('p1 acc_Wx0', 'p1 acc_Wh0', 'p1 dWx0')),
               2: (('p1 dWy', 'p1 dBy'), ('p1 acc_Wy', 'p1 acc_By', 'p1 acc_Wx0', 'p1 dWx0')),
-              3: (('p1 acc_Wx0', 'p1 acc_Wh0', 'p1 acc_Wrz0', 'p1 acc_Bh0'), ('p1 acc_Wy', 'p1 acc_By', 'p1 dWy'))}
+              3: (('p1 acc_Wx0', 'p1 acc_Wh0', 'p1 acc_Wrz0', 'p1 acc_Bh0'), ('p1 acc_Wy', 'p1 acc_By', 'p1 dWy')),
+              6: (('p1 dWy',), ('p1 acc_Wy', 'p1 acc_By', 'p1 acc_Wx0', 'p1 dWx0'))}
 
 
 @pytest.fixture(scope='module')
