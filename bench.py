@@ -48,6 +48,10 @@ CONFIGS = {
     'cfg4s': dict(n_items=100000, layers=[256], batch_size=512, n_sample=8192, loss='bpr-max', final_act='elu-0.5',
                   bpreg=1.0, learning_rate=0.1, momentum=0.0, sample_alpha=0.75, logq=0.0, dropout_p_embed=0.0,
                   dropout_p_hidden=0.0, constrained_embedding=True),
+    # configs[3]'s shape over a catalogue that is built in seconds (2 GB table, 16 x the Infinity Cache): the large-catalogue legs of the default line
+    'cfg4m': dict(n_items=2000000, layers=[256], batch_size=512, n_sample=8192, loss='bpr-max', final_act='elu-0.5',
+                  bpreg=1.0, learning_rate=0.1, momentum=0.0, sample_alpha=0.75, logq=0.0, dropout_p_embed=0.0,
+                  dropout_p_hidden=0.0, constrained_embedding=True),
     # BASELINE.json configs[4]
     'cfg5': dict(n_items=37483, layers=[100, 100], batch_size=128, n_sample=2048, loss='top1-max', final_act='elu-0.5',
                  bpreg=1.0, learning_rate=0.1, momentum=0.0, sample_alpha=0.75, logq=0.0, dropout_p_embed=0.2,
@@ -75,6 +79,12 @@ def algorithmic_cost(cfg):
         'k_gru_bwd_pre': dict(bound='hbm', bytes=B * D * 4 * 6),
         'k_gru_bwd_a': dict(bound='mfma', flops=2.0 * B * D * D, bytes=B * D * 4 * 4 + D * D * 4),
         'k_gru_bwd_b': dict(bound='mfma', flops=2.0 * B * 3 * D * D, bytes=B * D * 4 * 4 + 3 * D * D * 4),
+        # round 6, narrow layers (g4r_lean_kernels.cuh): the forward as k_gru_v (V = [y | H] [Wx ; 0 | Wrz], r, Hr, z) + k_gru_h (candidate, h), the
+        # backward as k_gru_da (da, dz', K-slice planes of dr') + k_gru_dy (dy = dV Wx^T, Adagrad pieces of the input rows)
+        'k_gru_v': dict(bound='mfma', flops=2.0 * B * 5 * D * D, bytes=B * D * 4 * 6 + 5 * D * D * 4),
+        'k_gru_h': dict(bound='mfma', flops=2.0 * B * D * D, bytes=B * D * 4 * 6 + D * D * 4),
+        'k_gru_da': dict(bound='mfma', flops=2.0 * B * D * D, bytes=B * D * 4 * 6 + D * D * 4),
+        'k_gru_dy': dict(bound='mfma', flops=2.0 * B * 3 * D * D, bytes=B * D * 4 * 6 + 3 * D * D * 4),
         # the three stages above in one launch (stage 0 / 1 are repeated by the column tiles of a row block: not counted)
         'k_gru_bwd': dict(bound='mfma', flops=2.0 * B * 4 * D * D, bytes=B * D * 4 * 10 + 4 * D * D * 4),
         'k_dense_grad': dict(bound='mfma', flops=2.0 * B * 6 * D * D, bytes=B * D * 4 * 6 + 3 * 6 * D * D * 4),
@@ -105,7 +115,7 @@ def rocprof_means(config):
     if not os.path.exists(path):
         return {}
     out = {'__file__': os.path.relpath(path, ROOT)}
-    alias = {'k_gru_fwd_fused': 'k_gru_fwd', 'k_gru_bwd_fused': 'k_gru_bwd', 'k_score_bwd2': 'k_score_bwd', 'k_gru_p1w': 'k_gru_p1', 'k_gru_p1s': 'k_gru_p1', 'k_gru_p2w': 'k_gru_p2',
+    alias = {'k_score_s': 'k_score_fwd', 'k_score_b': 'k_score_bwd', 'k_gru_fwd_fused': 'k_gru_fwd', 'k_gru_bwd_fused': 'k_gru_bwd', 'k_score_bwd2': 'k_score_bwd', 'k_gru_p1w': 'k_gru_p1', 'k_gru_p1s': 'k_gru_p1', 'k_gru_p2w': 'k_gru_p2',
              'k_gru_bwd_aw': 'k_gru_bwd_a', 'k_gru_bwd_bw': 'k_gru_bwd_b', 'k_dense_grad2': 'k_dense_grad'}
     acc = {}
     for r in csv.DictReader(open(path)):
@@ -239,11 +249,37 @@ def cpu_baseline(cfg, plan, support, budget_s=15.0):
         dt = time.time() - t0
         if n:
             wins.append((n / dt, n, ev, dt))
+    if not wins:      # (a plan too short for a single step per window)
+        return dict(value=0.0, unit='mini-batches/s', cores=int(threads), kind='port', sample='no step ran (plan of %d steps)' % plan['T'], host_cpus=os.cpu_count())
     best = max(wins)
     return dict(value=best[0], unit='mini-batches/s', cores=int(threads), kind='port',
                 sample='best of %d windows of %.0f s: %d steps (%d events) of the same plan, NumPy/BLAS fp32 oracle, %.1f s; all windows: %s' % (
                     len(wins), budget_s / 3.0, best[1], best[2], best[3], ', '.join('%.1f' % w[0] for w in wins)),
                 events_per_s=best[2] / best[3], host_cpus=os.cpu_count())
+
+
+def large_catalogue_legs(timeout=150):
+    """`bench.py --config cfg4m` without / with --defer in child processes -> {'immediate': {...}, 'deferred': {...}} (mini-batches/s, us per
+    step, the update launch, and for the deferred run the flush launch priced on the bytes it moves)."""
+    import subprocess
+    res = {'config': 'cfg4m: B = 512, n_sample = 8192, layers = [256], BPR-max over a 2,000,000-item catalogue (item table 2 GB + 2 GB accumulators)'}
+    for key, extra in (('immediate', []), ('deferred', ['--defer'])):
+        cmd = [sys.executable, os.path.abspath(__file__), '--config', 'cfg4m', '--steps', '600', '--warmup', '100', '--profile-steps', '128', '--long-steps', '0',
+               '--no-cpu-baseline', '--no-micro', '--no-defer-leg'] + extra
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            if not line:
+                res[key] = {'error': (r.stderr or r.stdout)[-300:]}
+                continue
+            o = json.loads(line[-1])
+            g = o.get('roofline_gather_scatter') or {}
+            res[key] = {'value': o['value'], 'unit': o['unit'], 'us_per_step': 1000.0 * o['ms_per_step'], 'steps': o['steps'],
+                        'update_launch': {'kernel': g.get('kernel'), 'avg_us': g.get('avg_us'), 'frac_of_8TBps_on_survey_8d_bytes': g.get('frac')},
+                        'deferred_flush': g.get('deferred_flush')}
+        except Exception as e:      # noqa: BLE001
+            res[key] = {'error': '%s: %s' % (type(e).__name__, e)}
+    return res
 
 
 def main():
@@ -262,6 +298,8 @@ def main():
                     'item rows + reconciliation: per-occurrence gradient rows all-gathered every step, nothing to reconcile')
     ap.add_argument('--session-items', type=int, default=0, help='distinct items the synthetic sessions are drawn from (0 = the whole catalogue of the '
                     'config; rounds 1-3 used 200000 for cfg3 / cfg4)')
+    ap.add_argument('--no-defer-leg', action='store_true', help='default line only: skip the two short large-catalogue legs (BASELINE configs[3] shape over a '
+                    '2 M-item catalogue, without / with deferred row updates) that fill roofline_gather_scatter.deferred_flush and large_catalogue')
     ap.add_argument('--long-steps', type=int, default=2000, help='a run of --steps below this also times that many steps behind the timed region and '
                     'reports them as "long_run" (a 20-step window is ~1 ms; 0 = off)')
     args = ap.parse_args()
@@ -678,6 +716,15 @@ def main():
                     micro.append({'mode': name, 'rows_per_launch': R * mult, 'steps_batched': mult, 'width': W, 'table_GB': n_big * W * 4 / 1e9 * (2 if mode == 2 else 1),
                                   'kernel_us': k_us, 'GBps': nb / k_us / 1e3, 'frac_of_8TBps': nb / k_us / 1e3 / 8000.0})
             out['gather_scatter_micro'] = micro
+        if args.config == 'cfg2' and not args.no_defer_leg and not args.defer and not args.no_cpu_baseline and 'roofline_gather_scatter' in out:
+            # The embedding gather / scatter at the sizes where it IS bound by the HBM (north_star's >= 60 % claim): BASELINE configs[3]'s shape
+            # over a 2 M-item catalogue (2 GB table + 2 GB of accumulators: 16 x the Infinity Cache; the full 10 M-item catalogue costs a
+            # minute of host-side weight initialisation, tools/final_profile.sh runs it), once without and once with deferred row updates,
+            # in child processes (their failure must not take this line down).  ~20 s each.
+            out['large_catalogue'] = large_catalogue_legs()
+            fl = (out['large_catalogue'].get('deferred') or {}).get('deferred_flush')
+            if fl:
+                out['roofline_gather_scatter']['deferred_flush'] = dict(fl, config='cfg4m: BASELINE configs[3] shape (B = 512, 8192 negatives, D = 256) over a 2 M-item catalogue')
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, plan, support)
     barrier()

@@ -32,26 +32,47 @@ static int build_lean_args(g4r_model* m) {
         v.cur_in = d.cur_in; v.Vc = d.Vc[l]; v.r = d.r[l]; v.Hr = d.Hr[l]; v.z = d.z[l]; v.yin0 = d.yin0;
         v.occ_idx = d.occ_idx; v.occ_fl = d.occ_fl + 4 * (constrained ? (size_t)0 : (size_t)d.n_items);
         v.st = d.st; v.seed = d.seed; v.B = d.B; v.D = d.D[l]; v.IN = d.IN[l]; v.R = d.R; v.first = (l == 0) ? 1 : 0; v.pub_fl = d.xmode == 0 ? 1 : 0;
-        v.drop_e = d.drop_e; v.dbg = d.dbgclk; v.n_items = d.n_items;
+        v.drop_e = d.drop_e; v.dbg = d.dbgclk; v.dbgtile = d.dbgtile; v.n_items = d.n_items;
         LeanH& h = ah[l]; memset(&h, 0, sizeof(h));
         h.Wh = d.dense_p + d.offWh[l]; h.H0 = d.H[l][0]; h.H1 = d.H[l][1]; h.Hr = d.Hr[l]; h.Vc = d.Vc[l]; h.z = d.z[l];
         h.cur_rst = d.cur_in + d.B; h.c = d.c[l]; h.hd = d.hd[l]; h.st = d.st; h.seed = d.seed; h.B = d.B; h.D = d.D[l];
-        h.hidden_act = d.hidden_act; h.stream = (int)(G4R_STREAM_DROP_HIDDEN + (unsigned)l); h.ha_p0 = d.ha_p0; h.ha_p1 = d.ha_p1; h.drop_h = d.drop_h; h.dbg = d.dbgclk;
+        h.hidden_act = d.hidden_act; h.stream = (int)(G4R_STREAM_DROP_HIDDEN + (unsigned)l); h.ha_p0 = d.ha_p0; h.ha_p1 = d.ha_p1; h.drop_h = d.drop_h; h.dbg = d.dbgclk; h.dbgtile = d.dbgtile;
         LeanDa& q = aa[l]; memset(&q, 0, sizeof(q));
         q.Wh = h.Wh; q.H0 = h.H0; q.H1 = h.H1; q.z = d.z[l]; q.c = d.c[l];
         if (l == L - 1) { q.dsrc = d.dhpart; q.ks = d.ksplit; }
         else if (d.bbn[l + 1] > 0) { q.dsrc = d.dyp; q.ks = d.bbn[l + 1]; }
         else { q.dsrc = d.dyl[l]; q.ks = 1; }
         q.dV = d.dV[l]; q.drp = d.drp; q.st = d.st; q.seed = d.seed; q.B = d.B; q.D = d.D[l]; q.hidden_act = d.hidden_act; q.stream = h.stream;
-        q.ha_p0 = d.ha_p0; q.ha_p1 = d.ha_p1; q.drop_h = d.drop_h; q.dbg = d.dbgclk;
+        q.ha_p0 = d.ha_p0; q.ha_p1 = d.ha_p1; q.drop_h = d.drop_h; q.dbg = d.dbgclk; q.dbgtile = d.dbgtile;
         LeanDy& y = ay[l]; memset(&y, 0, sizeof(y));
         y.Wx = v.Wx; y.H0 = h.H0; y.H1 = h.H1; y.r = d.r[l]; y.drp = d.drp; y.dV = d.dV[l]; y.occ_idx = d.occ_idx; y.occ_fl = v.occ_fl;
         y.accT = constrained ? d.accWy : d.accE; y.dSx = d.dSx; y.dAx = d.dAx; y.dylo = (l > 0) ? d.dyl[l - 1] : nullptr;
         y.st = d.st; y.seed = d.seed; y.dSx_stride = d.dSx_stride; y.B = d.B; y.D = d.D[l]; y.IN = d.IN[l]; y.layer0 = (l == 0) ? 1 : 0;
-        y.generic = d.generic; y.defer_mask = d.defer_mask; y.lr = d.lr; y.drop_e = d.drop_e; y.dbg = d.dbgclk; y.n_items = d.n_items;
+        y.generic = d.generic; y.defer_mask = d.defer_mask; y.lr = d.lr; y.drop_e = d.drop_e; y.dbg = d.dbgclk; y.dbgtile = d.dbgtile; y.n_items = d.n_items;
+    }
+    if (lean_scores(d)) {
+        LeanS q; memset(&q, 0, sizeof(q));
+        q.col_item = d.col_item; q.occ_idx = d.occ_idx + d.B; q.occ_fl = d.occ_fl; q.mp = nullptr; q.dbg = d.dbgclk; q.dbgtile = d.dbgtile; q.R = d.R; q.pub_fl = d.xmode == 0 ? 1 : 0; q.logq = d.logq;
+        m->h_leanS = q;
+        any = true;
+    }
+    if (lean_score_bwd(d)) {
+        LeanB q; memset(&q, 0, sizeof(q));
+        q.accBy = d.accBy; q.occ_fl = d.occ_fl; q.dSy = d.dSy; q.dAy = d.dAy; q.dSBy = d.dSBy; q.dABy = d.dABy; q.dhpart = d.dhpart; q.dbg = d.dbgclk; q.dbgtile = d.dbgtile;
+        q.dSy_stride = d.dSy_stride; q.dSBy_stride = d.dSBy_stride; q.defer_mask = d.defer_mask; q.generic = d.generic;
+        q.ndh = cdiv(d.Dtop + 1, 64); q.nA = cdiv(d.ldSc, 16) * q.ndh; q.nrb = cdiv(d.B, 16); q.ndb = cdiv(d.Dtop, 64); q.lr = d.lr;
+        m->h_leanB = q;
     }
     m->h_leanV = av; m->h_leanH = ah; m->h_leanDa = aa; m->h_leanDy = ay;      // (host copies: launch_step passes their hot fields as kernel arguments)
     if (!any) return 0;
+    if (lean_score_bwd(d)) {
+        if (dalloc(m, &m->d_leanB, (size_t)1)) return -1;
+        HIPCHK(hipMemcpyAsync(m->d_leanB, &m->h_leanB, sizeof(LeanB), hipMemcpyHostToDevice, m->stream));
+    }
+    if (lean_scores(d)) {
+        if (dalloc(m, &m->d_leanS, (size_t)1)) return -1;
+        m->h_leanS.mp = nullptr;      // (set below: the descriptor is allocated after this function)
+    }
     if (dalloc(m, &m->d_leanV, (size_t)L) || dalloc(m, &m->d_leanH, (size_t)L) || dalloc(m, &m->d_leanDa, (size_t)L) || dalloc(m, &m->d_leanDy, (size_t)L)) return -1;
     HIPCHK(hipMemcpyAsync(m->d_leanV, av.data(), L * sizeof(LeanV), hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemcpyAsync(m->d_leanH, ah.data(), L * sizeof(LeanH), hipMemcpyHostToDevice, m->stream));
@@ -242,6 +263,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
                 if (waste < best) { best = waste; d.kch = kch; }
             }
         }
+        if (lean_score_bwd(d)) d.kch = 128;      // k_score_b: slabs of 128 score columns (eight waves x 16)
         d.ksplit = cdiv(d.ldSc, d.kch);
         DA(d.dhpart, (size_t)d.ksplit * B * d.Dtop);
         const int TB = wide_scores(d) ? 64 : 32;      // tile edge of k_score_bwd
@@ -427,6 +449,10 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     }
     if (build_lean_args(m)) { g4r_destroy(m); return -1; }
     if (dalloc(m, &m->d_dm, 1) || sync_dm(m)) { g4r_destroy(m); return -1; }
+    if (m->d_leanS) {
+        m->h_leanS.mp = m->d_dm;
+        if (hipMemcpyAsync(m->d_leanS, &m->h_leanS, sizeof(LeanS), hipMemcpyHostToDevice, m->stream) != hipSuccess || hipStreamSynchronize(m->stream) != hipSuccess) { g4r_destroy(m); return fail("lean args upload"); }
+    }
     *out = m;
     return 0;
 }

@@ -67,12 +67,16 @@ struct g4r_model {
     WideGeo wg[G4R_MAX_LAYERS];
     bool wide_dense = false;
     bool defer_on = false;       // deferred row updates (k_defer_scan / k_sparse_flush around every replay of the step graph)
+    bool defer_broken = false;   // a call failed between a window's scan and its flush: pending row updates were lost, the handle refuses to go on
     hipEvent_t ev_df[4] = {nullptr, nullptr, nullptr, nullptr};      // profiling: scan / flush launches of a window
     DenseTile* d_tiles64 = nullptr;
     int ntiles64 = 0;
     float* d_tmpH = nullptr;
     // graph
+    LeanS h_leanS;
     std::vector<LeanV> h_leanV; std::vector<LeanH> h_leanH; std::vector<LeanDa> h_leanDa; std::vector<LeanDy> h_leanDy;
+    LeanS* d_leanS = nullptr;      // argument block of k_score_s
+    LeanB* d_leanB = nullptr; LeanB h_leanB;      // argument block of k_score_b
     LeanV* d_leanV = nullptr; LeanH* d_leanH = nullptr; LeanDa* d_leanDa = nullptr; LeanDy* d_leanDy = nullptr;      // [layers] argument blocks (g4r_lean_kernels.cuh)
     hipGraphExec_t gexec = nullptr;
     hipGraphExec_t gexec_small = nullptr;        // single GPU: G4R_GRAPH_STEPS_SMALL steps, for what a run leaves after the big replays
@@ -233,6 +237,14 @@ static inline bool score_fwd_dma(const DevModel& d) {
     return wide_scores(d) || (d.Dtop >= 256 && d.B >= 64 && d.ldSc >= 1024);
 }
 static const size_t SMEM_SF = tile_smem<SF_BM, GT_BN, GT_BK, false, true>() + GT_BN * sizeof(int);
+// scoring forward as register-fed 32 x 32 tiles (k_score_s, g4r_lean_kernels.cuh): narrow top layers at RSC15-like sizes, i.e. where the
+// LDS-staged 64 x 32 tiles of k_score_fwd ran (neither the wide-score nor the LDS-DMA tiles apply).  G4R_NO_LEAN=1: off.
+static inline bool lean_scores(const DevModel& d) {
+    static const bool off = getenv("G4R_NO_LEAN") != nullptr;
+    return !off && d.Dtop <= LN_MAXD && d.Dtop % 4 == 0 && !wide_scores(d) && !score_fwd_dma(d) && d.B < 65536 && d.ldSc < 65536;
+}
+// ... and the scoring backward as k_score_b (eight waves over a K of <= 128 batch rows / 128-column slabs)
+static inline bool lean_score_bwd(const DevModel& d) { return lean_scores(d) && d.B <= 128; }
 static const size_t SMEM_T2K = (size_t)(4 * 64 * 16) * sizeof(float);                               // gemm_tile2k: two 16-deep buffers per operand
 static const size_t SMEM_T3 = (size_t)Tile3Cfg<3, 32>::SMEM_FLOATS * sizeof(float);                 // gemm_tile3: ring of three 32-deep stages
 // publish the host descriptor to the device copy (stream-ordered; pageable source is staged before return)

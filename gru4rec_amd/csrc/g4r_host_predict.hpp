@@ -148,7 +148,9 @@ static int predict_forward(g4r_model* m, const int* d_in_idx, int mrows, const i
                                (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, 0, pa);
         {
             const dim3 g2(cdiv(d.D[l], GT_BN), cdiv(mrows, GT_BM));
-            if (deep_geometry(m->p2_geo_env, m->n_cu, d.D[l], mrows))
+            // (geometry from the TRAINING batch, not from this call's rows: the fp32 summation order of the hidden state must not depend
+            // on the evaluation batch size, nor differ between training and prediction)
+            if (deep_geometry(m->p2_geo_env, m->n_cu, d.D[l], d.B))
                 hipLaunchKernelGGL(k_gru_p2_w8d, g2, dim3(512), SMEM_P2_256, m->stream, (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, pa);
             else hipLaunchKernelGGL(k_gru_p2_w4, g2, dim3(GT_NTH), SMEM_NN, m->stream, (const DevModel*)m->d_dm, (StepState*)nullptr, l, 0, pa);
         }

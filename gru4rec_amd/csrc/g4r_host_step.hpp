@@ -101,7 +101,14 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         end();
     }
     begin(KN_SCORE_FWD);
-    if (score_fwd_dma(d)) LK(k_score_fwd_t3, dim3(cdiv(d.ldSc, 64), cdiv(B, 64)), dim3(GT_NTH), SMEM_SF3, s, dmp, stp);
+    if (lean_scores(d)) {
+        const unsigned dimsA = (unsigned)d.Dtop | ((unsigned)B << 16), dimsB = (unsigned)d.N | ((unsigned)d.ldSc << 16);
+        const dim3 gs(cdiv(d.ldSc, 32), cdiv(B, 32));
+        if (d.logq != 0.f) LK(k_score_s<true>, gs, dim3(256), 0, s, (const LeanS*)m->d_leanS, (const int*)(d.cur_in + 2 * B), (const int*)d.cur_col, (const float*)d.hd[L - 1],
+                              (const float*)d.Wy, (const float*)d.By, (float*)d.Sc, dimsA, dimsB);
+        else LK(k_score_s<false>, gs, dim3(256), 0, s, (const LeanS*)m->d_leanS, (const int*)(d.cur_in + 2 * B), (const int*)d.cur_col, (const float*)d.hd[L - 1],
+                (const float*)d.Wy, (const float*)d.By, (float*)d.Sc, dimsA, dimsB);
+    } else if (score_fwd_dma(d)) LK(k_score_fwd_t3, dim3(cdiv(d.ldSc, 64), cdiv(B, 64)), dim3(GT_NTH), SMEM_SF3, s, dmp, stp);
     else if (wide_scores(d) && score_tile2() && d.Dtop % T2_BK == 0) LK(k_score_fwd_t2, dim3(cdiv(d.ldSc, 64), cdiv(B, 64)), dim3(GT_NTH), SMEM_SF2, s, dmp, stp);
     else if (wide_scores(d)) LK(k_score_fwd_k64, dim3(cdiv(d.ldSc, SFW_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF64, s, dmp, stp);
     else LK(k_score_fwd_k128, dim3(cdiv(d.ldSc, GT_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF, s, dmp, stp);
@@ -125,7 +132,11 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     }
     end();
     begin(KN_SCORE_BWD);
-    if (score_bwd2(d)) {
+    if (lean_score_bwd(d)) {
+        const LeanB& q = m->h_leanB;
+        LK(k_score_b, dim3(q.nA + d.ksplit * q.nrb * q.ndb), dim3(512), 0, s, (const LeanB*)m->d_leanB, (const int*)(d.cur_in + 2 * B), (const int*)d.cur_col,
+           (const float*)d.Sc, (const float*)d.hd[L - 1], (const float*)d.Wy, (float*)d.accWy, (unsigned)d.Dtop | ((unsigned)B << 16), (unsigned)d.N | ((unsigned)d.ldSc << 16));
+    } else if (score_bwd2(d)) {
         const int ndt = d.Dtop / 64, nrt = cdiv(B, 64);
         int nA = cdiv(d.ldSc, 64) * ndt, nB = d.ksplit * nrt * ndt, nC = cdiv(d.ldSc, 64);
         LK(k_score_bwd2, dim3(nA + nB + nC), dim3(GT_NTH), (size_t)(4 * 64 * 16) * sizeof(float) + (size_t)std::max(d.kch, 64) * sizeof(int), s, dmp, stp, nA, nB, ndt, nrt);
@@ -391,6 +402,13 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
     if (!m->d_in) return fail("no plan uploaded");
     if (t0 < 0 || n_steps < 0 || t0 + n_steps > m->T) return fail("step range outside the plan");
     if (m->dm.ns > 0 && !m->have_pop && !m->store_frozen) return fail("negative sampling needs g4r_set_popularity first");
+    if (m->defer_on) {
+        // k_defer_scan keys its newest-use table by the low 32 bits of the global step (signed atomicMax): refuse before they wrap
+        // (27 h of training at 22 K steps/s on one handle; g4r_set_step_counters rebases the step and clears the table)
+        if (m->gstep + n_steps >= ((int64_t)1 << 31) - 64) return fail("deferred row updates: the global step would pass 2^31 -- rebase it with g4r_set_step_counters (epoch boundary) or create the model without defer_updates");
+        if (m->defer_broken) return fail("deferred row updates: an earlier call failed between a window's scan and its flush launch; the row updates pending then are lost -- recreate the model");
+    }
+    struct WindowGuard { g4r_model* m; bool open = false; ~WindowGuard() { if (open) m->defer_broken = true; } } wguard{m};
     HIPCHK(hipSetDevice(m->cfg.device));
     hipLaunchKernelGGL(k_set_state, dim3(1), dim3(512), 0, m->stream, (const DevModel*)m->d_dm, (StepState*)m->dm.st, (long long)t0, (long long)m->gstep);
     bool use_graph = m->cfg.use_graph && !m->profiling && !getenv("G4R_TRACE") && (m->dm.apply_dense_inplace || dist_graph_wanted(m));
@@ -426,6 +444,7 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
         // a deferral window around `nw` steps starting `done` steps into this run: which rows may wait (scan), ... steps ..., their flush
         auto window_open = [&](int64_t nw) {
             if (!m->defer_on) return;
+            wguard.open = true;
             const dim3 gs(cdiv(nw * m->dm.R, 256));
             if (m->profiling) (void)hipEventRecord(m->ev_df[0], m->stream);
             hipLaunchKernelGGL(k_defer_scan, gs, dim3(256), 0, m->stream, (const DevModel*)m->d_dm, (long long)(t + done), (long long)(m->gstep + done), (int)nw, 0);
@@ -443,6 +462,7 @@ int g4r_train_steps(g4r_model* m, int64_t t0, int64_t n_steps) {
                 if (hipEventElapsedTime(&ms, m->ev_df[0], m->ev_df[1]) == hipSuccess) { m->kn_ms[KN_SCAN] += ms; m->kn_n[KN_SCAN]++; }
                 if (hipEventElapsedTime(&ms, m->ev_df[2], m->ev_df[3]) == hipSuccess) { m->kn_ms[KN_FLUSH] += ms; m->kn_n[KN_FLUSH]++; }
             }
+            wguard.open = false;
             return 0;
         };
         if (use_graph && run >= G4R_GRAPH_STEPS_SMALL) {

@@ -42,10 +42,16 @@ __device__ __forceinline__ void stu4(GAS float* base, unsigned boff, float4 v) {
 #define LCLK_INIT(dbgp, slot) GAS long long* clk_ = ((dbgp) && blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && threadIdx.x == 0) ? (dbgp) + (slot) : nullptr
 #define LCLK(i) do { if (clk_) clk_[i] = wall_clock64(); } while (0)
 #define LCLK_USE(x) do { if (clk_ && (x) == 123.456f) clk_[15] = 0; } while (0)
+// every workgroup's (first stamp, last stamp) -> dbgtile[base + linear workgroup id] (tools/clk_lean.py: the launch's span on the wall clock)
+#define LSPAN_BEGIN(tilep, base) GAS long long* span_ = ((tilep) && threadIdx.x == 0) ? (tilep) + 8 * (size_t)((base) + (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) : nullptr; \
+    if (span_) span_[0] = wall_clock64()
+#define LSPAN_END() do { if (span_) span_[1] = wall_clock64(); } while (0)
 #else
 #define LCLK_INIT(dbgp, slot)
 #define LCLK(i)
 #define LCLK_USE(x)
+#define LSPAN_BEGIN(tilep, base)
+#define LSPAN_END()
 #endif
 
 // argument blocks (device resident, one per layer; g4r_host_create.hpp: build_lean_args).  Pointers only to buffers that live as long as the model.
@@ -60,7 +66,7 @@ struct LeanV {
     int B, D, IN, R, first, pub_fl;
     float drop_e;
     int n_items;
-    GP(long long) dbg;
+    GP(long long) dbg; GP(long long) dbgtile;
 };
 struct LeanH {
     GP(const float) Wh; GP(const float) H0; GP(const float) H1; GP(const float) Hr; GP(const float) Vc; GP(const float) z;
@@ -70,7 +76,7 @@ struct LeanH {
     unsigned long long seed;
     int B, D, hidden_act, stream;
     float ha_p0, ha_p1, drop_h, pad;
-    GP(long long) dbg;           // phase stamps (G4R_CLK builds)
+    GP(long long) dbg; GP(long long) dbgtile;           // phase stamps (G4R_CLK builds)
 };
 struct LeanDa {
     GP(const float) Wh; GP(const float) H0; GP(const float) H1; GP(const float) z; GP(const float) c;
@@ -80,7 +86,7 @@ struct LeanDa {
     unsigned long long seed;
     int B, D, ks, hidden_act, stream, pad0;      // ks: planes of dsrc to add (1: dsrc is dh itself)
     float ha_p0, ha_p1, drop_h, pad;
-    GP(long long) dbg;
+    GP(long long) dbg; GP(long long) dbgtile;
 };
 struct LeanDy {
     GP(const float) Wx; GP(const float) H0; GP(const float) H1; GP(const float) r; GP(const float) drp;
@@ -91,8 +97,24 @@ struct LeanDy {
     long long dSx_stride;
     int B, D, IN, layer0, generic, defer_mask;
     float lr, drop_e;
-    GP(long long) dbg;
+    GP(long long) dbg; GP(long long) dbgtile;
     int n_items, pad;
+};
+
+struct LeanS {
+    GP(int) col_item; GP(int) occ_idx; GP(int) occ_fl;      // occ_idx: at the Y | samples part (offset B); occ_fl: the Wy / By table's block
+    const DevModel* mp;                                         // (the logQ tables are set after g4r_create: read through the descriptor)
+    GP(long long) dbg; GP(long long) dbgtile;
+    int R, pub_fl;
+    float logq, pad;
+};
+
+struct LeanB {
+    GP(float) accBy; GP(const int) occ_fl; GP(float) dSy; GP(float) dAy; GP(float) dSBy; GP(float) dABy; GP(float) dhpart;
+    GP(long long) dbg; GP(long long) dbgtile;
+    long long dSy_stride, dSBy_stride;
+    int defer_mask, generic, nA, ndh, nrb, ndb;      // nA: role A workgroups; ndh: 64-wide d blocks of role A (D + 1 columns); role B: nrb row blocks x ndb d blocks per slab
+    float lr, pad;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -113,6 +135,16 @@ template <typename T> __device__ __forceinline__ void lean_pin1(T v) {
 #endif
 }
 template <typename... T> __device__ __forceinline__ void lean_pin(T... v) { (lean_pin1(v), ...); }
+// A value that must be COMPLETE here (not recomputed inside a later branch).  On gfx9 / CDNA stores count against vmcnt like loads: when
+// hipcc sinks the last use of a loaded operand into each of several conditional store blocks, every block gets its own
+// `s_waitcnt vmcnt(0)` -- which, from the second block on, waits for the previous block's STORE to be acknowledged: the stores of an
+// epilogue then go out one memory round trip apart (4 conditional row stores: +1.5 us; found in round 6, profiles/r06_experiments.md).
+// Computing the stored values first and pinning them keeps the blocks free of waits.
+__device__ __forceinline__ void lean_keep(float& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#endif
+}
 struct LeanState { unsigned g; int M; unsigned t_lo; };
 // staged (g lo, g hi, M, t lo, t hi) -> wave-uniform registers (every lane loaded the same 16 bytes)
 __device__ __forceinline__ LeanState lean_state(int4 mt) {
@@ -163,6 +195,7 @@ __global__ __launch_bounds__(512) void k_gru_v(const LeanV* __restrict__ ap, Ste
     const LeanV a = *ap;
     lean_pin(a.Bh, a.ysrc, a.Vc, a.r, a.Hr, a.z, a.yin0, a.occ_idx, a.occ_fl, a.seed, a.R, a.first, a.pub_fl, a.drop_e, a.n_items, a.dbg);
     LCLK_INIT(a.dbg, 0); LCLK(1);
+    LSPAN_BEGIN(a.dbgtile, 1024);
     const float bias = ldu(a.Bh, 4 * (part * D + nc));
     float4 ay;
     if (L0) ay = ld4(a.ysrc + (size_t)min((unsigned)max(item, 0), (unsigned)a.n_items - 1) * IN + 4 * Qy);      // (rows past M hold any staged id: clamped, masked below)
@@ -229,6 +262,7 @@ __global__ __launch_bounds__(512) void k_gru_v(const LeanV* __restrict__ ap, Ste
     else if (part == 1) { const float rr = sigmoidf_(v); stu(a.r, o, rr); stu(a.Hr, o, hep * rr); }
     else stu(a.z, o, sigmoidf_(v));
     LCLK(7);
+    LSPAN_END();
 }
 
 // (hipcc emits the device code of a __global__ template only for explicit instantiations)
@@ -265,6 +299,7 @@ __global__ __launch_bounds__(512) void k_gru_h(const LeanH* __restrict__ ap, con
     const LeanH a = *ap;
     lean_pin(a.c, a.hd, a.seed, a.hidden_act, a.stream, a.ha_p0, a.ha_p1, a.drop_h, a.dbg);
     LCLK_INIT(a.dbg, 16); LCLK(1);
+    LSPAN_BEGIN(a.dbgtile, 1280);
     const LeanState sx = lean_state(mt);
     const int M = sx.M;
     if ((int)m0 >= M) return;
@@ -297,6 +332,7 @@ __global__ __launch_bounds__(512) void k_gru_h(const LeanH* __restrict__ ap, con
     stu(a.hd, o, h);
     stu(Hnext, o, rst ? 0.f : h);
     LCLK(7);
+    LSPAN_END();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -305,7 +341,7 @@ __global__ __launch_bounds__(512) void k_gru_h(const LeanH* __restrict__ ap, con
 //   da = dh z act'(c), dz' = dh (c - H) z (1 - z) for its 16 x 16 elements -> dV[:, 0:D], dV[:, 2D:3D];
 //   dr'_j = da[:, slice j] Wh[:, slice j]^T for ALL D columns -> partial plane drp[j] (k_gru_dy adds the planes and applies H r (1 - r)).
 // Two waves, no LDS, no barrier: each builds the da fragment itself (the same 13 KB of loads) and takes four of the <= 8 column tiles.
-#define LN_SLB 10      // slabs per batch of loads
+#define LN_SLB 18      // slabs per batch of loads (one round trip for the 9 / 17 slabs of k_score_bwd / k_score_b)
 __global__ __launch_bounds__(128) void k_gru_da(const LeanDa* __restrict__ ap, const int* meta_, const float* dsrc_, const float* Wh_, const float* z_,
                                                 const float* c_, const float* H0_, const float* H1_, unsigned dims, unsigned B) {
     const unsigned tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
@@ -332,6 +368,7 @@ __global__ __launch_bounds__(128) void k_gru_da(const LeanDa* __restrict__ ap, c
     const LeanDa a = *ap;
     lean_pin(a.dV, a.drp, a.seed, a.hidden_act, a.stream, a.ha_p0, a.ha_p1, a.drop_h, a.dbg);
     LCLK_INIT(a.dbg, 32); LCLK(1);
+    LSPAN_BEGIN(a.dbgtile, 1400);
     float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int q = 0; q < LN_SLB; ++q) {      // planes in fixed order
@@ -404,6 +441,7 @@ __global__ __launch_bounds__(128) void k_gru_da(const LeanDa* __restrict__ ap, c
         }
     }
     LCLK(6);
+    LSPAN_END();
 }
 
 // Backward, launch 2: dy tile = [da | dr' | dz'] Wx^T (K = 3 D), 16 rows x 16 input columns per workgroup, sixteen waves over K:
@@ -502,6 +540,7 @@ __global__ __launch_bounds__(1024) void k_gru_dy(const LeanDy* __restrict__ ap, 
     if (wid >= 4) return;
     const LeanDy a = *ap;
     LCLK_INIT(a.dbg, 48); LCLK(6);
+    LSPAN_BEGIN(a.dbgtile, 1500);
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) v += sJ[(wid * 16 + w) * 64 + lane];      // K slices in wave order
@@ -518,4 +557,257 @@ __global__ __launch_bounds__(1024) void k_gru_dy(const LeanDy* __restrict__ ap, 
         stu(a.dylo, o, v);
     }
     LCLK(7);
+    LSPAN_END();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scoring forward of a narrow top layer (D <= 128) at RSC15-like sizes: Sc[B, N] = h Wy[Y | samples]^T + By - logq lq (gru4rec.py:493-495),
+// one 32 x 32 tile per workgroup (272 workgroups at B = 128, N = 2176), four waves = four quarters of K, each holding the WHOLE tile for its
+// two super-steps: 4 + 4 float4 fragment loads (the gathered Wy rows of the tile's columns behind their staged item ids: both operands are
+// K-contiguous), 32 MFMAs on four accumulators, no operand is loaded twice inside the workgroup (32 KB per workgroup).  Join through LDS,
+// wave q finishes sub-tile q (bias - logQ correction of the column's item, row < M, column < N).  Row tile 0 publishes col_item and the
+// Y | samples part of occ_idx / occ_fl.  Replaces k_score_fwd's 64 x 32 LDS-staged tiles there (5.0 -> ~2 us in the step, tools/kn_cost.py).
+template <bool LOGQ>
+__global__ __launch_bounds__(256) void k_score_s(const LeanS* __restrict__ ap, const int* meta_, const int* cur_col_, const float* hd_, const float* Wy_,
+                                                 const float* By_, float* Sc_, unsigned dimsA, unsigned dimsB) {
+    __shared__ f32x4 sJ[4 * 4 * 64];
+    const unsigned tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const unsigned wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned D = dimsA & 0xFFFFu, B = dimsA >> 16, N = dimsB & 0xFFFFu, ldSc = dimsB >> 16, Dq = D >> 2;
+    const unsigned n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const GAS int* cur_col = (const GAS int*)cur_col_;
+    // items of the two column sub-tiles' columns (staged by the previous step's bookkeeping), then the step's (g, M, t)
+    const unsigned nA = n0 + li, nB = n0 + 16 + li;
+    int it0 = ldu_i(cur_col, 4 * min(nA, ldSc - 1)), it1 = ldu_i(cur_col, 4 * min(nB, ldSc - 1));
+    const int4 mt = ldi4((const GAS int*)meta_);
+    // A fragments: h rows of the two row sub-tiles, this wave's two super-steps
+    const unsigned Q0 = 8 * wid + lg, Q1 = Q0 + 4;
+    const bool ok0 = Q0 < Dq, ok1 = Q1 < Dq;
+    const unsigned Qa = ok0 ? Q0 : 0, Qb = ok1 ? Q1 : 0;
+    const GAS float* hd = (const GAS float*)hd_;
+    const unsigned ra = 4 * (min(m0 + li, B - 1) * D), rb = 4 * (min(m0 + 16 + li, B - 1) * D);
+    float4 a00 = ldu4(hd, ra + 16 * Qa), a01 = ldu4(hd, ra + 16 * Qb), a10 = ldu4(hd, rb + 16 * Qa), a11 = ldu4(hd, rb + 16 * Qb);
+    const LeanS a = *ap;
+    lean_pin(a.col_item, a.occ_idx, a.occ_fl, a.R, a.pub_fl, a.logq, a.dbg);
+    LCLK_INIT(a.dbg, 56); LCLK(0);
+    LSPAN_BEGIN(a.dbgtile, 4096);
+    // B fragments: the gathered Wy rows (64-bit row addresses: the table may exceed 4 GB)
+    if (nA >= ldSc) it0 = -1;
+    if (nB >= ldSc) it1 = -1;
+    const GAS float* Wy = (const GAS float*)Wy_;
+    const GAS float *w0 = Wy + (size_t)max(it0, 0) * D, *w1 = Wy + (size_t)max(it1, 0) * D;
+    float4 b00 = ld4(w0 + 4 * Qa), b01 = ld4(w0 + 4 * Qb), b10 = ld4(w1 + 4 * Qa), b11 = ld4(w1 + 4 * Qb);
+    // epilogue operand of wave q (sub-tile (q >> 1, q & 1)): bias - logQ correction of its column's item
+    const int ite = (wid & 1) ? it1 : it0;
+    const unsigned ne = (wid & 1) ? nB : nA;
+    float bias = ((const GAS float*)By_)[max(ite, 0)];
+    if (LOGQ) {
+        const DevModel& m = *a.mp;
+        bias -= a.logq * (ne < B ? m.lq_tgt : m.lq_smp)[max(ite, 0)];
+    }
+    LCLK(1);
+    const LeanState sx = lean_state(mt);
+    const int M = sx.M;
+    if (blockIdx.y == 0 && wid == 0 && lg < 2) {      // lanes (li, 0): column n0 + li; lanes (li, 1): column n0 + 16 + li
+        const unsigned n = lg ? nB : nA;
+        const int item = lg ? it1 : it0;
+        if (n < ldSc) {
+            a.col_item[n] = item;
+            if (n < N) {
+                a.occ_idx[n] = item;
+                if (item >= 0 && a.pub_fl) {
+                    int* fl = (int*)a.occ_fl + 4 * (size_t)item;
+                    atomicMax(fl, (int)(B + n) + 1);
+                    atomicMax(fl + 1, a.R - (int)(B + n));
+                    atomicAdd(fl + 2, 1);
+                }
+            }
+        }
+    }
+    if ((int)m0 >= M) return;
+    LCLK(2);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(ok0 && (int)(m0 + li) < M)) a00 = z4;
+    if (!(ok1 && (int)(m0 + li) < M)) a01 = z4;
+    if (!(ok0 && (int)(m0 + 16 + li) < M)) a10 = z4;
+    if (!(ok1 && (int)(m0 + 16 + li) < M)) a11 = z4;
+    if (!(ok0 && it0 >= 0)) b00 = z4;
+    if (!(ok1 && it0 >= 0)) b01 = z4;
+    if (!(ok0 && it1 >= 0)) b10 = z4;
+    if (!(ok1 && it1 >= 0)) b11 = z4;
+    f32x4 c00 = (f32x4){0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;      // c[row sub-tile][column sub-tile]
+#define LS_STEP(A0, A1, B0, B1, C)                                  \
+    c00 = mfma16(A0.C, B0.C, c00); c01 = mfma16(A0.C, B1.C, c01);   \
+    c10 = mfma16(A1.C, B0.C, c10); c11 = mfma16(A1.C, B1.C, c11);
+    LS_STEP(a00, a10, b00, b10, x) LS_STEP(a00, a10, b00, b10, y) LS_STEP(a00, a10, b00, b10, z) LS_STEP(a00, a10, b00, b10, w)
+    LS_STEP(a01, a11, b01, b11, x) LS_STEP(a01, a11, b01, b11, y) LS_STEP(a01, a11, b01, b11, z) LS_STEP(a01, a11, b01, b11, w)
+#undef LS_STEP
+    LCLK_USE(c00[0] + c11[0]); LCLK(3);
+    sJ[(0 * 4 + wid) * 64 + lane] = c00; sJ[(1 * 4 + wid) * 64 + lane] = c01;
+    sJ[(2 * 4 + wid) * 64 + lane] = c10; sJ[(3 * 4 + wid) * 64 + lane] = c11;
+    __syncthreads();
+    LCLK(4);
+    f32x4 v = sJ[(wid * 4 + 0) * 64 + lane];      // K quarters in wave order
+    v += sJ[(wid * 4 + 1) * 64 + lane]; v += sJ[(wid * 4 + 2) * 64 + lane]; v += sJ[(wid * 4 + 3) * 64 + lane];
+    if (ne >= N) return;
+    const unsigned r0 = m0 + 16 * (wid >> 1) + 4 * lg;
+    GAS float* Sc = (GAS float*)Sc_;
+    float o[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) { o[rg] = v[rg] + bias; lean_keep(o[rg]); }      // (complete before the conditional stores: lean_keep)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+        if ((int)(r0 + rg) < M) stu(Sc, 4 * ((r0 + rg) * ldSc + ne), o[rg]);
+    LCLK(5);
+    LSPAN_END();
+}
+template __global__ void k_score_s<false>(const LeanS*, const int*, const int*, const float*, const float*, const float*, float*, unsigned, unsigned);
+template __global__ void k_score_s<true>(const LeanS*, const int*, const int*, const float*, const float*, const float*, float*, unsigned, unsigned);
+
+// ---------------------------------------------------------------------------------------------
+// Scoring backward of a narrow top layer at RSC15-like sizes (B <= 128, D <= 128), two roles in one launch (block ranges), both on the same
+// skeleton: eight waves = eight slices of K, each holding FOUR 16 x 16 accumulators that share one operand fragment -- the row-major operand
+// is loaded as float4 along its contiguous dimension, component c feeding sub-tile c (output index 4 i + c: a permutation that leaves every
+// lane with 16 CONTIGUOUS outputs, four per sub-tile row) --, one LDS hand-over in the layout [register rg][wave][lane] -> float4 over the four
+// sub-tiles, and wave rg finishing one float4 per lane (16-byte loads / stores of accumulator, step and slab rows).
+//   role A (blockIdx.x < nA): dSy[n, d] = sum_b ds[b, n] h[b, d] for 16 score columns x 64 d (the column d == D is a ones column of h:
+//          dSBy = colsum(ds)); K = the batch, wave w takes rows 16 w .. 16 w + 15.  Epilogue as k_score_bwd role A: per-occurrence Adagrad
+//          scaling with the item's PRE-step accumulator (gru4rec.py:335-340), accumulator in place for single-occurrence items.
+//   role B: slab kc of dh = ds Sy (gathered Wy rows of 128 score columns), 16 batch rows x 64 d; wave w takes columns 16 w .. 16 w + 15 of
+//          the slab.  k_gru_da adds the slabs in slab order.
+// Replaces k_score_bwd<32, 128> (LDS-staged 32 x 32 tiles, 6.0 us in the step) where k_score_s replaces k_score_fwd.
+__global__ __launch_bounds__(512) void k_score_b(const LeanB* __restrict__ ap, const int* meta_, const int* cur_col_, const float* Sc_, const float* hd_,
+                                                 const float* Wy_, float* accWy_, unsigned dimsA, unsigned dimsB) {
+    __shared__ f32x4 sJ[4 * 8 * 64];
+    const unsigned tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const unsigned wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned D = dimsA & 0xFFFFu, B = dimsA >> 16, N = dimsB & 0xFFFFu, ldSc = dimsB >> 16;
+    const GAS int* cur_col = (const GAS int*)cur_col_;
+    const GAS float *Sc = (const GAS float*)Sc_, *hd = (const GAS float*)hd_;
+    const int4 mt = ldi4((const GAS int*)meta_);
+    const LeanB a = *ap;      // (its role-dependent fields are used far below: the compiler's lazy loads cost nothing there)
+    LSPAN_BEGIN(a.dbgtile, 2048);
+    f32x4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (blockIdx.x < (unsigned)a.nA) {
+        // ---------------- role A
+        const unsigned nt = blockIdx.x / (unsigned)a.ndh, dh_ = blockIdx.x - nt * (unsigned)a.ndh;
+        const unsigned n0 = 16 * nt, d0 = 64 * dh_;
+        const unsigned n = n0 + li, nc = min(n, ldSc - 1);
+        // epilogue operands of wave rg (requested first: the gathers behind the item id are the longest chain of the kernel)
+        const unsigned d4 = d0 + 16 * lg + 4 * (wid & 3);
+        const int item = ldu_i(cur_col, 4 * nc);
+        // operands: wave w -> batch rows 16 w + 4 s + lg, s = 0 .. 3
+        float4 av[4];
+        float bv[4];
+        const unsigned da = d0 + 4 * li;      // h columns da .. da + 3 (A operand: output index i <-> d = d0 + 4 i + c)
+        const unsigned dac = min(da, D - 4);
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const unsigned b = min(16 * wid + 4 * s_ + lg, B - 1);
+            av[s_] = ldu4(hd, 4 * (b * D + dac));
+            bv[s_] = ldu(Sc, 4 * (b * ldSc + nc));
+        }
+        lean_pin(a.accBy, a.occ_fl);
+        const bool iok = item >= 0 && n < N;
+        const unsigned ic = (unsigned)max(item, 0);
+        // (every wave requests them, with clamped addresses and no branch around the loads: a branch here makes hipcc drain ALL loads
+        // at its join -- the accumulator gather's round trip then sits in front of the MFMAs instead of under them)
+        float4 acc4 = ld4((const GAS float*)accWy_ + (size_t)ic * D + min(d4, D - 4));
+        const float accb = a.accBy[ic];
+        const int cnt = a.occ_fl[4 * (size_t)ic + 2];
+        if (d4 >= D) acc4 = make_float4(accb, 0.f, 0.f, 0.f);
+        __builtin_amdgcn_sched_barrier(0);      // (all loads out before the first MFMA)
+        const LeanState sx = lean_state(mt);
+        const int M = sx.M;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const unsigned b = 16 * wid + 4 * s_ + lg;
+            const bool bok = (int)b < M;
+            float4 h4 = av[s_];
+            // columns past the layer: the ones column at d == D (bias gradient), zeros behind it
+            const float hx[4] = {h4.x, h4.y, h4.z, h4.w};
+            float hv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hv[c] = (da + c < D) ? hx[c] : ((da + c == D) ? 1.f : 0.f);
+            const float dsv = (bok && n < ldSc) ? bv[s_] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = mfma16(hv[c], dsv, acc[c]);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) sJ[(rg * 8 + wid) * 64 + lane] = (f32x4){acc[0][rg], acc[1][rg], acc[2][rg], acc[3][rg]};
+        __syncthreads();
+        if (wid >= 4) return;
+        f32x4 g4 = sJ[(wid * 8 + 0) * 64 + lane];      // batch slices in wave order
+#pragma unroll
+        for (int w = 1; w < 8; ++w) g4 += sJ[(wid * 8 + w) * 64 + lane];
+        if (n >= N || d4 > D) return;
+        const float gg[4] = {g4[0], g4[1], g4[2], g4[3]}, a0[4] = {acc4.x, acc4.y, acc4.z, acc4.w};
+        float st[4], an[4];
+        const bool generic = a.generic != 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            an[c] = a0[c] + G4R_MUT_ACC(gg[c] * gg[c]);
+            st[c] = iok ? G4R_MUT_ROW(n, G4R_MUT_STEP(a.lr * gg[c] * frsq(an[c] + G4R_EPS_ADAGRAD))) : 0.f;
+            if (generic) st[c] = iok ? gg[c] : 0.f;      // raw per-occurrence gradient: the update kernel applies the rule
+        }
+        const bool single = !generic && iok && cnt == 1;
+        const size_t slot = (size_t)(sx.g & (unsigned)a.defer_mask);
+        if (d4 < D) {
+            st4(a.dSy + slot * (size_t)a.dSy_stride + (size_t)n * D + d4, make_float4(st[0], st[1], st[2], st[3]));
+            if (single) st4((GAS float*)accWy_ + (size_t)ic * D + d4, make_float4(an[0], an[1], an[2], an[3]));
+            else st4(a.dAy + (size_t)n * D + d4, make_float4(an[0], an[1], an[2], an[3]));
+        } else {      // d4 == D: the bias column
+            (a.dSBy + slot * (size_t)a.dSBy_stride)[n] = st[0];
+            if (single) a.accBy[ic] = an[0]; else a.dABy[n] = an[0];
+        }
+        LSPAN_END();
+        return;
+    }
+    // ---------------- role B
+    {
+        const unsigned w_ = blockIdx.x - (unsigned)a.nA;
+        const unsigned per = (unsigned)(a.nrb * a.ndb);
+        const unsigned kc = w_ / per, rem = w_ - kc * per, rb = rem / (unsigned)a.ndb, db = rem - rb * (unsigned)a.ndb;
+        const unsigned b0 = 16 * rb, d0 = 64 * db;
+        // wave w: score columns kbeg + 16 w + 4 lg + u (u = 0 .. 3) as K; A operand: ds[b0 + li][those four] (K-contiguous float4),
+        // B operand: the gathered Wy rows of the four columns, float4 along d (output index j <-> d = d0 + 4 j + c)
+        const unsigned nk = 128 * kc + 16 * wid + 4 * lg;
+        const unsigned nkc = min(nk, ldSc - 4);
+        const int4 it4 = ldi4(cur_col + nkc);
+        float4 ds4 = ldu4(Sc, 4 * (min(b0 + li, B - 1) * ldSc + nkc));
+        const unsigned dq = d0 + 4 * li, dqc = min(dq, D - 4);
+        const GAS float* Wy = (const GAS float*)Wy_;
+        const int its[4] = {it4.x, it4.y, it4.z, it4.w};
+        float4 wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wv[u] = ld4(Wy + (size_t)max(its[u], 0) * D + dqc);
+        __builtin_amdgcn_sched_barrier(0);      // (all four gathers out before the first MFMA: hipcc otherwise sinks two of them behind it)
+        const LeanState sx = lean_state(mt);
+        const int M = sx.M;
+        if ((int)b0 >= M) return;
+        const float dsx[4] = {ds4.x, ds4.y, ds4.z, ds4.w};
+        const bool bok = (int)(b0 + li) < M;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool kok = nk + u < ldSc && nk == nkc && its[u] >= 0 && dq < D;
+            const float av_ = bok ? dsx[u] : 0.f;
+            const float4 w4 = kok ? wv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc[0] = mfma16(av_, w4.x, acc[0]);
+            acc[1] = mfma16(av_, w4.y, acc[1]);
+            acc[2] = mfma16(av_, w4.z, acc[2]);
+            acc[3] = mfma16(av_, w4.w, acc[3]);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) sJ[(rg * 8 + wid) * 64 + lane] = (f32x4){acc[0][rg], acc[1][rg], acc[2][rg], acc[3][rg]};
+        __syncthreads();
+        if (wid >= 4) return;
+        f32x4 v = sJ[(wid * 8 + 0) * 64 + lane];      // column groups in wave order
+#pragma unroll
+        for (int w = 1; w < 8; ++w) v += sJ[(wid * 8 + w) * 64 + lane];
+        const unsigned b = b0 + 4 * lg + (wid & 3);
+        if ((int)b < M && dq < D) st4(a.dhpart + ((size_t)kc * B + b) * D + dq, make_float4(v[0], v[1], v[2], v[3]));
+        LSPAN_END();
+    }
 }

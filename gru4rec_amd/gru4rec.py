@@ -345,6 +345,10 @@ class GRU4Rec:
             rank=rank, nranks=nranks, use_graph=1 if self.use_graph else 0,
             sparse_exact=({'sum': 1, 'mean': 2, 'reduce': 3}.get(self.sparse_exact, 3) if (self.sparse_exact and nranks > 1) else 0),
             defer_updates=1 if getattr(self, 'defer_updates', False) else 0)
+        if getattr(self, 'defer_updates', False) and not m.get_debug('defer_stats', 4)[2]:
+            import warnings
+            warnings.warn('defer_updates is set but cannot apply to this model (it needs a single GPU, Adagrad without momentum, lmbd = 0, '
+                          'no grad_cap): row updates are applied every step as usual')
         if self._dist and self._dist['unique_id'] is not None:
             m.comm_init(self._dist['unique_id'], nranks, rank)
             if nranks > 1:

@@ -20,7 +20,25 @@ for rep in range(5):
         v = np.asarray(v, dtype=np.int64)
         t0 = v[idx[0]]
         print('%-9s stamps (us after stamp %d): ' % (name, idx[0]) + '  '.join('[%d] %.2f' % (i, (v[i] - t0) / 100.) for i in idx[1:]))
-    show('k_gru_v', raw[0:16], [1, 2, 3, 4, 5, 6, 7])
-    show('k_gru_h', raw[16:32], [1, 2, 5, 6, 7])
+    show('score_b role A wg 21', raw[0:16], [0, 1, 2, 3, 4, 5])
+    show('score_b role B wg 21', raw[16:32], [0, 1, 2, 3, 4, 5])
     show('k_gru_da', raw[32:48], [1, 2, 3, 4, 5, 6])
     show('k_gru_dy', raw[48:64], [6, 7])
+    show('k_score_s', raw[56:64], [0, 1, 2, 3, 4, 5])
+    tl_all = m.get_debug('dbgtile', (2 * 8 * 8192,)).view(np.int64).reshape(8192, 8)
+    B_, N_, D_ = cfg['batch_size'], cfg['batch_size'] + cfg['n_sample'], cfg['layers'][-1]
+    ld = (N_ + 15) // 16 * 16
+    regions = [('k_gru_v', 1024, 3 * ((D_ + 15) // 16) * ((B_ + 15) // 16)), ('k_gru_h', 1280, ((D_ + 15) // 16) * ((B_ + 15) // 16)),
+               ('k_score_s', 4096, ((ld + 31) // 32) * ((B_ + 31) // 32)), ('k_score_b', 2048, ((ld + 15) // 16) * ((D_ + 64) // 64) + ((ld + 127) // 128) * ((B_ + 15) // 16) * ((D_ + 63) // 64)),
+               ('k_gru_da', 1400, ((D_ + 15) // 16) * ((B_ + 15) // 16)), ('k_gru_dy', 1500, ((D_ + 15) // 16) * ((B_ + 15) // 16))]
+    t0 = None
+    for name, base, n in regions:
+        t = tl_all[base:base + min(n, 2040)]
+        t = t[t[:, 1] > 0]
+        if not len(t):
+            continue
+        if t0 is None:
+            t0 = t[:, 0].min()
+        d = (t[:, 1] - t[:, 0]) / 100.
+        print('   %-10s %4d workgroups: first stamp at %+6.2f .. %+6.2f us, last stamp at %+6.2f .. %+6.2f us (after k_gru_v began); own duration median %.2f max %.2f' % (
+            name, len(t), (t[:, 0].min() - t0) / 100., (t[:, 0].max() - t0) / 100., (t[:, 1].min() - t0) / 100., (t[:, 1].max() - t0) / 100., np.median(d), d.max()))
