@@ -47,15 +47,24 @@ def mutant_path(k):
 def build_mutants(force=False, verbose=False):
     """The deliberately wrong libraries of tests/test_gpu_mutation.py (-DG4R_MUTATE=k, g4r_device.cuh): the parity suite has to
     turn red on each of them.  Test infrastructure: the product never loads them.  Built concurrently (one hipcc each)."""
+    import fcntl
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(os.path.join(HERE, '_variants'), exist_ok=True)
-    todo = [k for k in MUTANTS if force or not os.path.exists(mutant_path(k)) or
-            any(os.path.getmtime(mutant_path(k)) < os.path.getmtime(d) for d in DEPS)]
-    if not todo:
+
+    def stale():
+        return [k for k in MUTANTS if force or not os.path.exists(mutant_path(k)) or
+                any(os.path.getmtime(mutant_path(k)) < os.path.getmtime(d) for d in DEPS)]
+    if not stale():
         return [mutant_path(k) for k in MUTANTS]
-    _host_object(verbose)
-    with ThreadPoolExecutor(min(len(todo), 2)) as ex:      # two hipcc at a time (each peaks at ~2 GB)
-        list(ex.map(lambda k: _device(mutant_path(k), ['G4R_MUTATE=%d' % k], verbose, audit=(k != 4)), todo))
+    # one builder at a time (pytest-xdist workers share the tree: two of them building into the same _build/ directory lose each
+    # other's intermediates); whoever comes second finds the libraries fresh
+    with open(os.path.join(HERE, '_variants', '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        todo = stale()
+        if todo:
+            _host_object(verbose)
+            with ThreadPoolExecutor(min(len(todo), 2)) as ex:      # two hipcc at a time (each peaks at ~2 GB)
+                list(ex.map(lambda k: _device(mutant_path(k), ['G4R_MUTATE=%d' % k], verbose, audit=(k != 4)), todo))
     return [mutant_path(k) for k in MUTANTS]
 
 

@@ -77,7 +77,7 @@ int g4r_p2p_export(g4r_model* m, char* out_handle64) {
         void* q = nullptr;
         hipIpcMemHandle_t h;
         bool ok = false;
-        if (!getenv("G4R_P2P_COARSE") && hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) == hipSuccess) {
+        if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) == hipSuccess) {
             ok = hipIpcGetMemHandle(&h, q) == hipSuccess;
             if (!ok) { (void)hipFree(q); q = nullptr; }
         }

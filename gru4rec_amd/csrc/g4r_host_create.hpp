@@ -246,9 +246,9 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     // scoring backward geometry: role A tiles (n x d, one spare d column for dSBy), role B tiles (b x d x k-chunk)
     {
         // k_gru_bwd_fused sums the slabs next to everything else it loads: half as many, twice as deep (k_score_bwd +0.4 us at cfg2)
-        const int slabs_target = getenv("G4R_KSLABS") ? atoi(getenv("G4R_KSLABS")) : ((fused_bwd(d, d.n_layers - 1) || lean_gru(d, d.n_layers - 1)) ? 9 : 17);
+        const int slabs_target = (fused_bwd(d, d.n_layers - 1) || lean_gru(d, d.n_layers - 1)) ? 9 : 17;
         d.kch = GT_BK * std::max(1, (cdiv(d.ldSc, GT_BK) + slabs_target / 2) / slabs_target);      // ~17 slabs whatever the number of negatives
-        if (score_bwd2(d) && !getenv("G4R_KSLABS")) {
+        if (score_bwd2(d)) {
             // k_score_bwd2: its 64 x 64 tiles cost microseconds of MFMA each and all of them are resident at once, so the launch
             // lasts as long as the CU with one tile more than the others.  The number of dh slabs is free: take the one (12..24)
             // that makes role A + role B tiles fill whole rounds of CUs best (B = 512, N = 8704, D = 256: 17 slabs = 1088 tiles
@@ -393,7 +393,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     if (m->loss_long) m->smem_loss = (size_t)(d.ldSc + 18 * LOSS_NW) * sizeof(float);
     // four columns per thread and trip from 4 columns per thread on (measured, round 5: B = 512 with 8192 negatives 15.2 -> 13.0 us;
     // 2176 / 2528 columns: 4.7 / 4.4 us either way)
-    m->loss_quads = env_int("G4R_LOSS_V", d.ldSc >= 4 * LOSS_T ? 4 : 1) == 4;
+    m->loss_quads = d.ldSc >= 4 * LOSS_T;
     const int big = 156 * 1024;      // leaves room for the few bytes of static LDS some kernels use (__syncthreads_or)
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_p1_n32, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_p1_n64, hipFuncAttributeMaxDynamicSharedMemorySize, big));

@@ -60,7 +60,7 @@ struct g4r_model {
     int ntiles = 0, nblkA = 0, nblkB = 0, ndtA = 0, ndtB = 0, nrtB = 0, nblk_occ = 0, nblk_occ_g = 0;
     size_t smem_score = 0, smem_loss = 0, smem_sparse = 0;
     bool loss_long = false;      // k_loss_rows<true>: score rows too long for two LDS copies
-    bool loss_quads = false;     // k_loss_rows<., ., 4>: four columns per thread and trip (long score rows; G4R_LOSS_V=1/4 overrides)
+    bool loss_quads = false;     // k_loss_rows<., ., 4>: four columns per thread and trip (long score rows)
     // wide layers (g4r_wide_kernels.cuh): per layer which kernels run (bit 1 k_gru_p1s + k_gru_gate, 8 k_gru_bwd_bw) and their K-slice
     // geometry; wide_dense: the 64 x 64 dense-gradient tiles (k_dense_grad2, mask bit 16) as a launch of their own for the whole model
     struct WideGeo { int use = 0, ny = 1, nh = 1, kys = 0, khs = 0, bbn = 1, bbk = 0; };
@@ -173,13 +173,11 @@ static inline bool lean_gru(const DevModel& d, int l) {
 }
 // GRU backward in one launch (k_gru_bwd_fused) for layers whose operands fit its LDS plan
 static inline bool fused_bwd(const DevModel& d, int l) {
-    static const bool off = getenv("G4R_NO_FUSED_BWD") != nullptr;
-    return !off && d.D[l] <= BF_MAXD && d.D[l] % 4 == 0 && d.IN[l] % 4 == 0 && !(l == 0 && d.embed_mode == G4R_EMBED_ONEHOT);
+    return d.D[l] <= BF_MAXD && d.D[l] % 4 == 0 && d.IN[l] % 4 == 0 && !(l == 0 && d.embed_mode == G4R_EMBED_ONEHOT);
 }
 // GRU forward in one launch (k_gru_fwd_fused) for layers whose weights fit its LDS plan (in + D up to ~200)
 static inline bool fused_fwd(const DevModel& d, int l) {
-    static const bool off = getenv("G4R_NO_FUSED_FWD") != nullptr;
-    return !off && d.D[l] <= FF_LDR && d.IN[l] <= FF_LDR && d.D[l] % 4 == 0 && d.IN[l] % 4 == 0 && d.IN[l] >= 4 &&      // its load maps cover 112 rows / columns
+    return d.D[l] <= FF_LDR && d.IN[l] <= FF_LDR && d.D[l] % 4 == 0 && d.IN[l] % 4 == 0 && d.IN[l] >= 4 &&      // its load maps cover 112 rows / columns
            !(l == 0 && d.embed_mode == G4R_EMBED_ONEHOT) && (size_t)fwd_fused_lds(d.IN[l], d.D[l]).total * sizeof(float) <= 156 * 1024;
 }
 static inline size_t smem_fused_bwd(int D) { return (size_t)((((BF_ROWS + 32) * (3 * D + 2) + D * (D + 2) + 32 + 3) & ~3) + 4 * 6 * 64) * sizeof(float); }

@@ -224,12 +224,10 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     if (part == 1) { HIPCHK(hipGetLastError()); return 0; }
     if (part == 2) merged = merged_update(m) && !(recs && m->profile_split);
     // multi-rank: dense-gradient all-reduce, dense Adagrad, then the sparse embedding update, in stream order.
-    // Optionally the first two run on their own stream next to the sparse update (which touches item rows only)
-    // and join before the next step reads the GRU weights
-    // (measured on one MI355X with a one-rank communicator: the two cross-stream event dependencies cost ~20 us per
-    // step, more than the ~11 us of sparse update they can hide, so the overlap is opt-in: G4R_OVERLAP=1)
-    static const bool want_overlap = getenv("G4R_OVERLAP") != nullptr;
-    const bool overlap = !d.apply_dense_inplace && !recs && !trace && want_overlap && !d.generic && !merged && !m->p2p_ready && (m->cfg.nranks > 1 || m->comm_ready);
+    // (running the first two on a stream of their own next to the sparse update -- which touches item rows only -- was measured on one
+    // MI355X with a one-rank communicator: the two cross-stream event dependencies cost ~20 us per step, more than the ~11 us of sparse
+    // update they can hide; that path was removed in round 6)
+    const bool overlap = false;
     if (!d.apply_dense_inplace) {
         // staged dense path: (RCCL all-reduce when there are ranks) -> (global gradient norm -> clip factor, generic path with
         // grad_cap) -> dense rule on the flat gradient buffer
@@ -318,7 +316,7 @@ static int apply_compaction(g4r_model* m, int64_t ci) {
 #define G4R_GRAPH_STEPS 16
 #define G4R_GRAPH_STEPS_SMALL 4
 // N > 1 (or the one-rank staged mode): the all-reduce is captured with the step, so that a replay covers 16 whole steps
-// (kernels, RCCL all-reduce, dense apply) with no host work in between; G4R_RCCL_EAGER=1 keeps RCCL out of the graph
+// (kernels, RCCL all-reduce, dense apply) with no host work in between
 // one GPU, staged dense path without a communicator (the generic optimizers: rmsprop / adadelta / adam / plain SGD / grad_cap): no
 // collective in the step, so the whole step is captured like the fused single-GPU step (it used to replay a head graph and launch
 // its tail eagerly; G4R_NO_LOCAL_GRAPH=1 keeps that)
@@ -326,9 +324,8 @@ static inline bool local_staged(const g4r_model* m) {
     return !m->dm.apply_dense_inplace && m->cfg.nranks <= 1 && !m->comm_ready && !m->p2p_ready && !m->virtual_ranks;
 }
 static inline bool dist_graph_wanted(const g4r_model* m) {
-    static const bool eager = getenv("G4R_RCCL_EAGER") != nullptr;
     return !m->dm.apply_dense_inplace && !m->dist_graph_failed &&
-           (m->p2p_ready || (m->comm_ready && !eager && !getenv("G4R_OVERLAP")) || local_staged(m));
+           (m->p2p_ready || m->comm_ready || local_staged(m));
 }
 static int ensure_graph(g4r_model* m) {
     if (m->gexec) return 0;

@@ -51,7 +51,10 @@ def test_paramfile_trains_through_the_public_class(name):
 
 @pytest.mark.parametrize('name', sorted(PARAMFILES))
 def test_paramfile_steps_match_the_oracle(name):
-    """12 steps at the paramfile's full width / batch / 2048 negatives against the NumPy oracle (fp32)."""
+    """12 steps at the paramfile's full width / batch / 2048 negatives against the NumPy oracle: costs against the fp32 oracle; the
+    parameters against the fp64 oracle, within a bound bracketed by the fp32 oracle's own distance from it.  (Round 6: on
+    rsc15_xe_shared_100_best one element of Wy -- a first-touch Adagrad step with |g| ~ sqrt(eps) -- is 6.3e-4 off in the FP32 ORACLE, 2.4e-4
+    in the round-2 kernels and 1.2e-4 in the round-6 kernels: a fixed tolerance against the fp32 run failed the more accurate kernels.)"""
     p = dict(PARAMFILES[name])
     I, T, rows = 3000, 12, 8
     B, ns, D = p['batch_size'], p['n_sample'], p['layers'][0]
@@ -59,9 +62,17 @@ def test_paramfile_steps_match_the_oracle(name):
                       sample_alpha=p['sample_alpha'], learning_rate=p['learning_rate'], momentum=p['momentum'], bpreg=p['bpreg'],
                       logq=p['logq'], dropout_p_hidden=p['dropout_p_hidden'], dropout_p_embed=p['dropout_p_embed'],
                       constrained_embedding=True, dtype=np.float32, seed=11)
+    o64 = OracleGRU4Rec(n_items=I, layers=tuple(p['layers']), batch_size=B, loss=p['loss'], final_act=p['final_act'], n_sample=ns,
+                        sample_alpha=p['sample_alpha'], learning_rate=p['learning_rate'], momentum=p['momentum'], bpreg=p['bpreg'],
+                        logq=p['logq'], dropout_p_hidden=p['dropout_p_hidden'], dropout_p_embed=p['dropout_p_embed'],
+                        constrained_embedding=True, dtype=np.float64, seed=11)
     rng = np.random.RandomState(5)
-    o.set_popularity(rng.randint(1, 60, size=I))
-    o.make_sample_store(rows * ns)
+    pop = rng.randint(1, 60, size=I)
+    for q in (o, o64):
+        q.set_popularity(pop)
+        q.make_sample_store(rows * ns)
+    o64.Wx[0], o64.Wh[0], o64.Wrz[0] = (x.astype(np.float64) for x in (o.Wx[0], o.Wh[0], o.Wrz[0]))      # the same fp32 initial weights
+    o64.Wy, o64.By, o64.Bh[0] = o.Wy.astype(np.float64), o.By.astype(np.float64), o.Bh[0].astype(np.float64)
     fa = parse_act(p['final_act'])
     m = _native.Model(n_items=I, layers=[D], batch_size=B, n_sample=ns, loss=_native.LOSS_IDS[p['loss']],
                       final_act=_native.ACT_IDS[fa[0]], final_act_p0=fa[1], final_act_p1=fa[2], hidden_act=_native.ACT_IDS['tanh'],
@@ -76,9 +87,13 @@ def test_paramfile_steps_match_the_oracle(name):
                 reset=(rng.rand(T, B) < 0.2).astype(np.uint8), M=np.full(T, B, dtype=np.int32), T=T, n_compact=0)
     m.set_plan(plan)
     want = [o.train_step(plan['in_idx'][t], plan['out_idx'][t], B, plan['reset'][t].astype(bool)) for t in range(T)]
+    for t in range(T):
+        o64.train_step(plan['in_idx'][t], plan['out_idx'][t], B, plan['reset'][t].astype(bool))
     m.train_steps(0, T)
     got = m.get_losses(0, T)
     np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-5)
-    np.testing.assert_allclose(m.get_param('Wy', (I, D)), o.Wy, rtol=5e-3, atol=2e-4)
-    np.testing.assert_allclose(m.get_param('Wh', (D, D), 0), o.Wh[0], rtol=5e-3, atol=2e-4)
+    for name_, gpu, f32, f64 in (('Wy', m.get_param('Wy', (I, D)), o.Wy, o64.Wy), ('Wh', m.get_param('Wh', (D, D), 0), o.Wh[0], o64.Wh[0])):
+        gap = float(np.abs(f32.astype(np.float64) - f64).max())      # what fp32 arithmetic costs the oracle itself on this run
+        assert gap < 2e-3, (name_, gap)                               # (the run is not chaotic: the bracket below means something)
+        np.testing.assert_allclose(gpu.astype(np.float64), f64, rtol=5e-3, atol=max(2e-4, 2.0 * gap), err_msg='%s (fp32 oracle vs fp64: %.2e)' % (name_, gap))
     m.close()
