@@ -21,6 +21,7 @@ static int build_lean_args(g4r_model* m) {
     const int L = d.n_layers;
     std::vector<LeanV> av(L); std::vector<LeanH> ah(L); std::vector<LeanDa> aa(L); std::vector<LeanDy> ay(L);
     bool any = false;
+    const bool constrained_all = d.embed_mode == G4R_EMBED_CONSTRAINED;
     for (int l = 0; l < L; ++l) {
         if (!lean_gru(d, l)) continue;
         any = true;
@@ -62,6 +63,39 @@ static int build_lean_args(g4r_model* m) {
         q.dSy_stride = d.dSy_stride; q.dSBy_stride = d.dSBy_stride; q.defer_mask = d.defer_mask; q.generic = d.generic;
         q.ndh = cdiv(d.Dtop + 1, 64); q.nA = cdiv(d.ldSc, 16) * q.ndh; q.nrb = cdiv(d.B, 16); q.ndb = cdiv(d.Dtop, 64); q.lr = d.lr;
         m->h_leanB = q;
+    }
+    if (d.apply_dense_inplace && d.B <= 128 && std::max(d.Dtop, d.Ein) <= 256 && !d.generic) {
+        // k_update_l: argument block + its table of 16 x 64 dense tiles
+        LeanU u; memset(&u, 0, sizeof(u));
+        u.mp = nullptr; u.st = d.st; u.Wy = d.Wy; u.E = d.E; u.accWy = d.accWy; u.accE = d.accE; u.velWy = d.velWy; u.velE = d.velE;
+        u.By = d.By; u.accBy = d.accBy; u.velBy = d.velBy; u.dAx = d.dAx; u.dAy = d.dAy; u.dABy = d.dABy;
+        u.dense_p = d.dense_p; u.dense_acc = d.dense_acc; u.dense_vel = d.dense_vel; u.yin0 = d.yin0; u.meta = d.cur_in + 2 * d.B;
+        u.dbg = d.dbgclk; u.dbgtile = d.dbgtile; u.n_items = d.n_items; u.constrained = constrained_all ? 1 : 0; u.wE = d.Ein; u.wY = d.Dtop;
+        u.lr = d.lr; u.mom = d.mom; u.lmbd = d.lmbd;
+        m->h_leanU = u;
+        std::vector<DenseTile> tiles;
+        for (int l = 0; l < L; ++l) {
+            const int D = d.D[l], IN = d.IN[l];
+            auto add = [&](const float* x0, const float* x1, int ldx, int nrows, int ncols, int coff, int ldo, long long base) {
+                for (int r = 0; r < nrows; r += 16)
+                    for (int c = 0; c < ncols; c += 64) {
+                        DenseTile t;
+                        t.X0 = x0; t.X1 = x1; t.dV = d.dV[l]; t.base = base; t.ldx = ldx; t.ldv = 3 * D; t.nrows = nrows;
+                        t.ncols = ncols; t.coff = coff; t.ldo = ldo; t.r0 = r; t.c0 = c; t.gather = (x0 == nullptr && nrows > 1) ? 1 : 0; t.pad = 0;
+                        tiles.push_back(t);
+                    }
+            };
+            const float* yin = (l == 0) ? nullptr : d.hd[l - 1];
+            if (!(l == 0 && d.embed_mode == G4R_EMBED_ONEHOT)) add(yin, yin, IN, IN, 3 * D, 0, 3 * D, d.offWx[l]);
+            add(d.Hr[l], d.Hr[l], D, D, D, 0, D, d.offWh[l]);
+            add(d.H[l][0], d.H[l][1], D, D, 2 * D, D, 2 * D, d.offWrz[l]);
+            add(nullptr, nullptr, 0, 1, 3 * D, 0, 3 * D, d.offBh[l]);
+        }
+        m->ntiles16 = (int)tiles.size();
+        if (dalloc(m, &m->d_tiles16, tiles.size()) || dalloc(m, &m->d_leanU, (size_t)1)) return -1;
+        HIPCHK(hipMemcpyAsync(m->d_tiles16, tiles.data(), tiles.size() * sizeof(DenseTile), hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        any = true;
     }
     m->h_leanV = av; m->h_leanH = ah; m->h_leanDa = aa; m->h_leanDy = ay;      // (host copies: launch_step passes their hot fields as kernel arguments)
     if (!any) return 0;
@@ -449,6 +483,10 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     }
     if (build_lean_args(m)) { g4r_destroy(m); return -1; }
     if (dalloc(m, &m->d_dm, 1) || sync_dm(m)) { g4r_destroy(m); return -1; }
+    if (m->d_leanU) {
+        m->h_leanU.mp = m->d_dm;
+        if (hipMemcpyAsync(m->d_leanU, &m->h_leanU, sizeof(LeanU), hipMemcpyHostToDevice, m->stream) != hipSuccess || hipStreamSynchronize(m->stream) != hipSuccess) { g4r_destroy(m); return fail("lean args upload"); }
+    }
     if (m->d_leanS) {
         m->h_leanS.mp = m->d_dm;
         if (hipMemcpyAsync(m->d_leanS, &m->h_leanS, sizeof(LeanS), hipMemcpyHostToDevice, m->stream) != hipSuccess || hipStreamSynchronize(m->stream) != hipSuccess) { g4r_destroy(m); return fail("lean args upload"); }

@@ -77,6 +77,8 @@ struct g4r_model {
     std::vector<LeanV> h_leanV; std::vector<LeanH> h_leanH; std::vector<LeanDa> h_leanDa; std::vector<LeanDy> h_leanDy;
     LeanS* d_leanS = nullptr;      // argument block of k_score_s
     LeanB* d_leanB = nullptr; LeanB h_leanB;      // argument block of k_score_b
+    LeanU* d_leanU = nullptr; LeanU h_leanU;      // argument block of k_update_l, its 16 x 64 dense tiles
+    DenseTile* d_tiles16 = nullptr; int ntiles16 = 0;
     LeanV* d_leanV = nullptr; LeanH* d_leanH = nullptr; LeanDa* d_leanDa = nullptr; LeanDy* d_leanDy = nullptr;      // [layers] argument blocks (g4r_lean_kernels.cuh)
     hipGraphExec_t gexec = nullptr;
     hipGraphExec_t gexec_small = nullptr;        // single GPU: G4R_GRAPH_STEPS_SMALL steps, for what a run leaves after the big replays

@@ -6,7 +6,16 @@ static inline bool no_merge_tail() { static const bool v = getenv("G4R_NO_MERGE"
 static inline int row_chunks(const DevModel& d) { const int w = std::max(d.Dtop, d.Ein); return w <= 256 ? 1 : (w <= 512 ? 2 : 4); }
 // (rows wider than 512 floats take the two-launch form: k_update's register budget is sized for two chunks per lane)
 // (wide layers: the dense gradients run as 64 x 64 tiles in a launch of their own, k_dense_grad2, ahead of the sparse row update)
+// the lean form of the merged update (k_update_l, g4r_lean_kernels.cuh): one GPU, Adagrad(+momentum) with the dense rule fused, batches of <= 128
+// rows, item rows of <= 256 floats, no deferral, no touched-row bitmap (N > 1)
+static inline bool lean_update(const g4r_model* m);
 static inline bool merged_update(const g4r_model* m) { return !m->dm.generic && !no_merge_tail() && row_chunks(m->dm) <= 2 && !m->wide_dense; }
+static inline bool lean_update(const g4r_model* m) {
+    static const bool off = getenv("G4R_NO_LEAN") != nullptr;
+    const DevModel& d = m->dm;
+    return !off && merged_update(m) && m->d_leanU && d.apply_dense_inplace && d.B <= 128 && row_chunks(d) == 1 && !m->defer_on && d.xmode == 0 && !d.touched &&
+           d.R < 65536 && m->ntiles16 < 65536 && cdiv(d.R, 8) < 65536;
+}
 // part: 0 = the whole step; 1 = head (everything up to the dense gradients); 2 = tail (all-reduce, dense apply, sparse update)
 static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
     DevModel& d = m->dm;
@@ -200,6 +209,19 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         }
         begin(KN_UPDATE);
         const bool mo = d.mom > 0.f;
+        if (lean_update(m) && !(d.bbn[0] > 0)) {
+            const int nb8 = cdiv(d.R, 8);
+            const unsigned packA = (unsigned)m->ntiles16 | ((unsigned)nb8 << 16), packB = (unsigned)d.R | ((unsigned)B << 16);
+            const unsigned nbk = 1u + (unsigned)cdiv(d.ldSc, 512);
+            const dim3 gl(nbk + m->ntiles16 + nb8);
+            if (mo) LK(k_update_l<true>, gl, dim3(512), 0, s, (const LeanU*)m->d_leanU, (const DenseTile*)m->d_tiles16, (const int*)d.occ_idx, (int*)d.occ_fl,
+                       (const float*)d.dSx, (const float*)d.dSy, (const float*)d.dSBy, packA, packB, nbk);
+            else LK(k_update_l<false>, gl, dim3(512), 0, s, (const LeanU*)m->d_leanU, (const DenseTile*)m->d_tiles16, (const int*)d.occ_idx, (int*)d.occ_fl,
+                    (const float*)d.dSx, (const float*)d.dSy, (const float*)d.dSBy, packA, packB, nbk);
+            end();
+            HIPCHK(hipGetLastError());
+            return 0;
+        }
 #define G4R_LK_UPDATE(CH, DT_)                                                                                                          \
         do {                                                                                                                            \
             if (mo) LK((k_update<CH, DT_, true>), grid, blk, smem, s, dmp, stp, (const DenseTile*)m->d_tiles, m->ntiles, m->nblk_occ);  \

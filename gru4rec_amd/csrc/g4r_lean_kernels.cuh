@@ -117,6 +117,18 @@ struct LeanB {
     float lr, pad;
 };
 
+struct LeanU {
+    const DevModel* mp; StepState* st;      // the bookkeeping workgroup works through the descriptor
+    GP(float) Wy; GP(float) E; GP(float) accWy; GP(float) accE; GP(float) velWy; GP(float) velE;
+    GP(float) By; GP(float) accBy; GP(float) velBy;
+    GP(const float) dAx; GP(const float) dAy; GP(const float) dABy;
+    GP(float) dense_p; GP(float) dense_acc; GP(float) dense_vel; GP(const float) yin0;
+    GP(const int) meta;
+    GP(long long) dbg; GP(long long) dbgtile;
+    int n_items, constrained, wE, wY;
+    float lr, mom, lmbd, pad;
+};
+
 // ---------------------------------------------------------------------------------------------
 // How every kernel below is laid out in time (tools/clk_lean.py, profiles/r06_clk_lean_*.txt): a line the previous launch wrote costs
 // 0.4-0.6 us to fetch, the step state (rewritten every step) as much -- so NO load may wait for the state or for the argument block:
@@ -811,3 +823,301 @@ __global__ __launch_bounds__(512) void k_score_b(const LeanB* __restrict__ ap, c
         LSPAN_END();
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// The step's last launch for narrow layers on one GPU (B <= 128, rows of <= 256 floats, Adagrad(+momentum), no deferral): k_update's three
+// roles -- bookkeeping workgroup, dense-gradient tiles with the fused dense Adagrad, per-occurrence sparse row update -- rewritten on the
+// rules of this file.  Replaces k_update<1, 32, MOM> there (7.5 us; the sparse role's span was set by owners of repeated items: 3-4 us in
+// the LDS-staged list scan behind a workgroup barrier, tools/clk.py).
+//   dense tile (16 rows x 64 columns of dWx / dWh / dWrz / dBh, K = the batch over eight waves): the transposed product of k_score_b's role
+//     A -- dV as float4 along its columns (A operand), X as dwords (B operand) -- leaves every lane 16 contiguous columns of one output
+//     row: accumulator / parameter (/ velocity) quads in, Adagrad, quads out.  gru4rec.py:330-334,390-406.
+//   sparse role (one wave per occurrence k of X | Y | samples, eight per workgroup, NO LDS, no barrier): item id and step row with the
+//     first loads; behind the id the item's (last, first, count) entry, parameter row and bias -- one round trip; the wave of the LAST
+//     occurrence owns the row.  Single occurrences (~90 %) finish right there.  An owner of a repeated item finds the earlier
+//     occurrences itself: the id list is 9 KB and L2 resident, so it reads the slice [first, k) with 16-byte loads (up to 1024 ids per
+//     round trip), ballots the matches and adds their step rows in occurrence order, eight rows per round trip -- the arithmetic and the
+//     order of sparse_update_block (gru4rec.py:335-340,407-431: increments accumulate, accumulator and velocity take the last
+//     occurrence's value).  Items whose occurrences are all sampled negatives take the (count - 1) x own row shortcut as there.
+template <bool MOM>
+__device__ __forceinline__ void lean_rows_update(const LeanU& a, const GAS int* occ_idx, GAS int* occ_fl, const GAS float* dSx, const GAS float* dSy,
+                                                 const GAS float* dSBy, unsigned k, unsigned R, unsigned B) {
+    const unsigned lane = threadIdx.x & 63;
+    const bool tableE = k < B && !a.constrained;
+    const unsigned W = tableE ? (unsigned)a.wE : (unsigned)a.wY, nc4 = W >> 2;
+    const unsigned c4 = min(lane, nc4 - 1);
+    const bool lok = lane < nc4;
+    const unsigned kc = min(k, R - 1);
+    // first loads: the occurrence's item, its step row, its bias step
+    int item = ldu_i(occ_idx, 4 * kc);
+    const GAS float* srow = (kc < B) ? dSx + (size_t)kc * W : dSy + (size_t)(kc - B) * W;
+    const float4 sk = ld4(srow + 4 * c4);
+    const bool bias = k >= B;
+    const float bsk = bias ? dSBy[kc - B] : 0.f;
+    lean_pin(a.Wy, a.E, a.accWy, a.accE, a.By, a.accBy, a.dAx, a.dAy, a.dABy, a.n_items, a.lr, a.mom, a.lmbd);
+    if (k >= R) item = -1;
+    GAS float* P = tableE ? a.E : a.Wy;
+    GAS float* A = tableE ? a.accE : a.accWy;
+    GAS float* V = tableE ? a.velE : a.velWy;
+    const unsigned ic = (unsigned)max(item, 0);
+    // second level: the item's entry, its parameter (velocity) row, its bias state
+    GAS int* flp = occ_fl + 4 * ((tableE ? (size_t)a.n_items : 0) + ic);
+    const int4 fl = ldi4(flp);
+    const float4 pz = ld4(P + (size_t)ic * W + 4 * c4);
+    float4 vz = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MOM) vz = ld4(V + (size_t)ic * W + 4 * c4);
+    const float bpz = a.By[ic];
+    float bvz = 0.f;
+    if (MOM) bvz = a.velBy[ic];
+    const bool owner = item >= 0 && fl.x == (int)k + 1;
+    if (!owner) return;      // wave-uniform
+    if (lane == 0) *(GAS int4*)flp = make_int4(0, 0, 0, 0);      // the entry is taken back for the next step
+    const float lr = a.lr, momc = a.mom, lmbd = a.lmbd;
+    const int n = fl.z;
+    const int lo = (a.constrained || k < B) ? 0 : (int)B;
+    const int first_j = max(lo, (int)R - fl.y);
+    float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
+    float Sb = 0.f;
+    int nb_e = 0;
+    if (n > 1) {
+        if (first_j >= 2 * (int)B) {
+            // all occurrences are sampled negatives of this step: their score columns are copies of one another, so are their step rows
+            for (int cdup = 1; cdup < n; ++cdup) { S.x += sk.x; S.y += sk.y; S.z += sk.z; S.w += sk.w; Sb += bsk; }
+            nb_e = n - 1;
+        } else {
+            // earlier occurrences in [first_j, k): ids in slices of 1024 (four 16-byte loads per lane), matches in ascending order
+            for (int base0 = first_j & ~3; base0 < (int)k; base0 += 1024) {
+                int4 vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) vv[u] = ldi4(occ_idx + min(base0 + 256 * u + 4 * (int)lane, (int)((R + 3) & ~3u) - 4));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j0 = base0 + 256 * u + 4 * (int)lane;
+                    const int ids[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+                    unsigned long long mk[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mk[e] = __ballot(ids[e] == item && j0 + e >= first_j && j0 + e < (int)k);
+                    unsigned long long any = mk[0] | mk[1] | mk[2] | mk[3];
+                    // up to eight matches per batch of row loads (wave-uniform positions in scalar registers)
+                    while (any) {
+                        int js[8], nj = 0;
+                        while (any && nj < 8) {
+                            const int l = __builtin_ctzll(any);
+                            bool more = false;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if ((mk[e] >> l) & 1ull) {
+                                    if (nj < 8) {
+                                        const int jv = base0 + 256 * u + 4 * l + e;
+#pragma unroll
+                                        for (int q = 0; q < 8; ++q) if (q >= nj) js[q] = jv;      // (slots past nj repeat a valid position; no indexed register access)
+                                        ++nj; mk[e] &= ~(1ull << l);
+                                    } else more = true;
+                                }
+                            }
+                            if (!more) any &= ~(1ull << l);
+                        }
+                        float4 g[8];
+                        float gb[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int jj = js[q];
+                            const GAS float* r2 = (jj < (int)B) ? dSx + (size_t)jj * W : dSy + (size_t)(jj - (int)B) * W;
+                            g[q] = ld4(r2 + 4 * c4);
+                            gb[q] = (bias && jj >= (int)B) ? dSBy[jj - (int)B] : 0.f;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            if (q < nj) {      // wave-uniform
+                                S.x += g[q].x; S.y += g[q].y; S.z += g[q].z; S.w += g[q].w;
+                                if (js[q] >= (int)B) { Sb += gb[q]; ++nb_e; }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // final row: P = P0 - (S + s_k + n reg)   (momentum: V = mom V0 - (s_k + reg), P = P0 + n mom V0 - (S + s_k + n reg))
+    const float fn = (float)n;
+    const float p0[4] = {pz.x, pz.y, pz.z, pz.w}, v0[4] = {vz.x, vz.y, vz.z, vz.w}, sl[4] = {sk.x, sk.y, sk.z, sk.w};
+    const float ss[4] = {S.x + sk.x, S.y + sk.y, S.z + sk.z, S.w + sk.w};
+    float pn[4], vn[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float reg = (lmbd > 0.f) ? lr * lmbd * p0[e] : 0.f;
+        const float tot = (lmbd > 0.f) ? ss[e] + fn * reg : ss[e];
+        if (MOM) { vn[e] = momc * v0[e] - (sl[e] + reg); pn[e] = p0[e] + (fn * (momc * v0[e]) - tot); }
+        else { vn[e] = 0.f; pn[e] = p0[e] - tot; }
+    }
+    float bn = 0.f, bvn = 0.f;
+    if (bias) {
+        const float fb = (float)(nb_e + 1);
+        const float reg = (lmbd > 0.f) ? lr * lmbd * bpz : 0.f;
+        const float sb = Sb + bsk;
+        const float tot = (lmbd > 0.f) ? sb + fb * reg : sb;
+        if (MOM) { bn = bpz + (fb * (momc * bvz) - tot); bvn = momc * bvz - (bsk + reg); }
+        else bn = bpz - tot;
+    }
+    // the last occurrence's accumulator row (repeated items only: a single's accumulator was written in place by the producer of its step row)
+    float4 ak = make_float4(0.f, 0.f, 0.f, 0.f);
+    float bak = 0.f;
+    if (n > 1) {
+        const GAS float* arow = (k < B) ? a.dAx + (size_t)k * W : a.dAy + (size_t)(k - B) * W;
+        ak = ld4(arow + 4 * c4);
+        if (bias) bak = a.dABy[k - B];
+    }
+    lean_keep(bn); lean_keep(bvn); lean_keep(bak);
+    const size_t o = (size_t)item * W + 4 * c4;
+    if (lok) {
+        st4(P + o, make_float4(pn[0], pn[1], pn[2], pn[3]));
+        if (MOM) st4(V + o, make_float4(vn[0], vn[1], vn[2], vn[3]));
+        if (n > 1) st4(A + o, ak);
+    }
+    if (bias && lane == 0) {
+        a.By[item] = bn;
+        if (MOM) a.velBy[item] = bvn;
+        if (n > 1) a.accBy[item] = bak;
+    }
+}
+
+template <bool MOM>
+__device__ __forceinline__ void lean_dense_tile(const LeanU& a, const DenseTile* tiles_, unsigned tile, unsigned B) {
+    __shared__ f32x4 sJ[4 * 8 * 64];
+    const unsigned tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const unsigned wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const GAS DenseTile* tiles = (const GAS DenseTile*)tiles_;
+    const DenseTile tl = tiles[tile];      // 16 rows (r0 ..) x 64 columns (c0 ..), fully resolved on the host
+    // (g, M) of THIS step out of StepState::*_b: the staged copy behind cur_in is being rewritten for the next step by this launch's own
+    // bookkeeping workgroup
+    const GAS StepState* sg = (const GAS StepState*)a.st;
+    const long long g_ = sg->g_b;
+    const int M = sg->M_b;
+    const unsigned row = tl.r0 + li, rowc = min(row, (unsigned)tl.nrows - 1);
+    const unsigned cq = tl.c0 + 4 * li, cqc = min(cq, (unsigned)tl.ncols - 4);      // A operand: dV columns cq .. cq + 3 (output index i <-> column c0 + 4 i + c)
+    // both parities of X (H ping-pong) are requested; gather = 1: the step's input rows as the GRU saw them (yin0); X0 == null: the ones row of dBh
+    const bool ones = tl.X0 == nullptr && !tl.gather;
+    const GAS float* Xa = tl.gather ? a.yin0 : (ones ? tl.dV : tl.X0);
+    const GAS float* Xb = tl.gather ? a.yin0 : (ones ? tl.dV : tl.X1);
+    float4 av[4];
+    float x0[4], x1[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+        const unsigned b = min(16 * wid + 4 * s_ + lg, B - 1);
+        av[s_] = ldu4(tl.dV, 4 * (b * (unsigned)tl.ldv + (unsigned)tl.coff + cqc));
+        const unsigned ox = ones ? 0u : 4 * (b * (unsigned)tl.ldx + rowc);
+        x0[s_] = ldu(Xa, ox); x1[s_] = ldu(Xb, ox);
+    }
+    // epilogue operands of wave rg: accumulator / parameter (/ velocity) quads of (row r0 + li, columns c0 + 16 lg + 4 rg ..)
+    const unsigned ce = tl.c0 + 16 * lg + 4 * (wid & 3), cec = min(ce, (unsigned)tl.ncols - 4);
+    const size_t off = (size_t)tl.base + (size_t)rowc * tl.ldo + cec;
+    const float4 acc4 = ld4(a.dense_acc + off), p4 = ld4(a.dense_p + off);
+    float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MOM) v4 = ld4(a.dense_vel + off);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool odd = (g_ & 1) != 0;
+    f32x4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+        const unsigned b = 16 * wid + 4 * s_ + lg;
+        const bool bok = (int)b < M;
+        float xv = ones ? 1.f : (odd ? x1[s_] : x0[s_]);
+        if (!(bok && row < (unsigned)tl.nrows)) xv = 0.f;
+        const float4 d4 = (cq < (unsigned)tl.ncols) ? av[s_] : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc[0] = mfma16(d4.x, xv, acc[0]);
+        acc[1] = mfma16(d4.y, xv, acc[1]);
+        acc[2] = mfma16(d4.z, xv, acc[2]);
+        acc[3] = mfma16(d4.w, xv, acc[3]);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) sJ[(rg * 8 + wid) * 64 + lane] = (f32x4){acc[0][rg], acc[1][rg], acc[2][rg], acc[3][rg]};
+    __syncthreads();
+    if (wid >= 4) return;
+    f32x4 g4 = sJ[(wid * 8 + 0) * 64 + lane];      // batch slices in wave order
+#pragma unroll
+    for (int w = 1; w < 8; ++w) g4 += sJ[(wid * 8 + w) * 64 + lane];
+    if (row >= (unsigned)tl.nrows || ce >= (unsigned)tl.ncols) return;
+    const float gg[4] = {g4[0], g4[1], g4[2], g4[3]}, a0[4] = {acc4.x, acc4.y, acc4.z, acc4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+    float an[4], pn[4], vn[4];
+    const float lr = a.lr, momc = a.mom, lmbd = a.lmbd;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {      // gru4rec.py:330-334,390-406
+        an[c] = a0[c] + G4R_MUT_DACC(gg[c] * gg[c]);
+        const float gs = gg[c] * frsq(an[c] + G4R_EPS_ADAGRAD);
+        if (MOM) { vn[c] = momc * vv[c] - lr * (gs + lmbd * pp[c]); pn[c] = pp[c] + vn[c]; }
+        else { vn[c] = 0.f; pn[c] = pp[c] * (1.0f - lr * lmbd) - lr * gs; }
+    }
+    st4(a.dense_acc + off, make_float4(an[0], an[1], an[2], an[3]));
+    st4(a.dense_p + off, make_float4(pn[0], pn[1], pn[2], pn[3]));
+    if (MOM) st4(a.dense_vel + off, make_float4(vn[0], vn[1], vn[2], vn[3]));
+}
+
+// Step bookkeeping over 1 + ceil(ldSc / 512) workgroups (k_update's single bookkeeping workgroup took 4.1 us -- the longest path of the
+// launch, tools/clk_lean.py: state -> M of the next step -> row of in_idx -> columns in passes, with a lazily loaded descriptor field in
+// front of each): part 0 folds the row losses into loss_steps[t] (cost = sum_i L_i / batch_size, gru4rec.py:577; NaN flag, :626),
+// advances StepState::*_a and stages the next step's in_idx row, reset flags and (g, M, t); part p >= 1 stages 512 entries of the next
+// step's column -> item list (targets | -1 | its row of the sample store | -1: stage_step_inputs' rule).  Every part reads the state
+// and then has ONE round trip of loads.
+__device__ __forceinline__ void lean_bookkeep(const LeanU& a, unsigned part, unsigned B) {
+    const DevModel& m = *a.mp;
+    const unsigned tid = threadIdx.x;
+    const GAS StepState* sg = (const GAS StepState*)a.st;
+    const long long t = sg->t_b, g = sg->g_b;
+    const int M = sg->M_b;
+    const GAS int *in_idx = m.in_idx, *out_idx = m.out_idx, *Mplan = m.Mplan, *ST = m.ST;
+    const GAS unsigned char* reset = m.reset;
+    const int gl = m.gl, ns = m.ns, N = m.N, ld = m.ldSc;
+    GAS int *ci = m.cur_in, *cc = m.cur_col;
+    GAS float* loss_steps = m.loss_steps;
+    const GAS float* lossrow = m.lossrow;
+    const float inv_B = m.inv_B;
+    lean_pin(in_idx, out_idx, Mplan, ST, reset, gl, ns, N, ld, ci, cc, loss_steps, lossrow, inv_B);
+    const long long t1 = t + 1, g1 = g + 1;
+    const int Mn = Mplan[t1];      // (the plan carries one trailing entry and one trailing row)
+    if (part == 0) {
+        if (tid < 64) {
+            float s_ = 0.f;
+            for (int i = (int)tid; i < M; i += 64) s_ += lossrow[i];
+            s_ = wave_sum(s_);
+            if (tid == 0) {
+                const float cost = s_ * inv_B;
+                loss_steps[t] = cost;
+                GAS StepState* sw = (GAS StepState*)a.st;
+                if (isnan(cost)) sw->nan_flag = 1;
+                sw->t_a = t1; sw->g_a = g1; sw->M_a = Mn;
+                ci[2 * B] = (int)(unsigned)g1; ci[2 * B + 1] = (int)(g1 >> 32); ci[2 * B + 2] = Mn; ci[2 * B + 3] = (int)(unsigned)t1; ci[2 * B + 4] = (int)(t1 >> 32);
+            }
+        } else if (tid - 64 < B) {
+            const unsigned b = tid - 64;
+            ci[b] = in_idx[t1 * B + b];
+            ci[B + b] = reset[t1 * B + b];
+        }
+        return;
+    }
+    const int n = 512 * (int)(part - 1) + (int)tid;
+    const int vo = out_idx[t1 * B + min(n, (int)B - 1)];
+    const int vs = (ns > 0) ? ST[(size_t)(gl > 0 ? g1 % gl : 0) * ns + min(max(n - (int)B, 0), ns - 1)] : -1;
+    if (n < ld) cc[n] = (n < Mn) ? vo : (n >= (int)B && n < N && Mn > 0) ? vs : -1;      // Mn = 0: padding step of a multi-rank plan, nothing is touched
+}
+
+// workgroups [0, nbk): bookkeeping; [nbk, nbk + ntiles): dense tiles; the rest: eight occurrences each.
+// packA = ntiles | nblk << 16, packB = R | B << 16, nbk = 1 + ceil(ldSc / 512).
+template <bool MOM>
+__global__ __launch_bounds__(512) void k_update_l(const LeanU* __restrict__ ap, const DenseTile* __restrict__ tiles_, const int* occ_idx_, int* occ_fl_,
+                                                  const float* dSx_, const float* dSy_, const float* dSBy_, unsigned packA, unsigned packB, unsigned nbk) {
+    const unsigned ntiles = packA & 0xFFFFu, nblk = packA >> 16, R = packB & 0xFFFFu, B = packB >> 16;
+    const LeanU a = *ap;
+    LSPAN_BEGIN(a.dbgtile, 2700);
+    if (blockIdx.x < nbk) { lean_bookkeep(a, blockIdx.x, B); LSPAN_END(); return; }
+    const unsigned b = blockIdx.x - nbk;
+    if (b < ntiles) { lean_dense_tile<MOM>(a, tiles_, b, B); LSPAN_END(); return; }
+    // occurrences strided over the workgroups (wave w of workgroup q takes k = w nblk + q: the owners of the popular items -- the LAST
+    // occurrences, with their duplicate sums -- sit together at the end of the list; contiguous, they would share a few workgroups)
+    const unsigned q = b - ntiles, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    lean_rows_update<MOM>(a, (const GAS int*)occ_idx_, (GAS int*)occ_fl_, (const GAS float*)dSx_, (const GAS float*)dSy_, (const GAS float*)dSBy_, wid * nblk + q, R, B);
+    LSPAN_END();
+}
+template __global__ void k_update_l<false>(const LeanU*, const DenseTile*, const int*, int*, const float*, const float*, const float*, unsigned, unsigned, unsigned);
+template __global__ void k_update_l<true>(const LeanU*, const DenseTile*, const int*, int*, const float*, const float*, const float*, unsigned, unsigned, unsigned);

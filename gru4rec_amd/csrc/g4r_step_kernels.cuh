@@ -97,8 +97,8 @@ struct GruFwdPredict {
 #include "g4r_fwd_kernels.cuh"
 #include "g4r_loss_kernel.cuh"
 #include "g4r_bwd_kernels.cuh"
-#include "g4r_lean_kernels.cuh"
 #include "g4r_update_kernels.cuh"
+#include "g4r_lean_kernels.cuh"
 
 // ---------------------------------------------------------------------------------------------
 // Negative-sample store refill: ST[e] = upper_bound(P, u_e) with the end clamps of the reference's

@@ -428,8 +428,10 @@ def test_multirank_data_path_on_one_gpu(monkeypatch):
         outs.append((m.get_losses(0, T), m.get_param('Wy', (I, 16)), m.get_param('Wx', (16, 48), 0),
                      m.get_param('Bh', (48,), 0), m.get_param('acc_Wh', (16, 16), 0)))
         m.close()
+    # (the two paths run different dense-gradient tiles -- k_update_l's 16 x 64 register-fed tiles against k_dense_grad's LDS-staged
+    # 32 x 32 ones since round 6 --, i.e. different fp32 summation orders over the batch: equal to rounding, not to the bit)
     for a, b in zip(outs[0], outs[1]):
-        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-6)
 
 
 def test_epoch_with_real_schedule_and_compaction():

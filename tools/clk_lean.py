@@ -30,6 +30,7 @@ for rep in range(5):
     ld = (N_ + 15) // 16 * 16
     regions = [('k_gru_v', 1024, 3 * ((D_ + 15) // 16) * ((B_ + 15) // 16)), ('k_gru_h', 1280, ((D_ + 15) // 16) * ((B_ + 15) // 16)),
                ('k_score_s', 4096, ((ld + 31) // 32) * ((B_ + 31) // 32)), ('k_score_b', 2048, ((ld + 15) // 16) * ((D_ + 64) // 64) + ((ld + 127) // 128) * ((B_ + 15) // 16) * ((D_ + 63) // 64)),
+               ('k_update_l', 2700, 6 + 82 + (2 * B_ + cfg['n_sample'] + 7) // 8),
                ('k_gru_da', 1400, ((D_ + 15) // 16) * ((B_ + 15) // 16)), ('k_gru_dy', 1500, ((D_ + 15) // 16) * ((B_ + 15) // 16))]
     t0 = None
     for name, base, n in regions:
@@ -42,3 +43,15 @@ for rep in range(5):
         d = (t[:, 1] - t[:, 0]) / 100.
         print('   %-10s %4d workgroups: first stamp at %+6.2f .. %+6.2f us, last stamp at %+6.2f .. %+6.2f us (after k_gru_v began); own duration median %.2f max %.2f' % (
             name, len(t), (t[:, 0].min() - t0) / 100., (t[:, 0].max() - t0) / 100., (t[:, 1].min() - t0) / 100., (t[:, 1].max() - t0) / 100., np.median(d), d.max()))
+    if True:
+        nt = 82
+        nbk = 1 + (ld + 511) // 512
+        t = tl_all[2700:2700 + nbk + nt + (2 * B_ + cfg['n_sample'] + 7) // 8]
+        ok = t[:, 1] > 0
+        t0u = t[ok][:, 0].min()
+        for nm, sl in (('bookkeeping', slice(0, nbk)), ('dense tiles', slice(nbk, nbk + nt)), ('row workgroups (wave 0)', slice(nbk + nt, None))):
+            tt = t[sl]; tt = tt[tt[:, 1] > 0]
+            if len(tt):
+                print('      k_update_l %-24s %4d: start %+5.2f .. %+5.2f, end %+5.2f .. %+5.2f us; own duration median %.2f max %.2f' % (
+                    nm, len(tt), (tt[:, 0].min() - t0u) / 100., (tt[:, 0].max() - t0u) / 100., (tt[:, 1].min() - t0u) / 100., (tt[:, 1].max() - t0u) / 100.,
+                    np.median((tt[:, 1] - tt[:, 0]) / 100.), ((tt[:, 1] - tt[:, 0]) / 100.).max()))
