@@ -379,7 +379,7 @@ __global__ __launch_bounds__(128) void k_gru_da(const LeanDa* __restrict__ ap, c
     for (int q = 0; q < 4; ++q) bq[q] = ldu4((const GAS float*)Wh_, 4 * (min(16 * (4 * wid + q) + li, D - 1) * D + colc));
     const LeanDa a = *ap;
     lean_pin(a.dV, a.drp, a.seed, a.hidden_act, a.stream, a.ha_p0, a.ha_p1, a.drop_h, a.dbg);
-    LCLK_INIT(a.dbg, 32); LCLK(1);
+    LCLK_INIT((GAS long long*)nullptr, 32); LCLK(1);
     LSPAN_BEGIN(a.dbgtile, 1400);
     float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -472,6 +472,13 @@ __global__ __launch_bounds__(1024) void k_gru_dy(const LeanDy* __restrict__ ap, 
     const unsigned ncol = 16 * blockIdx.x + li, nc = min(ncol, IN - 1);
     const unsigned rowe = m0 + 4 * lg + (wid & 3);     // epilogue of waves 0 .. 3: component rg = wave
     const GAS float* Wx = (const GAS float*)Wx_;
+#if defined(G4R_CLK_TRACE)
+    const long long tk0 = wall_clock64();
+    GAS long long* ck = nullptr;
+#define DYCK(i) do { if (ck) ck[i] = wall_clock64(); } while (0)
+#else
+#define DYCK(i)
+#endif
     f32x4 acc;
     int4 mt;
     float a2 = 0.f;
@@ -490,12 +497,19 @@ __global__ __launch_bounds__(1024) void k_gru_dy(const LeanDy* __restrict__ ap, 
         const float4 b0 = ldu4(Wx, offw + 16 * Qa), b1 = ldu4(Wx, offw + 16 * Qb);
         const LeanDy a = *ap;
         lean_pin(a.accT, a.occ_fl, a.n_items, a.layer0);
+#if defined(G4R_CLK_TRACE)
+        ck = (a.dbg && blockIdx.x == 1 && blockIdx.y == 1 && tid == 0) ? a.dbg + 32 : nullptr;
+        if (ck) ck[0] = tk0;
+#endif
+        DYCK(1);
         if (a.layer0 && wid < 4) {      // -> the item's accumulator element, its occurrence count
             const unsigned ic = min((unsigned)max(itm, 0), (unsigned)a.n_items - 1);      // (rows past M hold an old id: clamped, unused)
             a2 = a.accT[(size_t)ic * IN + nc];
             cnt2 = a.occ_fl[4 * (size_t)ic + 2];
         }
+        DYCK(2);
         sx = lean_state(mt);
+        DYCK(3);
         const bool rowok = (int)row < sx.M;
         if (!(ok0 && rowok)) a0 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!(ok1 && rowok)) a1 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -509,6 +523,9 @@ __global__ __launch_bounds__(1024) void k_gru_dy(const LeanDy* __restrict__ ap, 
         acc0 = mfma16(a1.z, b1.z, acc0);
         acc1 = mfma16(a1.w, b1.w, acc1);
         acc = acc0 + acc1;
+#if defined(G4R_CLK_TRACE)
+        if (ck) { if (acc[0] == 123.4f) ck[15] = 0; ck[4] = wall_clock64(); }
+#endif
     } else {
         // ---- dr' part: planes of k_gru_da -> (sum) * H * r (1 - r)
         mt = ldi4((const GAS int*)meta_);
@@ -523,6 +540,11 @@ __global__ __launch_bounds__(1024) void k_gru_dy(const LeanDy* __restrict__ ap, 
         const float4 b0 = ldu4(Wx, 4 * (nc * 3 * D + D) + 16 * Qa);
         const LeanDy a = *ap;
         lean_pin(a.H0, a.H1, a.dV);
+#if defined(G4R_CLK_TRACE)
+        ck = (a.dbg && blockIdx.x == 1 && blockIdx.y == 1 && tid == 512) ? a.dbg + 40 : nullptr;
+        if (ck) ck[0] = tk0;
+#endif
+        DYCK(1);
         const float4 h40 = ldu4(a.H0, offr), h41 = ldu4(a.H1, offr);
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -530,6 +552,7 @@ __global__ __launch_bounds__(1024) void k_gru_dy(const LeanDy* __restrict__ ap, 
             const float w = ((unsigned)q < NTD) ? 1.f : 0.f;
             s.x = fmaf(w, pv[q].x, s.x); s.y = fmaf(w, pv[q].y, s.y); s.z = fmaf(w, pv[q].z, s.z); s.w = fmaf(w, pv[q].w, s.w);
         }
+        DYCK(2);
         sx = lean_state(mt);
         const float4 h4 = (sx.g & 1u) ? h41 : h40;
         s.x *= h4.x * r4.x * (1.f - r4.x); s.y *= h4.y * r4.y * (1.f - r4.y);
@@ -543,6 +566,9 @@ __global__ __launch_bounds__(1024) void k_gru_dy(const LeanDy* __restrict__ ap, 
         acc0 = mfma16(s.z, b0.z, acc0);
         acc1 = mfma16(s.w, b0.w, acc1);
         acc = acc0 + acc1;
+#if defined(G4R_CLK_TRACE)
+        if (ck) { if (acc[0] == 123.4f) ck[7] = 0; ck[3] = wall_clock64(); }
+#endif
     }
     const int M = sx.M;
     if ((int)m0 >= M) return;      // (uniform over the workgroup: no wave is left at the barrier)

@@ -6,25 +6,30 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 cfg = bench.CONFIGS[os.environ.get('CFG', 'cfg2')]
 plan, support = bench.make_plan(cfg, 400, 0, 1)
-m = bench.create_model(cfg, support, 0, 1, 0, None, use_graph=False)
+GRAPH = bool(os.environ.get('GRAPH'))
+m = bench.create_model(cfg, support, 0, 1, 0, None, use_graph=GRAPH)
 for k in ('in_idx', 'out_idx', 'reset', 'M'):
     plan[k] = plan[k][:400]
 plan['T'] = 400; plan['n_compact'] = 0
 m.set_plan(plan); m.reset_hidden()
 m.train_steps(0, 200)
 for rep in range(5):
-    m.train_steps(200 + rep, 1)
+    if GRAPH:
+        m.train_steps(200 + 16 * rep, 16)      # one replay of the 16-step graph: the stamps are those of its last step
+    else:
+        m.train_steps(200 + rep, 1)
     R = 2 * cfg['batch_size'] + cfg['n_sample']
     raw = m.get_debug('dbgclk', (2 * (64 + 8 * R),)).view(np.int64)
     def show(name, v, idx):
         v = np.asarray(v, dtype=np.int64)
         t0 = v[idx[0]]
-        print('%-9s stamps (us after stamp %d): ' % (name, idx[0]) + '  '.join('[%d] %.2f' % (i, (v[i] - t0) / 100.) for i in idx[1:]))
-    show('score_b role A wg 21', raw[0:16], [0, 1, 2, 3, 4, 5])
-    show('score_b role B wg 21', raw[16:32], [0, 1, 2, 3, 4, 5])
-    show('k_gru_da', raw[32:48], [1, 2, 3, 4, 5, 6])
-    show('k_gru_dy', raw[48:64], [6, 7])
-    show('k_score_s', raw[56:64], [0, 1, 2, 3, 4, 5])
+        print('%s: stamps (us after stamp %d): ' % (name, idx[0]) + '  '.join('[%d] %.2f' % (i, (v[i] - t0) / 100.) for i in idx[1:]))
+    show('k_gru_v (args pinned | y requested | m0 < M | masks | MFMAs | barrier | end)', raw[0:16], [1, 2, 3, 4, 5, 6, 7])
+    show('k_gru_h (args pinned | m0 < M | MFMAs | barrier | end)', raw[16:32], [1, 2, 5, 6, 7])
+    show('k_gru_dy wave 0 (start | args pinned | gathers requested | state | MFMAs)', raw[32:40], [0, 1, 2, 3, 4])
+    show('k_gru_dy wave 8 (start | args pinned | H requested | MFMAs)', raw[40:48], [0, 1, 2, 3])
+    show('k_gru_dy epilogue', raw[48:64], [6, 7])
+    show('k_score_s (args pinned | gathers requested | m0 < M | MFMAs | barrier | end)', raw[56:64], [0, 1, 2, 3, 4, 5])
     tl_all = m.get_debug('dbgtile', (2 * 8 * 8192,)).view(np.int64).reshape(8192, 8)
     B_, N_, D_ = cfg['batch_size'], cfg['batch_size'] + cfg['n_sample'], cfg['layers'][-1]
     ld = (N_ + 15) // 16 * 16
