@@ -257,6 +257,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     // moves at BASELINE configs[2] -- but the step gets 2-5 % SLOWER, because the update launch it relieves is at its latency floor
     // (cfg3: k_sparse_update 7.5 -> 6.2 us with 90 % of the rows gone) or bound by its dense-gradient tiles (cfg4), and the flush
     // (2.9 / 7.4 us per step) and scan (0.7 / 1.1) come on top (profiles/r05_experiments.md #7).
+    m->lean_upd = env_int("G4R_LEAN_UPDATE", 1) != 0;
     m->defer_on = d.apply_dense_inplace && !d.generic && cfg->momentum <= 0.f && cfg->lmbd == 0.f && env_int("G4R_DEFER", cfg->defer_updates) != 0;
     if (m->defer_on) {
         const size_t W = G4R_DEFER_SLOTS;
@@ -437,6 +438,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_k64, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_t2, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_t3, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_score_mt_4s, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd_n, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_fwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));

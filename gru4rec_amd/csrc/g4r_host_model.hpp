@@ -66,6 +66,7 @@ struct g4r_model {
     struct WideGeo { int use = 0, ny = 1, nh = 1, kys = 0, khs = 0, bbn = 1, bbk = 0; };
     WideGeo wg[G4R_MAX_LAYERS];
     bool wide_dense = false;
+    bool lean_upd = true;        // k_update_l allowed (G4R_LEAN_UPDATE=0 at create: the merged k_update, as the deferred mode runs it -- the reference run of tests/test_gpu_defer.py)
     bool defer_on = false;       // deferred row updates (k_defer_scan / k_sparse_flush around every replay of the step graph)
     bool defer_broken = false;   // a call failed between a window's scan and its flush: pending row updates were lost, the handle refuses to go on
     hipEvent_t ev_df[4] = {nullptr, nullptr, nullptr, nullptr};      // profiling: scan / flush launches of a window
@@ -237,6 +238,19 @@ static inline bool score_fwd_dma(const DevModel& d) {
     return wide_scores(d) || (d.Dtop >= 256 && d.B >= 64 && d.ldSc >= 1024);
 }
 static const size_t SMEM_SF = tile_smem<SF_BM, GT_BN, GT_BK, false, true>() + GT_BN * sizeof(int);
+// macro-tile scoring forward (k_score_mt, g4r_score_mt.cuh): the score matrix cut into at most n_cu tiles of 64 rows x W = 64 NB + 16
+// columns, one per compute unit.  Applies when that W is one of the instantiated widths: returns W (0: the 64 x 64 tiles).
+// G4R_NO_MT=1: off (A/B runs).
+static constexpr auto k_score_mt_4s = k_score_mt<4, true>;       // W = 272: B = 512, N = 8704 on 256 CUs
+static const size_t SMEM_MT_4S = (size_t)MtCfg<4, true>::SMEM_FLOATS * sizeof(float);
+static inline int score_mt_width(const DevModel& d, int n_cu) {
+    static const bool off = getenv("G4R_NO_MT") != nullptr;
+    if (off || !score_fwd_dma(d) || d.Dtop % 16 != 0) return 0;
+    const int nrb = cdiv(d.B, 64), G = n_cu / nrb;
+    if (G < 1) return 0;
+    const int W = 16 * cdiv(d.ldSc, 16 * G);
+    return (W == 272 && nrb * cdiv(d.ldSc, W) * 8 >= n_cu * 7) ? W : 0;      // (tiles for >= 7/8 of the CUs)
+}
 // scoring forward as register-fed 32 x 32 tiles (k_score_s, g4r_lean_kernels.cuh): narrow top layers at RSC15-like sizes, i.e. where the
 // LDS-staged 64 x 32 tiles of k_score_fwd ran (neither the wide-score nor the LDS-DMA tiles apply).  G4R_NO_LEAN=1: off.
 static inline bool lean_scores(const DevModel& d) {

@@ -95,6 +95,7 @@ struct GruFwdPredict {
 #endif
 
 #include "g4r_fwd_kernels.cuh"
+#include "g4r_score_mt.cuh"
 #include "g4r_loss_kernel.cuh"
 #include "g4r_bwd_kernels.cuh"
 #include "g4r_update_kernels.cuh"

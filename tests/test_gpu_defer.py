@@ -1,7 +1,8 @@
 """Deferred row updates (g4r_update_kernels.cuh: k_defer_scan / k_sparse_flush): a row whose item is not gathered again before the end of
 the current window of steps (one replay of the step graph) is applied by the window's flush launch instead of by its step's update
 launch.  The claim is EXACTNESS: same operands, same arithmetic, so every loss, parameter and accumulator has the same BITS as with
-G4R_DEFER=0 -- across windows, call boundaries, sample-store refills inside a call, batch tails, catalogues small enough that most
+G4R_DEFER=0 on the same update kernel (the deferred mode runs the merged k_update; where the immediate mode would take k_update_l, whose
+dense tiles add the batch in another order, the reference run sets G4R_LEAN_UPDATE=0) -- across windows, call boundaries, sample-store refills inside a call, batch tails, catalogues small enough that most
 items are gathered again right away, two item tables, one-hot input, two layers.  (Integer-exact comparison: assert_array_equal.)"""
 import os
 
@@ -11,6 +12,11 @@ import pytest
 from test_gpu_parity import make_pair, random_plan
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _merged_update_in_both_runs(monkeypatch):
+    monkeypatch.setenv('G4R_LEAN_UPDATE', '0')      # read by g4r_create: immediate and deferred runs on the merged k_update
 
 CASES = {
     # name: (I, B, ns, T, store_rows, calls, kwargs)

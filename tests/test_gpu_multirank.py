@@ -40,7 +40,9 @@ def test_padding_steps_touch_nothing(monkeypatch, staged):
 
 def test_staged_path_replays_from_a_graph_that_holds_the_allreduce(monkeypatch):
     """N > 1 data path with a one-rank communicator: gradient staging -> RCCL all-reduce -> k_dense_apply, 16 whole steps per
-    graph replay (the all-reduce is captured), against the fused single-GPU step."""
+    graph replay (the all-reduce is captured), against the fused single-GPU step (on the merged k_update, whose dense tiles add the batch
+    in the order of the staged gradients; k_update_l's order differs in the last bits: tests/test_gpu_parity.py compares that one)."""
+    monkeypatch.setenv('G4R_LEAN_UPDATE', '0')
     kw = CASES['bprmax_mom_drop']
     I, B, ns, T = 80, 12, 24, 70
     plan = random_plan(I, B, T, seed=17)
