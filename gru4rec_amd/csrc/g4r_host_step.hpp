@@ -117,7 +117,9 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
                               (const float*)d.Wy, (const float*)d.By, (float*)d.Sc, dimsA, dimsB);
         else LK(k_score_s<false>, gs, dim3(256), 0, s, (const LeanS*)m->d_leanS, (const int*)(d.cur_in + 2 * B), (const int*)d.cur_col, (const float*)d.hd[L - 1],
                 (const float*)d.Wy, (const float*)d.By, (float*)d.Sc, dimsA, dimsB);
-    } else if (score_mt_width(d, m->n_cu) == 272) LK(k_score_mt_4s, dim3(cdiv(B, 64) * cdiv(d.ldSc, 272)), dim3(256), SMEM_MT_4S, s, dmp, stp, cdiv(B, 64));
+    } else if (score_mt_width(d, m->n_cu) == 272) LK(k_score_mt_4s, dim3(cdiv(B, 64) * cdiv(d.ldSc, 272)), dim3(256), SMEM_MT_4S, s, (const int*)d.cur_col, (const int*)(d.cur_in + 2 * B),
+                                                       (const float*)d.hd[L - 1], (const float*)d.Wy, (const float*)d.zrow, dmp, (unsigned)d.Dtop | ((unsigned)cdiv(B, 64) << 16),
+                                                       (unsigned)d.N, (unsigned)d.ldSc, (unsigned)B);
     else if (score_fwd_dma(d)) LK(k_score_fwd_t3, dim3(cdiv(d.ldSc, 64), cdiv(B, 64)), dim3(GT_NTH), SMEM_SF3, s, dmp, stp);
     else if (wide_scores(d) && score_tile2() && d.Dtop % T2_BK == 0) LK(k_score_fwd_t2, dim3(cdiv(d.ldSc, 64), cdiv(B, 64)), dim3(GT_NTH), SMEM_SF2, s, dmp, stp);
     else if (wide_scores(d)) LK(k_score_fwd_k64, dim3(cdiv(d.ldSc, SFW_BN), cdiv(B, SF_BM)), dim3(GT_NTH), SMEM_SF64, s, dmp, stp);

@@ -80,6 +80,7 @@ struct GruFwdPredict {
     int M;
 };
 
+
 // Threads per GEMM workgroup.  Kernels whose grid is a few dozen tiles (one workgroup per CU, most CUs idle) run 8 waves:
 // two wave groups split each K chunk (g4r_gemm.cuh) so that two waves per SIMD overlap their issue / MFMA latencies
 // (measured: k_gru_p1 11.2 -> 8.9 us, k_gru_bwd_b 7.8 -> 6.6, k_dense_grad 5.5 -> 5.1).  The scoring kernels already
