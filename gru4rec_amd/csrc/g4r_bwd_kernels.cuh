@@ -206,6 +206,63 @@ __global__ __launch_bounds__(256, G4R_BWD2_WPE) void k_score_bwd2(const DevModel
     }
 }
 
+// The Adagrad rule for the item rows of the scoring backward, for launches whose role A left RAW gradient rows in the step plane
+// (k_score_bmt): g = dSy[n][:] -> acc' = acc + g^2, step = lr g / sqrt(acc' + eps); the step replaces g, acc' goes to the accumulator table in
+// place when the row's item occurs once in the step and to dAy[n] otherwise (k_score_bwd2's role-A epilogue; gru4rec.py:335-340).  A wave per
+// row, float4 per lane (D <= 512); workgroup `wg` of `nwg` takes the 16-row chunks wg, wg + nwg, ... (4 waves x 4 rows, every load of a chunk
+// in flight at once: the chain item -> accumulator row -> stores is latency, so the host gives every chunk a workgroup of its own).
+__device__ __forceinline__ void score_fin_rows(const DevModel& m, long long g_, int wg, int nwg) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int nw = 4;                   // (the launches that carry this role have 4 or 8 waves: the row partition must not depend on that)
+    if (w >= nw) return;
+    const int N = m.N, D = m.Dtop, D4 = D >> 2;
+    GAS float* dSy = G4R_DSY(m, g_);
+    GAS float *dAy = m.dAy, *accWy = m.accWy;
+    const GAS int *col_item = m.col_item, *occ_fl = m.occ_fl;
+    const float lr = m.lr;
+    const bool generic = m.generic != 0;
+    constexpr int UN = 4;
+    for (int r0 = (wg * nw + w) * UN; r0 < N; r0 += nwg * nw * UN) {
+        int item[UN], cnt[UN];
+        float4 g[UN][2], a0[UN][2];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) item[u] = col_item[min(r0 + u, N - 1)];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int n = min(r0 + u, N - 1);
+            cnt[u] = occ_fl[4 * (size_t)max(item[u], 0) + 2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int d4 = min(lane + 64 * q, D4 - 1);
+                g[u][q] = ld4(dSy + (size_t)n * D + 4 * d4);
+                a0[u][q] = ld4(accWy + (size_t)max(item[u], 0) * D + 4 * d4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int n = r0 + u;
+            if (n >= N) continue;
+            const bool ok = item[u] >= 0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int d4 = lane + 64 * q;
+                if (d4 >= D4) continue;
+                const float gv[4] = {g[u][q].x, g[u][q].y, g[u][q].z, g[u][q].w}, av[4] = {a0[u][q].x, a0[u][q].y, a0[u][q].z, a0[u][q].w};
+                float sv[4], nv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    nv[e] = av[e] + G4R_MUT_ACC(gv[e] * gv[e]);
+                    sv[e] = ok ? G4R_MUT_ROW(n, G4R_MUT_STEP(lr * gv[e] * frsq(nv[e] + G4R_EPS_ADAGRAD))) : 0.f;
+                    if (generic) sv[e] = ok ? gv[e] : 0.f;
+                }
+                st4(dSy + (size_t)n * D + 4 * d4, make_float4(sv[0], sv[1], sv[2], sv[3]));
+                if (!generic && ok && cnt[u] == 1) st4(accWy + (size_t)item[u] * D + 4 * d4, make_float4(nv[0], nv[1], nv[2], nv[3]));
+                else st4(dAy + (size_t)n * D + 4 * d4, make_float4(nv[0], nv[1], nv[2], nv[3]));
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // GRU backward (no BPTT: H is a constant input, gru4rec.py:460-463,576), element-wise head:
 //   dh = sum of split-K slabs (top layer) or the upper layer's dy ; hidden-dropout mask ;
@@ -254,11 +311,17 @@ __global__ __launch_bounds__(256) void k_gru_bwd_pre(const DevModel* __restrict_
 
 // dr' = (da Wh^T) * H * r (1 - r)  -> dV[:, D:2D]      (B provider reads Wh rows: B[k][n] = Wh[n][k])
 // (NTH / BK as for k_gru_p2)
+// nfin > 0 (top layer behind k_score_bmt): the grid has nfin extra rows of workgroups that finish the item rows of the scoring backward
+// (score_fin_rows: 16 rows each, one batch of loads) next to this launch's 128-odd tiles
 template <int NTH, int BK>
-__global__ __launch_bounds__(NTH) void k_gru_bwd_a(const DevModel* __restrict__ mp, StepState* st, int l) {
+__global__ __launch_bounds__(NTH) void k_gru_bwd_a(const DevModel* __restrict__ mp, StepState* st, int l, int nfin) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevModel& m = *mp;
     const StepCtx c = load_ctx(st);
+    if (nfin > 0 && (int)blockIdx.y >= (int)gridDim.y - nfin) {
+        score_fin_rows(m, c.g, ((int)blockIdx.y - ((int)gridDim.y - nfin)) * (int)gridDim.x + (int)blockIdx.x, nfin * (int)gridDim.x);
+        return;
+    }
     const int M = c.M, D = m.D[l], D3 = 3 * D;
     const int m0 = blockIdx.y * GT_BM, n0 = blockIdx.x * GT_BN;
     if (m0 >= M) return;

@@ -273,7 +273,7 @@ template __global__ void k_gru_p1<GT_BN, P1_BK>(const DevModel*, StepState*, int
 template __global__ void k_gru_p1<64, 256>(const DevModel*, StepState*, int, int, int, GruFwdPredict);
 template __global__ void k_gru_p2<GT_NTH, GT_BK>(const DevModel*, StepState*, int, int, GruFwdPredict);
 template __global__ void k_gru_p2<512, 256>(const DevModel*, StepState*, int, int, GruFwdPredict);
-template __global__ void k_gru_bwd_a<GT_NTH, GT_BK>(const DevModel*, StepState*, int);
-template __global__ void k_gru_bwd_a<512, 256>(const DevModel*, StepState*, int);
+template __global__ void k_gru_bwd_a<GT_NTH, GT_BK>(const DevModel*, StepState*, int, int);
+template __global__ void k_gru_bwd_a<512, 256>(const DevModel*, StepState*, int, int);
 template __global__ void k_score_all<32, false>(const DevModel*, const float*, int, const int*, long long, float*, long long, int, int*, long long, const int*, unsigned);
 template __global__ void k_score_all<32, true>(const DevModel*, const float*, int, const int*, long long, float*, long long, int, int*, long long, const int*, unsigned);

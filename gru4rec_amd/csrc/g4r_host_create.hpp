@@ -298,6 +298,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
                 if (waste < best) { best = waste; d.kch = kch; }
             }
         }
+        if (score_bmt_slabs(d, m->n_cu)) d.kch = d.ldSc / score_bmt_slabs(d, m->n_cu);      // k_score_bmt: as many role-B as role-A tiles
         if (lean_score_bwd(d)) d.kch = 128;      // k_score_b: slabs of 128 score columns (eight waves x 16)
         d.ksplit = cdiv(d.ldSc, d.kch);
         DA(d.dhpart, (size_t)d.ksplit * B * d.Dtop);
@@ -439,6 +440,7 @@ int g4r_create(const g4r_config* cfg, g4r_model** out) {
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_t2, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_fwd_t3, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_mt_4s, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute((const void*)k_score_bmt, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_score_bwd_n, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_bwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute((const void*)k_gru_fwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big));

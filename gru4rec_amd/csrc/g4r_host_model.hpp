@@ -216,6 +216,19 @@ static inline bool score_tile2() { return true; }
 static inline bool wide_scores(const DevModel& d);
 // gemm_tile2k scoring backward (k_score_bwd2): long score rows / big batches and D a multiple of 64
 static inline bool score_bwd2(const DevModel& d) { return wide_scores(d) && score_tile2() && d.Dtop % 64 == 0; }
+// macro-tile scoring backward (k_score_bmt, g4r_score_bmt.cuh): role A in 272 x 32 tiles, role B in 64 x 128 tiles x `ks` slabs, as many
+// of each and together two per CU.  Returns ks (0: k_score_bwd2).  G4R_NO_BMT=1: off (A/B runs).
+static inline int score_bmt_slabs(const DevModel& d, int n_cu) {
+    static const bool off = getenv("G4R_NO_BMT") != nullptr;
+    if (off || !score_bwd2(d) || d.Dtop % 128 != 0 || d.Dtop > 512 || d.ldSc % BMT_WA != 0 || d.ldSc > 0xFFFF || d.B > 0xFFFF) return 0;
+    if (lean_gru(d, d.n_layers - 1) || fused_bwd(d, d.n_layers - 1)) return 0;      // (the Adagrad rule of the item rows rides on the top layer's k_gru_bwd_a)
+    const int ntA = d.ldSc / BMT_WA * (d.Dtop / 32), den = cdiv(d.B, 64) * (d.Dtop / 128);
+    if (ntA % den != 0 || ntA % 8 != 0 || ntA > n_cu || ntA * 8 < n_cu * 7 || BMT_WA % (d.Dtop / 32) != 0 || 4 * (BMT_WA / (d.Dtop / 32)) > 256) return 0;      // (bias columns: 272 / (D / 32) per tile, four threads each)
+    const int ks = ntA / den;
+    if (ks < 2 || ks > 24 || d.ldSc % ks != 0 || (d.ldSc / ks) % 32 != 0 || d.ldSc / ks > 2048) return 0;
+    return ks;
+}
+static const size_t SMEM_BMT = std::max((size_t)BMT_NST_A * BMT_STAGE_A * sizeof(float), (size_t)BMT_NST_B * BMT_STAGE_B * sizeof(float) + 2048 * sizeof(int));
 static const size_t SMEM_SF64 = tile_smem<SF_BM, SFW_BN, SFW_BK, false, true>() + SFW_BN * sizeof(int);
 static constexpr auto k_score_bwd_n = k_score_bwd<32, GT_BK>;
 static constexpr auto k_score_bwd_w = k_score_bwd<64, 64>;

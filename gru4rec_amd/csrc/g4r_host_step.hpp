@@ -148,6 +148,11 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         const LeanB& q = m->h_leanB;
         LK(k_score_b, dim3(q.nA + d.ksplit * q.nrb * q.ndb), dim3(512), 0, s, (const LeanB*)m->d_leanB, (const int*)(d.cur_in + 2 * B), (const int*)d.cur_col,
            (const float*)d.Sc, (const float*)d.hd[L - 1], (const float*)d.Wy, (float*)d.accWy, (unsigned)d.Dtop | ((unsigned)B << 16), (unsigned)d.N | ((unsigned)d.ldSc << 16));
+    } else if (score_bmt_slabs(d, m->n_cu)) {
+        const int ntile = d.ldSc / BMT_WA * (d.Dtop / 32);
+        LK(k_score_bmt, dim3(2 * ntile), dim3(256), SMEM_BMT, s, (const float*)d.Sc, (const float*)d.hd[L - 1], (const float*)d.Wy, (const int*)d.col_item,
+           (const int*)(d.cur_in + 2 * B), (const float*)d.zrow, dmp, (unsigned)d.Dtop | ((unsigned)(d.Dtop / 32) << 16), (unsigned)d.N | ((unsigned)d.ldSc << 16),
+           (unsigned)B | ((unsigned)d.kch << 16), (unsigned)cdiv(B, 64) | ((unsigned)(d.Dtop / 128) << 16));
     } else if (score_bwd2(d)) {
         const int ndt = d.Dtop / 64, nrt = cdiv(B, 64);
         int nA = cdiv(d.ldSc, 64) * ndt, nB = d.ksplit * nrt * ndt, nC = cdiv(d.ldSc, 64);
@@ -187,9 +192,13 @@ static int launch_step(g4r_model* m, std::vector<EvRec>* recs, int part = 0) {
         const int nrt64 = cdiv(B, 64);
         begin(KN_BWD_A);
         {
-            const dim3 ga(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM));
-            if (deep_geometry(m->ba_geo_env, m->n_cu, d.D[l], B)) LK(k_gru_bwd_a_w8d, ga, dim3(512), SMEM_BA_256, s, dmp, stp, l);
-            else LK(k_gru_bwd_a_w4, ga, dim3(GT_NTH), SMEM_NT, s, dmp, stp, l);
+            dim3 ga(cdiv(d.D[l], GT_BN), cdiv(B, GT_BM));
+            // behind k_score_bmt (raw gradient rows in the step plane) the top layer's launch carries their Adagrad rule: one extra
+            // workgroup per 16 item rows (score_fin_rows)
+            int nfin = 0;
+            if (l == L - 1 && score_bmt_slabs(d, m->n_cu)) { nfin = cdiv(cdiv(d.N, 16), (int)ga.x); ga.y += nfin; }
+            if (deep_geometry(m->ba_geo_env, m->n_cu, d.D[l], B)) LK(k_gru_bwd_a_w8d, ga, dim3(512), SMEM_BA_256, s, dmp, stp, l, nfin);
+            else LK(k_gru_bwd_a_w4, ga, dim3(GT_NTH), SMEM_NT, s, dmp, stp, l, nfin);
         }
         end();
         begin(KN_BWD_B);

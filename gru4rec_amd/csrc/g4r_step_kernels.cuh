@@ -99,6 +99,7 @@ struct GruFwdPredict {
 #include "g4r_score_mt.cuh"
 #include "g4r_loss_kernel.cuh"
 #include "g4r_bwd_kernels.cuh"
+#include "g4r_score_bmt.cuh"
 #include "g4r_update_kernels.cuh"
 #include "g4r_lean_kernels.cuh"
 
