@@ -108,6 +108,12 @@ def newest_profile(suffix):
     return hits[-1] if hits else os.path.join(ROOT, 'profiles', 'none_' + suffix)
 
 
+# device kernel name (rocprofv3) -> the launch slot bench.py / g4r_profile report it under
+KERNEL_ALIAS = {'k_score_s': 'k_score_fwd', 'k_score_mt': 'k_score_fwd', 'k_score_b': 'k_score_bwd', 'k_score_bmt': 'k_score_bwd', 'k_gru_fwd_fused': 'k_gru_fwd',
+                'k_gru_bwd_fused': 'k_gru_bwd', 'k_score_bwd2': 'k_score_bwd', 'k_gru_p1w': 'k_gru_p1', 'k_gru_p1s': 'k_gru_p1', 'k_gru_p2w': 'k_gru_p2',
+                'k_gru_bwd_aw': 'k_gru_bwd_a', 'k_gru_bwd_bw': 'k_gru_bwd_b', 'k_dense_grad2': 'k_dense_grad'}
+
+
 def rocprof_means(config):
     """{bench kernel name: mean us} from the tracked rocprofv3 --kernel-trace --stats CSV of this config (+ '__file__')."""
     import csv
@@ -115,8 +121,7 @@ def rocprof_means(config):
     if not os.path.exists(path):
         return {}
     out = {'__file__': os.path.relpath(path, ROOT)}
-    alias = {'k_score_s': 'k_score_fwd', 'k_score_b': 'k_score_bwd', 'k_gru_fwd_fused': 'k_gru_fwd', 'k_gru_bwd_fused': 'k_gru_bwd', 'k_score_bwd2': 'k_score_bwd', 'k_gru_p1w': 'k_gru_p1', 'k_gru_p1s': 'k_gru_p1', 'k_gru_p2w': 'k_gru_p2',
-             'k_gru_bwd_aw': 'k_gru_bwd_a', 'k_gru_bwd_bw': 'k_gru_bwd_b', 'k_dense_grad2': 'k_dense_grad'}
+    alias = KERNEL_ALIAS
     acc = {}
     for r in csv.DictReader(open(path)):
         name = r['Name'].split('(')[0].replace('void ', '').split('<')[0].strip()
@@ -617,7 +622,7 @@ def main():
 
         def traffic_of(name):      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_summary.py), bytes per launch
             for k, v in pmc.items():
-                if k == name or k.startswith(name):
+                if k == name or KERNEL_ALIAS.get(k) == name or k.startswith(name):
                     return v.get('traffic_bytes')
             return None
         pmc2_path = newest_profile('pmc_traffic_%s_no_merge.json' % args.config)
@@ -625,7 +630,7 @@ def main():
 
         def traffic_split(name):      # the same counters from the passes run with G4R_NO_MERGE=1 (the update launch as its two roles)
             for k, v in pmc2.items():
-                if k == name or k.startswith(name):
+                if k == name or KERNEL_ALIAS.get(k) == name or k.startswith(name):
                     return v.get('traffic_bytes')
             return None
         # the roofline entry: the DOMINANT kernel of the step (largest time per step), priced with its algorithmic flops / bytes

@@ -57,6 +57,7 @@ int g4r_get_debug(g4r_model* m, const char* name, float* host, int64_t count) {
         host[0] = (float)(deep_geometry(m->p2_geo_env, m->n_cu, d.D[0], d.B) + 2 * deep_geometry(m->ba_geo_env, m->n_cu, d.D[0], d.B)); return 0;
     }
     else if (s == "score_mt") { if (count < 1) return fail("count"); host[0] = (float)score_mt_width(d, m->n_cu); return 0; }      // macro-tile width of the scoring forward (0: 64 x 64 tiles)
+    else if (s == "score_bmt") { if (count < 1) return fail("count"); host[0] = (float)score_bmt_slabs(d, m->n_cu); return 0; }      // slabs of the macro-tile scoring backward (0: k_score_bwd2)
     else if (s == "ksplit") { if (count < 1) return fail("count"); host[0] = (float)d.ksplit; return 0; }
     else if (s == "dev_syncs") { if (count < 1) return fail("count"); host[0] = (float)m->n_dev_syncs; return 0; }
     else if (s == "dense_count") { if (count < 1) return fail("count"); host[0] = (float)d.dense_count; return 0; }

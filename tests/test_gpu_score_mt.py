@@ -1,5 +1,8 @@
-"""Oracle parity of the macro-tile scoring forward (k_score_mt, g4r_score_mt.cuh): the score matrix of B = 512, 8192 negatives cut
-into 256 tiles of 64 rows x 272 columns, one per compute unit.  Edges: steps whose live batch M ends inside a 64-row tile, inside a
+"""Oracle parity of the macro-tile scoring kernels.  Forward (k_score_mt, g4r_score_mt.cuh): the score matrix of B = 512, 8192 negatives cut
+into 256 tiles of 64 rows x 272 columns, one per compute unit.  Backward (k_score_bmt, g4r_score_bmt.cuh; D = 256): 256 tiles of 272 x 32
+of dS and 256 of 64 x 128 x 16 slabs of dh, the raw gradient rows finished by extra workgroups of k_gru_bwd_a, the bias gradient folded
+into the dS tiles -- same edges: batch rows past M read the zero row (K of dS), inactive columns, items that repeat (accumulator in place
+only for single occurrences).  Edges: steps whose live batch M ends inside a 64-row tile, inside a
 wave's 32-row block and inside the 16-row strip blocks (rows past M read the zero row and are not stored), the -1 items of the
 in-batch columns [M, B), items repeated between input and negatives, K = 64 (fewer stages than the ring holds: the counted waits of
 the prologue and of the tail) and K = 256 / 512 (steady iterations); cross-entropy with the logQ correction (the epilogue's second
@@ -23,6 +26,7 @@ def _run(tag, I, T, store_rows, D, **kw):
     B, ns = 512, 8192
     o, m = make_pair(I, B, ns, store_rows=store_rows, layers=(D,), constrained_embedding=True, **kw)
     assert m.get_debug('score_mt', 1)[0] == 272, 'the macro-tile kernel was not selected at B = 512, N = 8704'
+    assert (m.get_debug('score_bmt', 1)[0] == 16) == (D == 256), 'macro-tile backward: 16 slabs at D = 256, k_score_bwd2 elsewhere'
     plan = random_plan(I, B, T, seed=31, tail=True)
     plan['M'][:] = B
     plan['M'][1] = B - 37          # ends inside a 64-row tile and a 32-row block
@@ -51,7 +55,7 @@ def test_macro_tiles_cross_entropy_with_logq():
 
 
 def test_the_replaced_tiles_still_pass_the_exact_shape_test():
-    env = dict(os.environ, G4R_NO_MT='1')
+    env = dict(os.environ, G4R_NO_MT='1', G4R_NO_BMT='1')
     r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_baseline_configs.py::test_cfg4_exact_shape', '-x', '-q', '-p', 'no:cacheprovider'],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]

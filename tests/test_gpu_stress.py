@@ -6,7 +6,8 @@ chunk of a tile was written to LDS from registers whose loads might not have lan
 tests were green, and only the 10 GB-table test with three other processes on the GPU saw it.  That build is kept as mutation
 build 4 (gru4rec_amd/build.py; the only library built with the ISA audit switched off -- the audit flags it, tests/test_isa_audit.py).
 
-Here the same training steps (the cfg #4 tile shapes: gemm_tile2k in k_score_bwd2, gemm_tile3 in k_score_fwd, a 2 GB item table)
+Here the same training steps (the cfg #4 tile shapes: the macro-tile kernels k_score_mt / k_score_bmt with their counted LDS-DMA waits -- and,
+in the child run, gemm_tile2k in k_score_bwd2 --, a 2 GB item table)
 run twice, once on an idle GPU and once next to `MemoryStress` -- passes of a streaming read-modify-write over 6 GB on a second
 stream, which multiplies the load latencies the kernels see.  The product library must produce the same bits both times; the
 mutant must not (run in a child process with G4R_LIB pointing at it), which is what proves the load is heavy enough to expose
@@ -73,7 +74,7 @@ def test_the_stale_register_build_is_caught_under_load():
     paths = dict(zip(sorted(g4r_build.MUTANTS), g4r_build.build_mutants()))
     if 'G4R_LIB' in os.environ:
         pytest.skip('already inside a child run')
-    env = dict(os.environ, G4R_LIB=paths[4])
+    env = dict(os.environ, G4R_LIB=paths[4], G4R_NO_BMT='1')      # (the mutation sits in gemm_tile2k: k_score_bwd2, which k_score_bmt replaces at this shape)
     r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_stress.py::test_results_do_not_depend_on_memory_load', '-x', '-q',
                         '-p', 'no:cacheprovider'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 1 and 'differs between an idle and a loaded GPU' in (r.stdout + r.stderr), \
