@@ -100,8 +100,8 @@ __device__ __forceinline__ void mt_pipeline(int nchunk, int wid, int stage_float
 struct BmtFragA { float2 a[8]; float b[8]; float sa[2], sb[2]; float bs[4]; };
 struct BmtFragB { float4 a[2]; float2 b[8]; };
 
-// grid: 2 x ntile workgroups; workgroup id -> role (id >> 3) & 1, tile ((id >> 4) << 3) | (id & 7): every XCD (id mod 8) gets both
-// roles alternately.  Role A tile t (XCD-contiguous order) -> column group t / ndg, d group t % ndg; role B tile t -> slab t / (nrt * 2),
+// grid: 2 x ntile workgroups; workgroup id -> role ((id >> 3) ^ (id >> 8)) & 1, tile ((id >> 4) << 3) | (id & 7): every XCD (id mod 8) gets both
+// roles alternately, and its k-th and (k + 32)-th workgroup (the pair that shares a CU when the dispatcher deals one per CU first) one of each.  Role A tile t (XCD-contiguous order) -> column group t / ndg, d group t % ndg; role B tile t -> slab t / (nrt * 2),
 // row tile, d part of 128.  kch = slab depth (a multiple of 32), ntile = number of tiles of EACH role.
 __global__ __launch_bounds__(256, 2) void k_score_bmt(const float* __restrict__ ds_, const float* __restrict__ h_, const float* __restrict__ Wy_,
                                                       const int* __restrict__ item_, const int* __restrict__ meta_, const float* __restrict__ zrow_,
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void k_score_bmt(const float* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, lh = lane >> 5, li = lane & 15, lg = lane >> 4;
-    const int role = ((int)blockIdx.x >> 3) & 1;
+    const int role = (((int)blockIdx.x >> 3) ^ ((int)blockIdx.x >> 8)) & 1;      // (an XCD's k-th and (k + 32)-th workgroup -- the two a CU gets -- differ in role)
     const int ntile = (int)gridDim.x >> 1;
     const int tile = G4R_XCD_TILE((((int)blockIdx.x >> 4) << 3) | ((int)blockIdx.x & 7), ntile);
 #if defined(G4R_CLK_TRACE)
@@ -232,7 +232,14 @@ __global__ __launch_bounds__(256, 2) void k_score_bmt(const float* __restrict__ 
                 for (int j = 0; j < 4; ++j) { const int n = n0 + 256 + 4 * lg + j; if (n < N) dSy[(size_t)n * D + d0 + 16 * sb + li] = sacc[j]; }
             }
         }
-        if (trc && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[4] = wall_clock64(); }
+        if (trc && tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            trc[4] = wall_clock64();
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            trc[7] = (long long)hw | ((long long)(xcc & 0xF) << 32);
+        }
         return;
     }
     // ---------------------------------------------------------------------------------------------------- role B
@@ -299,7 +306,14 @@ __global__ __launch_bounds__(256, 2) void k_score_bmt(const float* __restrict__ 
             const int b = m0 + 32 * wm + 8 * (j >> 2) + 4 * lh + (j & 3);
             if (b < M) *reinterpret_cast<GAS float2*>(dhpart + ((size_t)kc * B + b) * D + d0 + 64 * wn + 2 * l32) = make_float2(acc0[j], acc1[j]);
         }
-        if (trc && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[4] = wall_clock64(); }
+        if (trc && tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            trc[4] = wall_clock64();
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            trc[7] = (long long)hw | ((long long)(xcc & 0xF) << 32);
+        }
     }
 }
 
