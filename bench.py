@@ -279,8 +279,12 @@ def large_catalogue_legs(timeout=150):
                 continue
             o = json.loads(line[-1])
             g = o.get('roofline_gather_scatter') or {}
+            kk = o.get('kernels') or {}
+            gemm = {n: {'avg_us': kk[n].get('avg_us'), 'achieved': kk[n].get('achieved'), 'unit': kk[n].get('unit'), 'frac_of_fp32_mfma_peak': kk[n].get('frac')}
+                    for n in ('k_score_fwd', 'k_score_bwd') if n in kk and kk[n].get('bound') == 'mfma'}
             res[key] = {'value': o['value'], 'unit': o['unit'], 'us_per_step': 1000.0 * o['ms_per_step'], 'steps': o['steps'],
                         'update_launch': {'kernel': g.get('kernel'), 'avg_us': g.get('avg_us'), 'frac_of_8TBps_on_survey_8d_bytes': g.get('frac')},
+                        'scoring_gemms': gemm,      # the macro-tile scoring kernels (k_score_mt / k_score_bmt), HIP events on the dispatches
                         'deferred_flush': g.get('deferred_flush')}
         except Exception as e:      # noqa: BLE001
             res[key] = {'error': '%s: %s' % (type(e).__name__, e)}
