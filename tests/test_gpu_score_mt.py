@@ -50,6 +50,14 @@ def test_macro_tiles_bprmax_ragged_batches(D):
     _run('mt bpr-max D=%d' % D, I=30000, T=4, store_rows=6, D=D, loss='bpr-max', final_act='elu-0.5', learning_rate=0.1, bpreg=1.0)
 
 
+@pytest.mark.parametrize('kw', [dict(adapt='rmsprop', adapt_params=[0.9], learning_rate=0.02), dict(momentum=0.1, learning_rate=0.1), dict(lmbd=1e-4, learning_rate=0.1)],
+                         ids=['rmsprop', 'adagrad_momentum', 'adagrad_l2'])
+def test_macro_tile_backward_with_the_other_update_rules(kw):
+    """k_score_bmt leaves RAW gradient rows behind and `score_fin_rows` (riding on k_gru_bwd_a) finishes them: the generic optimizers take the raw
+    gradient as the step, Adagrad with momentum / an L2 term takes the Adagrad step and leaves the rest to the update launch."""
+    _run('mt ' + '/'.join(sorted(kw)), I=30000, T=3, store_rows=5, D=256, loss='bpr-max', final_act='elu-0.5', bpreg=1.0, **kw)
+
+
 def test_macro_tiles_cross_entropy_with_logq():
     _run('mt xe logq', I=30000, T=4, store_rows=6, D=128, loss='cross-entropy', final_act='softmax', learning_rate=0.07, logq=1.0, sample_alpha=0.5)
 
