@@ -17,8 +17,8 @@
 //   * one wave per SIMD has nobody to hide behind: whatever it issues between two MFMAs -- the stage wait, the barrier, six DMA
 //     pieces, twelve fragment reads -- leaves the matrix pipe idle unless an MFMA is executing meanwhile (first version, everything in
 //     front of the stage's 36 MFMAs: 2850 clocks per stage against 2200 of MFMA issue).  So a stage's MFMAs run out of a register
-//     set filled one stage earlier, and the wait / barrier / DMA / reads of the next stage are dealt out BETWEEN its eight groups of
-//     four MFMAs (sched_barrier fences keep hipcc from regrouping them); the K loop is unrolled by two so that both register sets
+//     set filled one stage earlier, and the wait / barrier / DMA / reads of the next stage are dealt out ONE behind each of its MFMAs
+//     (sched_barrier fences keep hipcc from regrouping them); the K loop is unrolled by two so that both register sets
 //     are addressed statically;
 //   * the waits are the kernel's own counted `s_waitcnt vmcnt(n)` (hipcc does not see the DMA pieces): n = pieces of the stages that
 //     may stay in flight.  Other vector-memory operations of a wave only make such a wait more conservative (it retires in order),
@@ -29,6 +29,7 @@
 // vector-memory operations retire in order) sat in front of the first stage of the workgroups that had them.
 // The hot pointers and sizes are kernel arguments (preloaded into scalar registers) and M comes from the copy of the step state
 // staged behind cur_in (a vector load issued with the column items): nothing waits for the descriptor.
+// -DMT_X_NO_DMA / _NO_WAIT / _NO_READ / _NO_BAR: ablation builds (results garbage) behind the table in profiles/r06_experiments.md #9.
 #pragma once
 
 template <int NB, bool STRIP>
